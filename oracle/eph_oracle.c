@@ -1,0 +1,854 @@
+/* eph_oracle.c -- CPU ORACLE (test infrastructure, NOT product code). See eph_oracle.h.
+ *
+ * Plain-C restatement of the reference algorithm, in the reference's loop order, AoS double[3] vectors,
+ * compiled with -ffp-contract=off (Rust never fuses a*b+c). Each function cites the reference file:line
+ * (relative to /root/reference) that it follows.
+ */
+#include "eph_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Ratio  (integration/src/ratio.rs)                                                                */
+/* ------------------------------------------------------------------------------------------------ */
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+typedef struct { int64_t hi; uint64_t lo; } EPH_I128;
+typedef struct { EPH_I128 n, d; } EPH_RATIO;
+#include "coeff_tables.inc"
+
+static i128 i128_of(EPH_I128 v) { return (i128)(((u128)(uint64_t)v.hi << 64) | (u128)v.lo); }
+
+/* Mul<Ratio> for f64: `self * (rhs.numer as f64 / rhs.denom as f64)`  ratio.rs:221-228.
+ * `as f64` on i128 rounds to nearest-even; so does gcc's __floattidf. */
+static double ratio_f64(EPH_RATIO r) { return (double)i128_of(r.n) / (double)i128_of(r.d); }
+static double int_f64(EPH_I128 v) { return (double)i128_of(v); }
+
+static u128 uabs(i128 v) { return v < 0 ? (u128)0 - (u128)v : (u128)v; }
+static int ctz128(u128 v) {
+    uint64_t lo = (uint64_t)v;
+    if (lo) return __builtin_ctzll(lo);
+    return 64 + __builtin_ctzll((uint64_t)(v >> 64));
+}
+/* Stein's gcd, ratio.rs:246-271 */
+static u128 gcd_u128(u128 a, u128 b) {
+    u128 m = a, n = b;
+    if (m == 0 || n == 0) return m | n;
+    int shift = ctz128(m | n);
+    m >>= ctz128(m);
+    n >>= ctz128(n);
+    while (m != n) {
+        if (m > n) { m -= n; m >>= ctz128(m); }
+        else { n -= m; n >>= ctz128(n); }
+    }
+    return m << shift;
+}
+/* normalize, ratio.rs:153-177 */
+static void ratio_normalize(i128 *numer, i128 *denom) {
+    if (*denom == 0) return;
+    if (*numer == 0) { *denom = 1; return; }
+    if (*numer == *denom) { *numer = 1; *denom = 1; return; }
+    i128 g = (i128)gcd_u128(uabs(*numer), uabs(*denom));
+    *numer /= g;
+    *denom /= g;
+    if (*denom < 0) { *numer = -*numer; *denom = -*denom; }
+}
+static u128 pow10_u128(unsigned p) { u128 r = 1; while (p--) r *= 10; return r; }
+
+/* Ratio::from_f64, ratio.rs:75-103 (finite inputs only) */
+double orc_ratio_from_f64(double val, int64_t out_nd[4]) {
+    unsigned p = 0;
+    double new_val = val;
+    for (;;) {
+        double a = fabs(new_val);
+        /* `(a as u64) as f64 == a` with Rust's saturating float->int cast */
+        uint64_t au = a >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)a;
+        if ((double)au == a) break;
+        p += 1;
+        new_val = val * (double)pow10_u128(p);
+    }
+    i128 n = (i128)new_val, d = (i128)pow10_u128(p);
+    ratio_normalize(&n, &d);
+    if (out_nd) {
+        out_nd[0] = (int64_t)(n >> 64); out_nd[1] = (int64_t)(uint64_t)n;
+        out_nd[2] = (int64_t)(d >> 64); out_nd[3] = (int64_t)(uint64_t)d;
+    }
+    return (double)n / (double)d;
+}
+double orc_ratio_to_f64(int64_t n_hi, uint64_t n_lo, int64_t d_hi, uint64_t d_lo) {
+    EPH_RATIO r = {{n_hi, n_lo}, {d_hi, d_lo}};
+    return ratio_f64(r);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* coefficient lookup                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+static const EPH_SRKN_TABLE *find_srkn(const char *name) {
+    for (int i = 0; i < EPH_N_SRKN_TABLES; ++i)
+        if (!strcmp(eph_srkn_tables[i].name, name)) return &eph_srkn_tables[i];
+    return NULL;
+}
+static const EPH_ELM2_TABLE *find_elm2(const char *name) {
+    for (int i = 0; i < EPH_N_ELM2_TABLES; ++i)
+        if (!strcmp(eph_elm2_tables[i].name, name)) return &eph_elm2_tables[i];
+    return NULL;
+}
+static const EPH_ERK_TABLE *find_erk(const char *name) {
+    for (int i = 0; i < EPH_N_ERK_TABLES; ++i)
+        if (!strcmp(eph_erk_tables[i].name, name)) return &eph_erk_tables[i];
+    return NULL;
+}
+
+int orc_srkn_coeffs(const char *name, int *stages, int *fsal, double *A, double *B) {
+    const EPH_SRKN_TABLE *t = find_srkn(name);
+    if (!t) return ORC_BAD_ARGUMENT;
+    *stages = t->stages; *fsal = t->fsal;
+    for (int s = 0; s < t->stages; ++s) { A[s] = ratio_f64(t->A[s]); B[s] = ratio_f64(t->B[s]); }
+    return ORC_OK;
+}
+int orc_elm2_coeffs(const char *name, int *order, double *wa, double *wb, double *inv_beta_d, double *cw,
+                    double *inv_cowell_d) {
+    const EPH_ELM2_TABLE *t = find_elm2(name);
+    if (!t) return ORC_BAD_ARGUMENT;
+    *order = t->order;
+    for (int j = 0; j < t->order; ++j) {
+        /* P::Time::one() * Ratio::from_int(-C::ALPHA[j+1])  second_order/mod.rs:107 */
+        wa[j] = 1.0 * ((double)(-i128_of(t->ALPHA[j + 1])) / 1.0);
+        wb[j] = 1.0 * (int_f64(t->BETA_N[j + 1]) / 1.0);
+        cw[j] = 1.0 * (int_f64(t->COWELL_N[j]) / 1.0);
+    }
+    *inv_beta_d = 1.0 / int_f64(t->BETA_D);      /* Ratio::from_recip -> 1 as f64 / D as f64 */
+    *inv_cowell_d = 1.0 / int_f64(t->COWELL_D);
+    return ORC_OK;
+}
+int orc_erk_coeffs(const char *name, int *stages, int *order, int *order_embedded, int *fsal, double *A,
+                   double *B, double *C, double *E) {
+    const EPH_ERK_TABLE *t = find_erk(name);
+    if (!t) return ORC_BAD_ARGUMENT;
+    int s = t->stages;
+    *stages = s; *order = t->order; *order_embedded = t->order_embedded; *fsal = t->fsal;
+    for (int i = 0; i < s * (s - 1) / 2; ++i) A[i] = ratio_f64(t->A[i]);
+    for (int i = 0; i < s; ++i) {
+        B[i] = ratio_f64(t->B[i]);
+        C[i] = ratio_f64(t->C[i]);
+        E[i] = t->E ? ratio_f64(t->E[i]) : 0.0;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* NewtonianGravity::eval  ephemeris/src/propagators/nbody.rs:16-39                                 */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct { double x, y, z; } v3;
+
+static uint64_t g_pair_counter = 0;
+uint64_t orc_pair_counter(void) { return g_pair_counter; }
+
+/* (V, f64)::acceleration_paired(&other, &softening=0.0) -- crate `particular` 0.8.0-dev @ d490707a, source
+ * NOT on disk (Cargo.lock:4277-4285): PARITY UNPINNED. Restated in the form of the published crate
+ * (<= 0.7): dir = p_other - p_self ; n2 = dir.length_squared() (+ softening^2 = 0) ;
+ * inv = 1 / (n2 * sqrt(n2)) ; (dir * (mu_other*inv), -dir * (mu_self*inv)).
+ * glam DVec3::length_squared = x*x + y*y + z*z evaluated left to right (glam 0.30.10). */
+static inline void acceleration_paired(v3 pi, double mui, v3 pj, double muj, v3 *ai, v3 *aj) {
+    double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+    double n2 = dx * dx + dy * dy + dz * dz;
+    double inv = 1.0 / (n2 * sqrt(n2));
+    double si = muj * inv, sj = mui * inv;
+    ai->x = dx * si; ai->y = dy * si; ai->z = dz * si;
+    aj->x = -dx * sj; aj->y = -dy * sj; aj->z = -dz * sj;
+}
+
+static void gravity_eval(int n, const v3 *y, const double *mu, v3 *ddy) {
+    for (int i = 0; i < n; ++i) {
+        v3 out = {0.0, 0.0, 0.0};                       /* let mut output_i = V::default() */
+        for (int j = i + 1; j < n; ++j) {
+            v3 ai, aj;
+            acceleration_paired(y[i], mu[i], y[j], mu[j], &ai, &aj);
+            out.x += ai.x; out.y += ai.y; out.z += ai.z;     /* output_i += computed.0 */
+            ddy[j].x += aj.x; ddy[j].y += aj.y; ddy[j].z += aj.z; /* ddy[j] += computed.1 */
+        }
+        ddy[i].x += out.x; ddy[i].y += out.y; ddy[i].z += out.z;  /* ddy[i] += output_i */
+    }
+    g_pair_counter += (uint64_t)n * (uint64_t)(n - 1) / 2;
+}
+void orc_newtonian_gravity_eval(int n, const double *y, const double *mu, double *ddy) {
+    gravity_eval(n, (const v3 *)y, mu, (v3 *)ddy);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* NBodyProblem = ODEProblem<f64, SecondOrderState<Vec<V>>, NewtonianGravity>  nbody.rs:41           */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    double time, bound;
+    int n;
+    v3 *y, *dy;      /* state */
+    double *mu;      /* ode.gravitational_parameters */
+    uint64_t evals;
+} problem_t;
+
+static v3 *v3_alloc(int n) { return (v3 *)calloc((size_t)(n > 0 ? n : 1), sizeof(v3)); }
+static v3 *v3_dup(const v3 *s, int n) { v3 *d = v3_alloc(n); memcpy(d, s, sizeof(v3) * (size_t)n); return d; }
+static void v3_zero(v3 *v, int n) { for (int i = 0; i < n; ++i) v[i].x = v[i].y = v[i].z = 0.0; }
+
+static void ode_eval(problem_t *p, const v3 *y, v3 *ddy_zeroed) {
+    gravity_eval(p->n, y, p->mu, ddy_zeroed);
+    p->evals++;
+}
+
+/* ---- SRKN<C, V>  integration/src/runge_kutta/nystrom/symplectic.rs:36-102 ------------------------- */
+typedef struct {
+    int stages, fsal;
+    double A[32], B[32];
+    uint32_t i;
+    v3 *ddy;
+} srkn_t;
+
+static int srkn_init(srkn_t *k, const char *name, int n) {
+    const EPH_SRKN_TABLE *t = find_srkn(name);
+    if (!t || t->stages > 32) return ORC_BAD_ARGUMENT;
+    k->stages = t->stages; k->fsal = t->fsal; k->i = 0;
+    for (int s = 0; s < t->stages; ++s) { k->A[s] = ratio_f64(t->A[s]); k->B[s] = ratio_f64(t->B[s]); }
+    k->ddy = v3_alloc(n);
+    return ORC_OK;
+}
+/* symplectic.rs:69-102 */
+static void srkn_advance(srkn_t *k, double h, problem_t *p) {
+    for (int s = 0; s < k->stages; ++s) {
+        if (!k->fsal || s > 0 || k->i == 0) {
+            v3_zero(k->ddy, p->n);                 /* self.ddy.zero() */
+            ode_eval(p, p->y, k->ddy);             /* t_stage unused by NewtonianGravity */
+        }
+        double hb = h * k->B[s], ha = h * k->A[s];
+        for (int b = 0; b < p->n; ++b) {
+            p->dy[b].x = p->dy[b].x + k->ddy[b].x * hb;
+            p->dy[b].y = p->dy[b].y + k->ddy[b].y * hb;
+            p->dy[b].z = p->dy[b].z + k->ddy[b].z * hb;
+            p->y[b].x = p->y[b].x + p->dy[b].x * ha;
+            p->y[b].y = p->y[b].y + p->dy[b].y * ha;
+            p->y[b].z = p->y[b].z + p->dy[b].z * ha;
+        }
+    }
+    p->time = p->time + h;
+    k->i += 1;
+}
+/* FixedRungeKuttaIntegrator::advance  runge_kutta/mod.rs:112-125 */
+static int frk_advance(srkn_t *k, double h, problem_t *p) {
+    if (p->time >= p->bound) return ORC_BOUND_REACHED;
+    if (p->time + h == p->time) return ORC_STEP_SIZE_UNDERFLOW;
+    srkn_advance(k, h, p);
+    return ORC_OK;
+}
+
+/* ---- ELM2 + Cowell + LMBuffer ------------------------------------------------------------------ */
+#define ELM_MAX_ORDER 16
+typedef struct {
+    int order;                 /* ORDER; ring has ORDER-1 slots */
+    double wa[ELM_MAX_ORDER], wb[ELM_MAX_ORDER], cw[ELM_MAX_ORDER];
+    double inv_beta_d, inv_cowell_d;
+    uint32_t i;
+    v3 *current_ddy;
+    /* LMBuffer<StepOrder2>  multistep/buffer.rs:1-66 */
+    int head, len;
+    v3 **sy, **sdy, **sddy;    /* steps[k].state.y / .state.dy / .ddy */
+    v3 *sum1, *sum2;
+} elm2_t;
+
+static int elm2_init(elm2_t *e, const char *name, const problem_t *p) {
+    int order;
+    if (orc_elm2_coeffs(name, &order, e->wa, e->wb, &e->inv_beta_d, e->cw, &e->inv_cowell_d)) return ORC_BAD_ARGUMENT;
+    e->order = order; e->i = 0;
+    e->len = order - 1;
+    e->head = e->len;                                   /* buffer.rs:12-15: head = data.len() */
+    e->current_ddy = v3_alloc(p->n);
+    e->sy = calloc((size_t)e->len, sizeof(v3 *));
+    e->sdy = calloc((size_t)e->len, sizeof(v3 *));
+    e->sddy = calloc((size_t)e->len, sizeof(v3 *));
+    for (int k = 0; k < e->len; ++k) {                  /* second_order/mod.rs:73-88 */
+        e->sy[k] = v3_dup(p->y, p->n);
+        e->sdy[k] = v3_dup(p->dy, p->n);
+        e->sddy[k] = v3_alloc(p->n);
+    }
+    e->sum1 = v3_alloc(p->n);
+    e->sum2 = v3_alloc(p->n);
+    return ORC_OK;
+}
+#define SWAPP(a, b) do { v3 *t_ = (a); (a) = (b); (b) = t_; } while (0)
+/* prepare_next_step  second_order/mod.rs:41-45 */
+static void elm2_prepare_next_step(elm2_t *e) {
+    e->head = (e->head + e->len - 1) % e->len;          /* rotate_right buffer.rs:34-36 */
+    SWAPP(e->sddy[e->head], e->current_ddy);
+}
+/* LMBuffer::iter item `idx` (front -> oldest)  buffer.rs:39-66 */
+static inline int ring_at(const elm2_t *e, int idx) { return (e->head + idx) % e->len; }
+
+/* Cowell::<ORDER>::update_velocity  cowell.rs:17-53 */
+static void cowell_update_velocity(elm2_t *e, problem_t *p, double h) {
+    int n = p->n;
+    v3_zero(e->sum1, n);
+    for (int j = 0; j < e->order; ++j) {
+        const v3 *ddy = j == 0 ? e->current_ddy : e->sddy[ring_at(e, j - 1)];
+        double c = e->cw[j];
+        for (int b = 0; b < n; ++b) {
+            e->sum1[b].x = e->sum1[b].x + ddy[b].x * c;
+            e->sum1[b].y = e->sum1[b].y + ddy[b].y * c;
+            e->sum1[b].z = e->sum1[b].z + ddy[b].z * c;
+        }
+    }
+    const v3 *ym1 = e->sy[e->head];                      /* lm.steps.front().state.y */
+    double hc = h * e->inv_cowell_d;                     /* h * Ratio::from_recip(BETA_D) */
+    for (int b = 0; b < n; ++b) {
+        p->dy[b].x = (p->y[b].x - ym1[b].x) / h + e->sum1[b].x * hc;
+        p->dy[b].y = (p->y[b].y - ym1[b].y) / h + e->sum1[b].y * hc;
+        p->dy[b].z = (p->y[b].z - ym1[b].z) / h + e->sum1[b].z * hc;
+    }
+}
+/* ELM2::advance  second_order/mod.rs:90-131 */
+static void elm2_advance(elm2_t *e, double h, problem_t *p) {
+    int n = p->n;
+    v3_zero(e->sum1, n);
+    v3_zero(e->sum2, n);
+    for (int j = 0; j < e->order; ++j) {
+        const v3 *y = j == 0 ? p->y : e->sy[ring_at(e, j - 1)];
+        const v3 *ddy = j == 0 ? e->current_ddy : e->sddy[ring_at(e, j - 1)];
+        double a = e->wa[j], bb = e->wb[j];
+        for (int b = 0; b < n; ++b) {
+            e->sum1[b].x = e->sum1[b].x + y[b].x * a;
+            e->sum1[b].y = e->sum1[b].y + y[b].y * a;
+            e->sum1[b].z = e->sum1[b].z + y[b].z * a;
+            e->sum2[b].x = e->sum2[b].x + ddy[b].x * bb;
+            e->sum2[b].y = e->sum2[b].y + ddy[b].y * bb;
+            e->sum2[b].z = e->sum2[b].z + ddy[b].z * bb;
+        }
+    }
+    elm2_prepare_next_step(e);
+    SWAPP(e->sy[e->head], p->y);                         /* mem::swap(front.state, problem.state) */
+    SWAPP(e->sdy[e->head], p->dy);
+    double hh = h * h * e->inv_beta_d;                   /* h * h * Ratio::from_recip(BETA_D) */
+    for (int b = 0; b < n; ++b) {
+        p->y[b].x = e->sum1[b].x + e->sum2[b].x * hh;
+        p->y[b].y = e->sum1[b].y + e->sum2[b].y * hh;
+        p->y[b].z = e->sum1[b].z + e->sum2[b].z * hh;
+    }
+    p->time = p->time + h;
+    v3_zero(e->current_ddy, n);
+    ode_eval(p, p->y, e->current_ddy);
+    cowell_update_velocity(e, p, h);
+    e->i += 1;
+}
+
+/* ---- the integrator object --------------------------------------------------------------------- */
+struct orc_nbody {
+    problem_t p;
+    double h;
+    int is_multistep;
+    elm2_t lm;
+    srkn_t starter;      /* Substepper<4, FixedRungeKutta<BlanesMoan6B>> inner, or the plain SRKN method */
+    int substeps;
+    double h_sub;
+};
+
+static void problem_free(problem_t *p) { free(p->y); free(p->dy); free(p->mu); }
+
+orc_nbody *orc_nbody_new(int n, const double *pos, const double *vel, const double *mu, double t0, double h,
+                         const char *method) {
+    orc_nbody *o = calloc(1, sizeof(*o));
+    o->p.time = t0; o->p.bound = INFINITY; o->p.n = n;     /* nbody.rs:110-113 */
+    o->p.y = v3_dup((const v3 *)pos, n);
+    o->p.dy = v3_dup((const v3 *)vel, n);
+    o->p.mu = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    memcpy(o->p.mu, mu, sizeof(double) * (size_t)n);
+    o->h = h;
+    if (find_elm2(method)) {
+        /* LinearMultistep::new + Substepper::new  multistep/mod.rs:54-57,120-128 ; methods.rs:37-40 */
+        o->is_multistep = 1;
+        o->substeps = 4;
+        o->h_sub = h * (1.0 / 4.0);                     /* params.h * Ratio::from_recip(SUBSTEPS) */
+        if (elm2_init(&o->lm, method, &o->p) || srkn_init(&o->starter, "BlanesMoan6B", n)) { free(o); return NULL; }
+    } else if (find_srkn(method)) {
+        o->is_multistep = 0;
+        o->substeps = 1;
+        o->h_sub = h;
+        if (srkn_init(&o->starter, method, n)) { free(o); return NULL; }
+    } else {
+        problem_free(&o->p); free(o); return NULL;
+    }
+    return o;
+}
+
+orc_nbody *orc_nbody_clone(const orc_nbody *s) {
+    orc_nbody *o = malloc(sizeof(*o));
+    *o = *s;
+    int n = s->p.n;
+    o->p.y = v3_dup(s->p.y, n); o->p.dy = v3_dup(s->p.dy, n);
+    o->p.mu = malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    memcpy(o->p.mu, s->p.mu, sizeof(double) * (size_t)n);
+    o->starter.ddy = v3_dup(s->starter.ddy, n);
+    if (s->is_multistep) {
+        const elm2_t *e = &s->lm;
+        elm2_t *d = &o->lm;
+        d->current_ddy = v3_dup(e->current_ddy, n);
+        d->sum1 = v3_dup(e->sum1, n); d->sum2 = v3_dup(e->sum2, n);
+        d->sy = calloc((size_t)e->len, sizeof(v3 *));
+        d->sdy = calloc((size_t)e->len, sizeof(v3 *));
+        d->sddy = calloc((size_t)e->len, sizeof(v3 *));
+        for (int k = 0; k < e->len; ++k) {
+            d->sy[k] = v3_dup(e->sy[k], n); d->sdy[k] = v3_dup(e->sdy[k], n); d->sddy[k] = v3_dup(e->sddy[k], n);
+        }
+    }
+    return o;
+}
+
+void orc_nbody_free(orc_nbody *o) {
+    if (!o) return;
+    problem_free(&o->p);
+    free(o->starter.ddy);
+    if (o->is_multistep) {
+        elm2_t *e = &o->lm;
+        for (int k = 0; k < e->len; ++k) { free(e->sy[k]); free(e->sdy[k]); free(e->sddy[k]); }
+        free(e->sy); free(e->sdy); free(e->sddy); free(e->current_ddy); free(e->sum1); free(e->sum2);
+    }
+    free(o);
+}
+
+/* SubstepperIntegrator::advance  multistep/mod.rs:101-107 */
+static int substepper_advance(orc_nbody *o) {
+    for (int s = 0; s < o->substeps; ++s) {
+        int st = frk_advance(&o->starter, o->h_sub, &o->p);
+        if (st) return st;
+    }
+    return ORC_OK;
+}
+/* ELM2::advance_with  second_order/mod.rs:133-153 */
+static int elm2_advance_with(orc_nbody *o, int run_starter) {
+    elm2_t *e = &o->lm;
+    problem_t *p = &o->p;
+    elm2_prepare_next_step(e);
+    memcpy(e->sy[e->head], p->y, sizeof(v3) * (size_t)p->n);    /* front.state.clone_from(problem.state) */
+    memcpy(e->sdy[e->head], p->dy, sizeof(v3) * (size_t)p->n);
+    if (run_starter) {
+        int st = substepper_advance(o);
+        if (st) return st;
+    }
+    v3_zero(e->current_ddy, p->n);
+    ode_eval(p, p->y, e->current_ddy);
+    return ORC_OK;
+}
+/* LinearMultistepIntegrator::advance  multistep/mod.rs:201-224 */
+static int integrator_advance(orc_nbody *o) {
+    problem_t *p = &o->p;
+    if (!o->is_multistep) return frk_advance(&o->starter, o->h, p);
+    if (p->time >= p->bound) return ORC_BOUND_REACHED;
+    if (p->time + o->h == p->time) return ORC_STEP_SIZE_UNDERFLOW;
+    uint32_t starter_count = o->starter.i / (uint32_t)o->substeps;   /* multistep/mod.rs:93-95 */
+    if (starter_count < (uint32_t)o->lm.order) {
+        if (starter_count == 0) {
+            int st = elm2_advance_with(o, 0);
+            if (st) return st;
+        }
+        return elm2_advance_with(o, 1);
+    }
+    elm2_advance(&o->lm, o->h, p);
+    return ORC_OK;
+}
+
+int orc_nbody_advance(orc_nbody *o, int64_t nsteps) {
+    for (int64_t s = 0; s < nsteps; ++s) {
+        int st = integrator_advance(o);
+        if (st) return st;
+    }
+    return ORC_OK;
+}
+static uint32_t integrator_step_count(const orc_nbody *o) {
+    if (!o->is_multistep) return o->starter.i;
+    return o->starter.i / (uint32_t)o->substeps + o->lm.i;       /* multistep/mod.rs:170-172 */
+}
+void orc_nbody_get_state(const orc_nbody *o, double *pos, double *vel, double *t, uint32_t *step_count) {
+    if (pos) memcpy(pos, o->p.y, sizeof(v3) * (size_t)o->p.n);
+    if (vel) memcpy(vel, o->p.dy, sizeof(v3) * (size_t)o->p.n);
+    if (t) *t = o->p.time;
+    if (step_count) *step_count = integrator_step_count(o);
+}
+void orc_nbody_get_acc(const orc_nbody *o, double *acc) {
+    memcpy(acc, o->is_multistep ? o->lm.current_ddy : o->starter.ddy, sizeof(v3) * (size_t)o->p.n);
+}
+void orc_nbody_set_bound(orc_nbody *o, double bound) { o->p.bound = bound; }
+uint64_t orc_nbody_eval_count(const orc_nbody *o) { return o->p.evals; }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Polynomial / UniformSpline  ephemeris/src/trajectory.rs:337-633                                  */
+/* ------------------------------------------------------------------------------------------------ */
+#define DIV 8                              /* trajectory.rs:335 */
+typedef struct { int ncoef; v3 c[DIV]; } poly_t;    /* SmallVec<[V; 8]> */
+
+/* eval_slice_horner trajectory.rs:398-410 */
+static v3 poly_eval(const poly_t *p, double t) {
+    v3 r = {0.0, 0.0, 0.0};
+    for (int k = p->ncoef - 1; k >= 0; --k) {
+        r.x = r.x * t + p->c[k].x; r.y = r.y * t + p->c[k].y; r.z = r.z * t + p->c[k].z;
+    }
+    return r;
+}
+/* Polynomial::eval_and_deriv trajectory.rs:368-385 */
+static void poly_eval_and_deriv(const poly_t *p, double t, v3 *eval, v3 *deriv) {
+    v3 zero = {0.0, 0.0, 0.0};
+    v3 first = p->ncoef ? p->c[0] : zero;
+    v3 last = p->ncoef ? p->c[p->ncoef - 1] : zero;
+    v3 e = last, d = last;
+    /* self.0.iter().skip(1).rev().skip(1): indices ncoef-2 .. 1 */
+    for (int k = p->ncoef - 2; k >= 1; --k) {
+        e.x = e.x * t + p->c[k].x; e.y = e.y * t + p->c[k].y; e.z = e.z * t + p->c[k].z;
+        d.x = d.x * t + e.x; d.y = d.y * t + e.y; d.z = d.z * t + e.z;
+    }
+    e.x = e.x * t + first.x; e.y = e.y * t + first.y; e.z = e.z * t + first.z;
+    *eval = e; *deriv = d;
+}
+void orc_poly_eval_and_deriv(int ncoef, const double *coeffs, double tau, double *val, double *deriv) {
+    poly_t p; p.ncoef = ncoef;
+    memcpy(p.c, coeffs, sizeof(v3) * DIV);
+    v3 e, d;
+    poly_eval_and_deriv(&p, tau, &e, &d);
+    memcpy(val, &e, sizeof e); memcpy(deriv, &d, sizeof d);
+}
+
+typedef struct {
+    double start, interval;
+    /* VecDeque<Polynomial>: stored with a movable front */
+    poly_t *buf; int64_t cap, off, len;
+} spline_t;
+
+static void spline_init(spline_t *s, double start, double interval) {
+    s->start = start; s->interval = interval; s->buf = NULL; s->cap = s->off = s->len = 0;
+}
+static void spline_reserve(spline_t *s, int64_t front, int64_t back) {
+    if (s->off >= front && s->off + s->len + back <= s->cap) return;
+    int64_t ncap = (s->len + front + back) * 2 + 16;
+    poly_t *nb = malloc(sizeof(poly_t) * (size_t)ncap);
+    int64_t noff = (ncap - s->len) / 2;
+    if (noff < front) noff = front;
+    if (s->len) memcpy(nb + noff, s->buf + s->off, sizeof(poly_t) * (size_t)s->len);
+    free(s->buf); s->buf = nb; s->cap = ncap; s->off = noff;
+}
+static void spline_push_back(spline_t *s, const poly_t *p) {      /* trajectory.rs:510-513 */
+    spline_reserve(s, 0, 1);
+    s->buf[s->off + s->len++] = *p;
+}
+static void spline_push_front(spline_t *s, const poly_t *p) {     /* trajectory.rs:504-508 */
+    spline_reserve(s, 1, 0);
+    s->buf[--s->off] = *p; s->len++;
+    s->start -= s->interval;
+}
+static double spline_span(const spline_t *s) { return s->interval * (double)s->len; }  /* :624-627 scaled */
+static double spline_end(const spline_t *s) { return s->start + spline_span(s); }      /* :437-440 */
+/* get_polynomial trajectory.rs:551-561 with get_index_local_exclusive :600-607, index_local_exclusive :614-617 */
+static const poly_t *spline_get_polynomial(const spline_t *s, double at, double *tau) {
+    double local = at - s->start;
+    if (signbit(local) || local > spline_span(s)) return NULL;    /* Duration::is_negative = sign bit */
+    double q = ceil(local / s->interval);
+    /* `as usize` saturating cast, then saturating_sub(1) */
+    uint64_t qi = q <= 0.0 ? 0 : (q >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)q);
+    uint64_t idx = qi == 0 ? 0 : qi - 1;
+    double local_polynomial = local - s->interval * (double)idx;
+    *tau = local_polynomial / s->interval;
+    if (idx >= (uint64_t)s->len) return NULL;                     /* self.polynomials.get(local_index)? */
+    return &s->buf[s->off + (int64_t)idx];
+}
+
+struct orc_solution { int n; spline_t *s; };
+
+static orc_solution *solution_alloc(int n) {
+    orc_solution *so = malloc(sizeof(*so));
+    so->n = n; so->s = calloc((size_t)(n > 0 ? n : 1), sizeof(spline_t));
+    return so;
+}
+void orc_solution_free(orc_solution *so) {
+    if (!so) return;
+    for (int b = 0; b < so->n; ++b) free(so->s[b].buf);
+    free(so->s); free(so);
+}
+static orc_solution *solution_clone(const orc_solution *src) {
+    orc_solution *so = solution_alloc(src->n);
+    for (int b = 0; b < src->n; ++b) {
+        so->s[b] = src->s[b];
+        so->s[b].buf = NULL; so->s[b].cap = so->s[b].off = 0;
+        if (src->s[b].len) {
+            so->s[b].buf = malloc(sizeof(poly_t) * (size_t)src->s[b].len);
+            memcpy(so->s[b].buf, src->s[b].buf + src->s[b].off, sizeof(poly_t) * (size_t)src->s[b].len);
+            so->s[b].cap = src->s[b].len;
+        }
+    }
+    return so;
+}
+int orc_solution_bodies(const orc_solution *so) { return so->n; }
+void orc_solution_info(const orc_solution *so, int body, double *start, double *interval, int64_t *npoly) {
+    *start = so->s[body].start; *interval = so->s[body].interval; *npoly = so->s[body].len;
+}
+void orc_solution_coeffs(const orc_solution *so, int body, double *coeffs, int32_t *ncoef) {
+    const spline_t *s = &so->s[body];
+    for (int64_t p = 0; p < s->len; ++p) {
+        const poly_t *q = &s->buf[s->off + p];
+        ncoef[p] = q->ncoef;
+        for (int k = 0; k < DIV; ++k) {
+            v3 c = k < q->ncoef ? q->c[k] : (v3){0.0, 0.0, 0.0};
+            coeffs[(p * DIV + k) * 3 + 0] = c.x; coeffs[(p * DIV + k) * 3 + 1] = c.y; coeffs[(p * DIV + k) * 3 + 2] = c.z;
+        }
+    }
+}
+/* EvaluateTrajectory for UniformSpline  trajectory.rs:450-471 */
+int orc_solution_eval(const orc_solution *so, int body, double at, double *pos, double *vel) {
+    const spline_t *s = &so->s[body];
+    double tau;
+    const poly_t *p = spline_get_polynomial(s, at, &tau);
+    if (!p) return 0;
+    if (vel) {
+        v3 e, d;
+        poly_eval_and_deriv(p, tau, &e, &d);
+        pos[0] = e.x; pos[1] = e.y; pos[2] = e.z;
+        vel[0] = d.x / s->interval; vel[1] = d.y / s->interval; vel[2] = d.z / s->interval;
+    } else {
+        v3 e = poly_eval(p, tau);
+        pos[0] = e.x; pos[1] = e.y; pos[2] = e.z;
+    }
+    return 1;
+}
+/* UniformSpline::append (direction>0) / prepend (direction<0)  trajectory.rs:515-539 */
+int orc_solution_append(orc_solution *a, const orc_solution *b, int direction) {
+    if (a->n != b->n) return 0;
+    for (int k = 0; k < a->n; ++k) {
+        spline_t *x = &a->s[k];
+        const spline_t *y = &b->s[k];
+        if (x->interval != y->interval) return 0;
+        if (direction > 0) {
+            if (spline_end(x) != y->start) return 0;
+            spline_reserve(x, 0, y->len);
+            for (int64_t p = 0; p < y->len; ++p) x->buf[x->off + x->len++] = y->buf[y->off + p];
+        } else {
+            if (x->start != spline_end(y)) return 0;
+            x->start = y->start;
+            spline_reserve(x, y->len, 0);
+            for (int64_t p = y->len - 1; p >= 0; --p) { x->buf[--x->off] = y->buf[y->off + p]; x->len++; }
+        }
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* LeastSquaresFit::interpolate  ephemeris_explorer/src/dynamics/celestial.rs:24-135                */
+/* DVec3 quantities whose three components are always identical (gamma, b, c, p_k, px) are carried  */
+/* as scalars: every component undergoes the same f64 operations, so the bits are the same.          */
+/* ------------------------------------------------------------------------------------------------ */
+static int least_squares_fit(int degree_in, int m, const double *ts, const v3 *xs, poly_t *out) {
+    v3 d0 = {0, 0, 0};
+    double gamma0 = 0.0, b0 = 0.0;
+    for (int k = 0; k < m; ++k) {                        /* :32-40 */
+        d0.x += xs[k].x; d0.y += xs[k].y; d0.z += xs[k].z;
+        gamma0 += 1.0;
+        b0 += ts[k];
+    }
+    if (gamma0 == 0.0) return -1;                        /* :42-44 */
+    int degree = degree_in < m - 1 ? degree_in : m - 1;  /* :46 */
+    b0 /= gamma0;
+    d0.x /= gamma0; d0.y /= gamma0; d0.z /= gamma0;
+    memset(out, 0, sizeof(*out));
+    if (degree == 0) { out->ncoef = 1; out->c[0] = d0; return 1; }   /* :53-56 */
+    if (degree + 1 > DIV) return -2;                     /* SmallVec<[V;8]> would spill; never in the app */
+    int nco = degree + 1;
+    v3 pdata[DIV + 1];
+    double pa[DIV + 2], pb[DIV + 2];
+    double *p_km1 = pa, *p_k = pb;
+    for (int i = 0; i < nco; ++i) { pdata[i] = (v3){0, 0, 0}; pa[i] = 0.0; pb[i] = 0.0; }
+    pdata[0] = d0;
+    p_k[0] = 1.0;
+    double gamma_k = gamma0, b_k = b0, minus_c_k = 0.0;
+    int kp1 = 1;
+    for (;;) {
+        for (int i = 0; i < kp1; ++i) p_km1[i] = minus_c_k * p_km1[i] - b_k * p_k[i];   /* :76-80 */
+        for (int im1 = 0; im1 < kp1; ++im1) p_km1[im1 + 1] += p_k[im1];                 /* :82-86 */
+        v3 d = {0, 0, 0};
+        double g = 0.0, bsum = 0.0;
+        for (int k = 0; k < m; ++k) {                    /* :88-103 */
+            double px = 0.0;
+            for (int c = kp1; c >= 0; --c) px = px * ts[k] + p_km1[c];   /* eval_slice_horner */
+            double wipx = px;
+            d.x += xs[k].x * wipx; d.y += xs[k].y * wipx; d.z += xs[k].z * wipx;
+            double wipxpx = wipx * px;
+            g += wipxpx;
+            bsum += ts[k] * wipxpx;
+        }
+        if (g == 0.0) break;                             /* :105-107 */
+        d.x /= g; d.y /= g; d.z /= g;
+        for (int i = 0; i < kp1 + 1; ++i) {              /* :111-115 */
+            pdata[i].x += d.x * p_km1[i]; pdata[i].y += d.y * p_km1[i]; pdata[i].z += d.z * p_km1[i];
+        }
+        if (kp1 == degree) break;
+        bsum /= g;
+        kp1 += 1;
+        b_k = bsum;
+        minus_c_k = -(g / gamma_k);
+        gamma_k = g;
+        double *t = p_k; p_k = p_km1; p_km1 = t;
+    }
+    int ncoef = nco;                                     /* Polynomial::trim trajectory.rs:387-395 */
+    while (ncoef > 0 && pdata[ncoef - 1].x == 0.0 && pdata[ncoef - 1].y == 0.0 && pdata[ncoef - 1].z == 0.0) ncoef--;
+    out->ncoef = ncoef;
+    for (int i = 0; i < ncoef; ++i) out->c[i] = pdata[i];
+    return ncoef;
+}
+int orc_least_squares_fit(int degree, int m, const double *ts, const double *xs, double *coeffs) {
+    poly_t p;
+    int r = least_squares_fit(degree, m, ts, (const v3 *)xs, &p);
+    if (r < 0) return r;
+    for (int k = 0; k < DIV; ++k) {
+        v3 c = k < p.ncoef ? p.c[k] : (v3){0, 0, 0};
+        coeffs[k * 3] = c.x; coeffs[k * 3 + 1] = c.y; coeffs[k * 3 + 2] = c.z;
+    }
+    return p.ncoef;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* SplineInterpolators solout + NBodyPropagator  ephemeris/src/propagators/nbody.rs:243-517         */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    double last_sample_time, sample_period;   /* Durations */
+    int index;                                /* PolyonmialInterpolator.index */
+    v3 samples[DIV + 1];
+    int degree;                               /* LeastSquaresFit.degree */
+} interp_t;
+
+struct orc_prop {
+    orc_nbody *integ;       /* Integration.problem + .integrator */
+    int direction;
+    double delta;           /* SplineInterpolators.delta (positive) */
+    interp_t *interp;
+    orc_solution *solution; /* Integration.solution */
+};
+
+/* D::offset  propagators/mod.rs:49-51,84-86 */
+static double dir_offset(int direction, double to, double duration) {
+    return direction > 0 ? to + duration : to - duration;
+}
+/* D::distance :54-56,89-91 */
+static double dir_distance(int direction, double from, double to) { return direction > 0 ? to - from : from - to; }
+/* SplineInterpolator::time  nbody.rs:317-323 */
+static double interp_time(const interp_t *it) {
+    int len1 = it->index > 0 ? it->index - 1 : 0;
+    return it->last_sample_time + it->sample_period * (double)len1;
+}
+/* Solout::new_solution  nbody.rs:454-469 */
+static orc_solution *prop_new_solution(const orc_prop *pr) {
+    int n = pr->integ->p.n;
+    orc_solution *so = solution_alloc(n);
+    for (int b = 0; b < n; ++b)
+        spline_init(&so->s[b], dir_offset(pr->direction, pr->integ->p.time, -interp_time(&pr->interp[b])),
+                    pr->interp[b].sample_period * (double)DIV);
+    return so;
+}
+static double spline_bound(const spline_t *s, int direction) { return direction > 0 ? spline_end(s) : s->start; }
+
+orc_prop *orc_prop_new(int n, const double *pos, const double *vel, const double *mu, double t0, double dt,
+                       int direction, const char *method, const uint32_t *count, const uint32_t *degree) {
+    orc_prop *pr = calloc(1, sizeof(*pr));
+    double delta = fabs(dt);                                     /* Forward::new / Backward::new: delta.abs() */
+    double h = direction > 0 ? delta : -delta;                   /* signed_delta */
+    pr->integ = orc_nbody_new(n, pos, vel, mu, t0, h, method);
+    if (!pr->integ) { free(pr); return NULL; }
+    pr->direction = direction > 0 ? 1 : -1;
+    pr->delta = dt;                                              /* SplineInterpolators::new(delta, ..) celestial.rs:183 */
+    pr->interp = calloc((size_t)(n > 0 ? n : 1), sizeof(interp_t));
+    for (int b = 0; b < n; ++b) {
+        interp_t *it = &pr->interp[b];
+        it->last_sample_time = 0.0;
+        it->sample_period = dt * (double)count[b];               /* load/mod.rs:325 */
+        it->index = 1;                                           /* PolyonmialInterpolator::new nbody.rs:251-259 */
+        for (int k = 0; k <= DIV; ++k) it->samples[k] = ((const v3 *)pos)[b];
+        it->degree = (int)degree[b];
+    }
+    pr->solution = prop_new_solution(pr);                        /* with_solout lib.rs:441-451 */
+    return pr;
+}
+orc_prop *orc_prop_clone(const orc_prop *s) {
+    orc_prop *pr = malloc(sizeof(*pr));
+    *pr = *s;
+    pr->integ = orc_nbody_clone(s->integ);
+    int n = s->integ->p.n;
+    pr->interp = malloc(sizeof(interp_t) * (size_t)(n > 0 ? n : 1));
+    memcpy(pr->interp, s->interp, sizeof(interp_t) * (size_t)n);
+    pr->solution = solution_clone(s->solution);
+    return pr;
+}
+void orc_prop_free(orc_prop *pr) {
+    if (!pr) return;
+    orc_nbody_free(pr->integ); free(pr->interp); orc_solution_free(pr->solution); free(pr);
+}
+/* SplineInterpolators::solout  nbody.rs:371-400,471-489 */
+static int prop_solout(orc_prop *pr) {
+    const problem_t *p = &pr->integ->p;
+    for (int b = 0; b < p->n; ++b) {
+        interp_t *it = &pr->interp[b];
+        spline_t *traj = &pr->solution->s[b];
+        it->last_sample_time += pr->delta;
+        if (it->last_sample_time == it->sample_period) {
+            it->last_sample_time = 0.0;
+            if (it->index >= DIV + 1) abort();                   /* assert!(self.index < LEN) nbody.rs:266 */
+            it->samples[it->index++] = p->y[b];
+            if (it->index == DIV + 1) {                          /* try_to_polynomial: is_full */
+                double ts[DIV + 1];
+                for (int i = 0; i <= DIV; ++i)                   /* SplineBound::samples nbody.rs:422-424,439-441 */
+                    ts[i] = pr->direction > 0 ? (double)i / (double)DIV : 1.0 - (double)i / (double)DIV;
+                poly_t poly;
+                if (least_squares_fit(it->degree, DIV + 1, ts, it->samples, &poly) < 0) return 0;
+                if (pr->direction > 0) spline_push_back(traj, &poly); else spline_push_front(traj, &poly);
+                v3 t0 = it->samples[0];                          /* finish(): swap(0, index-1); index = 1 */
+                it->samples[0] = it->samples[it->index - 1];
+                it->samples[it->index - 1] = t0;
+                it->index = 1;
+            }
+        }
+    }
+    return 1;
+}
+int orc_prop_step(orc_prop *pr) {
+    int st = integrator_advance(pr->integ);                      /* Integration::advance lib.rs:496-503 */
+    if (st) return st;
+    if (!prop_solout(pr)) return ORC_SOLOUT_EXIT;                /* nbody.rs:201-204 */
+    return ORC_OK;
+}
+/* DirectionalSolout::solution_time  nbody.rs:501-508 */
+double orc_prop_time(const orc_prop *pr) {
+    int n = pr->solution->n;
+    if (n == 0) return dir_offset(pr->direction, 0.0, -1.7976931348623157e308);
+    double best = spline_bound(&pr->solution->s[0], pr->direction);
+    for (int b = 1; b < n; ++b) {                                /* min_by(D::cmp): keeps the first minimum */
+        double x = spline_bound(&pr->solution->s[b], pr->direction);
+        /* D::cmp(x, best) = 0.cmp(distance(x, best)); Less  <=>  0 < distance(x,best) */
+        if (0.0 < dir_distance(pr->direction, x, best)) best = x;
+    }
+    return best;
+}
+/* DirectionalSolout::has_reached  nbody.rs:510-516 */
+int orc_prop_has_reached(const orc_prop *pr, double t) {
+    for (int b = 0; b < pr->solution->n; ++b) {
+        double bound = spline_bound(&pr->solution->s[b], pr->direction);
+        /* D::cmp(&bound, &time).is_ge()  <=>  !(0 < distance(bound, time)) */
+        if (0.0 < dir_distance(pr->direction, bound, t)) return 0;
+    }
+    return 1;
+}
+int orc_prop_step_to(orc_prop *pr, double t) {
+    for (;;) {
+        if (orc_prop_has_reached(pr, t)) return ORC_OK;
+        int st = orc_prop_step(pr);
+        if (st) return st;
+    }
+}
+double orc_prop_integrator_time(const orc_prop *pr) { return pr->integ->p.time; }
+void orc_prop_get_state(const orc_prop *pr, double *pos, double *vel, double *t, uint32_t *sc) {
+    orc_nbody_get_state(pr->integ, pos, vel, t, sc);
+}
+/* Propagator::take_solution  nbody.rs:182-189 */
+orc_solution *orc_prop_take_solution(orc_prop *pr) {
+    orc_solution *old = pr->solution;
+    pr->solution = prop_new_solution(pr);
+    return old;
+}

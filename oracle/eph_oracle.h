@@ -1,0 +1,108 @@
+/* eph_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's hot path (Canleskis/ephemeris-explorer, crates `integration`
+ * and `ephemeris`, plus the arithmetic the app crate contributes to the path). Every function cites the
+ * reference file:line it follows. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product (ephemeris_explorer_amd/) never does.
+ *
+ * PARITY PINNING: the reference cannot be built here (no Rust toolchain) and its innermost arithmetic
+ * (`particular::gravity::newtonian`, git rev d490707a, Cargo.lock:4277-4285) is not on disk, so the pair
+ * formula is "parity unpinned" (see DESIGN.md). Everything else is pinned by: the coefficient tables
+ * (tests/golden/coeff_tables.json, generated from the reference's constants), the doc-test known answers
+ * (integration/src/lib.rs:32-56,60-93), an independent Python restatement (oracle/pyoracle.py) and the
+ * committed systems fixtures (tests/golden/systems).
+ */
+#ifndef EPH_ORACLE_H
+#define EPH_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes = integration::StepError (integration/src/lib.rs:312-318) + NBodyPropagatorError::Solout */
+enum {
+    ORC_OK = 0,
+    ORC_STEP_SIZE_UNDERFLOW = 1,
+    ORC_MAX_ITERATIONS = 2,
+    ORC_BOUND_REACHED = 3,
+    ORC_EVAL_FAILED = 4,
+    ORC_SOLOUT_EXIT = 5,
+    ORC_BAD_ARGUMENT = -1
+};
+
+/* ---- Ratio (integration/src/ratio.rs) ---------------------------------------------------------- */
+/* from_f64 (:75-103) + normalize (:153-177): out = {numer_hi, numer_lo, denom_hi, denom_lo}; returns the
+ * f64 the ratio converts back to (:221-228). */
+double orc_ratio_from_f64(double v, int64_t out_nd[4]);
+double orc_ratio_to_f64(int64_t n_hi, uint64_t n_lo, int64_t d_hi, uint64_t d_lo);
+
+/* ---- coefficient tables as the f64 the reference multiplies with ------------------------------- */
+int orc_srkn_coeffs(const char *name, int *stages, int *fsal, double *A, double *B);
+/* w_alpha[j] = (double)(-ALPHA[j+1]), w_beta[j] = (double)BETA_N[j+1], j = 0..order-1;
+ * cowell[j] = (double)Cowell<order>::BETA_N[j]; inv_* = 1.0/(double)D */
+int orc_elm2_coeffs(const char *name, int *order, double *w_alpha, double *w_beta, double *inv_beta_d,
+                    double *cowell, double *inv_cowell_d);
+/* A is the flattened strict lower triangle (row s has s entries) */
+int orc_erk_coeffs(const char *name, int *stages, int *order, int *order_embedded, int *fsal, double *A,
+                   double *B, double *C, double *E);
+
+/* ---- NewtonianGravity::eval (ephemeris/src/propagators/nbody.rs:16-39) --------------------------- */
+/* y, ddy: AoS xyz; ddy is ACCUMULATED into (caller zeroes), exactly like the reference. */
+void orc_newtonian_gravity_eval(int n, const double *y, const double *mu, double *ddy);
+/* number of (paired) interactions evaluated since process start -- used by bench.py for ns/pair */
+uint64_t orc_pair_counter(void);
+
+/* ---- fixed-step N-body integrator (no solout) --------------------------------------------------- */
+typedef struct orc_nbody orc_nbody;
+/* method: "QuinlanTremaine12" | "Stormer13" (LinearMultistep<_, f64, Substepper<4, BlanesMoan6B>>,
+ * integration/src/methods.rs:37-40) or any SRKN table name ("BlanesMoan6B", "BlanesMoan14A", ...)
+ * = FixedRungeKutta<SRKN>. h is signed (Backward = negative, propagators/mod.rs:78-82). */
+orc_nbody *orc_nbody_new(int n, const double *pos, const double *vel, const double *mu, double t0, double h,
+                         const char *method);
+orc_nbody *orc_nbody_clone(const orc_nbody *);
+void orc_nbody_free(orc_nbody *);
+int orc_nbody_advance(orc_nbody *, int64_t nsteps); /* nsteps x Integrator::advance */
+void orc_nbody_get_state(const orc_nbody *, double *pos, double *vel, double *t, uint32_t *step_count);
+void orc_nbody_get_acc(const orc_nbody *, double *acc); /* current_ddy of the multistep / ddy of SRKN */
+void orc_nbody_set_bound(orc_nbody *, double bound);
+uint64_t orc_nbody_eval_count(const orc_nbody *);
+
+/* ---- NBodyPropagator + SplineInterpolators solout + UniformSpline ------------------------------ */
+typedef struct orc_prop orc_prop;
+/* dt > 0; direction +1 Forward / -1 Backward; count[b] = sample_period_b / dt (load/mod.rs:325),
+ * degree[b] = LeastSquaresFit.degree */
+orc_prop *orc_prop_new(int n, const double *pos, const double *vel, const double *mu, double t0, double dt,
+                       int direction, const char *method, const uint32_t *count, const uint32_t *degree);
+orc_prop *orc_prop_clone(const orc_prop *);
+void orc_prop_free(orc_prop *);
+int orc_prop_step(orc_prop *);               /* IncrementalPropagator::step  nbody.rs:200-207 */
+int orc_prop_step_to(orc_prop *, double t);  /* ephemeris/src/lib.rs:49-60 */
+double orc_prop_time(const orc_prop *);      /* DirectionalPropagator::time  nbody.rs:225-227,502-508 */
+int orc_prop_has_reached(const orc_prop *, double t);
+double orc_prop_integrator_time(const orc_prop *); /* NBodyPropagator::time nbody.rs:150-152 */
+void orc_prop_get_state(const orc_prop *, double *pos, double *vel, double *t, uint32_t *step_count);
+
+typedef struct orc_solution orc_solution;   /* Vec<UniformSpline<DVec3>> */
+orc_solution *orc_prop_take_solution(orc_prop *); /* nbody.rs:182-189 */
+void orc_solution_free(orc_solution *);
+int orc_solution_bodies(const orc_solution *);
+/* per body: start [s], interval [s], number of polynomials */
+void orc_solution_info(const orc_solution *, int body, double *start, double *interval, int64_t *npoly);
+/* copies npoly*8*3 doubles (coeff k of poly p at [(p*8+k)*3 + c], zero padded) and npoly coefficient counts */
+void orc_solution_coeffs(const orc_solution *, int body, double *coeffs, int32_t *ncoef);
+/* UniformSpline::position / state_vector (trajectory.rs:459-470); returns 1 if `at` is inside, else 0 */
+int orc_solution_eval(const orc_solution *, int body, double at, double *pos, double *vel);
+/* append b to a (UniformSpline::append / prepend, trajectory.rs:515-539); returns 0 on contiguity failure */
+int orc_solution_append(orc_solution *a, const orc_solution *b, int direction);
+
+/* LeastSquaresFit::interpolate (ephemeris_explorer/src/dynamics/celestial.rs:24-135):
+ * ts[m], xs[m*3] -> coeffs[8*3] (zero padded), returns ncoef after trim, or -1 on Err(()) */
+int orc_least_squares_fit(int degree, int m, const double *ts, const double *xs, double *coeffs);
+/* Polynomial::eval_and_deriv on one 8x3 coefficient block (trajectory.rs:368-385) */
+void orc_poly_eval_and_deriv(int ncoef, const double *coeffs, double tau, double *val, double *deriv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

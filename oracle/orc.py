@@ -1,0 +1,304 @@
+"""ctypes binding of the CPU oracle (oracle/libeph_oracle.so). TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package `ephemeris_explorer_amd` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+
+OK, STEP_SIZE_UNDERFLOW, MAX_ITERATIONS, BOUND_REACHED, EVAL_FAILED, SOLOUT_EXIT = 0, 1, 2, 3, 4, 5
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build(native=False):
+    target = "libeph_oracle_native.so" if native else "libeph_oracle.so"
+    subprocess.check_call(["make", "-s", "-C", str(HERE), target])
+    return HERE / target
+
+
+def _ptr(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+_libs = {}
+
+
+def lib(native=False):
+    if native in _libs:
+        return _libs[native]
+    path = HERE / ("libeph_oracle_native.so" if native else "libeph_oracle.so")
+    if not path.exists() or path.stat().st_mtime < (HERE / "eph_oracle.c").stat().st_mtime:
+        build(native)
+    L = C.CDLL(str(path))
+    vp = C.c_void_p
+    L.orc_ratio_from_f64.restype = C.c_double
+    L.orc_ratio_from_f64.argtypes = [C.c_double, C.POINTER(C.c_int64)]
+    L.orc_ratio_to_f64.restype = C.c_double
+    L.orc_ratio_to_f64.argtypes = [C.c_int64, C.c_uint64, C.c_int64, C.c_uint64]
+    L.orc_srkn_coeffs.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]
+    L.orc_elm2_coeffs.argtypes = [C.c_char_p, C.POINTER(C.c_int), _dp, _dp, _dp, _dp, _dp]
+    L.orc_erk_coeffs.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4 + [_dp] * 4
+    L.orc_newtonian_gravity_eval.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.orc_newtonian_gravity_eval.restype = None
+    L.orc_pair_counter.restype = C.c_uint64
+    L.orc_nbody_new.restype = vp
+    L.orc_nbody_new.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_char_p]
+    L.orc_nbody_clone.restype = vp
+    L.orc_nbody_clone.argtypes = [vp]
+    L.orc_nbody_free.argtypes = [vp]
+    L.orc_nbody_free.restype = None
+    L.orc_nbody_advance.argtypes = [vp, C.c_int64]
+    L.orc_nbody_get_state.argtypes = [vp, _dp, _dp, _dp, _u32p]
+    L.orc_nbody_get_state.restype = None
+    L.orc_nbody_get_acc.argtypes = [vp, _dp]
+    L.orc_nbody_get_acc.restype = None
+    L.orc_nbody_set_bound.argtypes = [vp, C.c_double]
+    L.orc_nbody_set_bound.restype = None
+    L.orc_nbody_eval_count.argtypes = [vp]
+    L.orc_nbody_eval_count.restype = C.c_uint64
+    L.orc_prop_new.restype = vp
+    L.orc_prop_new.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_char_p, _u32p, _u32p]
+    L.orc_prop_clone.restype = vp
+    L.orc_prop_clone.argtypes = [vp]
+    L.orc_prop_free.argtypes = [vp]
+    L.orc_prop_free.restype = None
+    L.orc_prop_step.argtypes = [vp]
+    L.orc_prop_step_to.argtypes = [vp, C.c_double]
+    L.orc_prop_time.argtypes = [vp]
+    L.orc_prop_time.restype = C.c_double
+    L.orc_prop_has_reached.argtypes = [vp, C.c_double]
+    L.orc_prop_integrator_time.argtypes = [vp]
+    L.orc_prop_integrator_time.restype = C.c_double
+    L.orc_prop_get_state.argtypes = [vp, _dp, _dp, _dp, _u32p]
+    L.orc_prop_get_state.restype = None
+    L.orc_prop_take_solution.restype = vp
+    L.orc_prop_take_solution.argtypes = [vp]
+    L.orc_solution_free.argtypes = [vp]
+    L.orc_solution_free.restype = None
+    L.orc_solution_bodies.argtypes = [vp]
+    L.orc_solution_info.argtypes = [vp, C.c_int, _dp, _dp, C.POINTER(C.c_int64)]
+    L.orc_solution_info.restype = None
+    L.orc_solution_coeffs.argtypes = [vp, C.c_int, _dp, _i32p]
+    L.orc_solution_coeffs.restype = None
+    L.orc_solution_eval.argtypes = [vp, C.c_int, C.c_double, _dp, _dp]
+    L.orc_solution_append.argtypes = [vp, vp, C.c_int]
+    L.orc_least_squares_fit.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    L.orc_poly_eval_and_deriv.argtypes = [C.c_int, _dp, C.c_double, _dp, _dp]
+    L.orc_poly_eval_and_deriv.restype = None
+    _libs[native] = L
+    return L
+
+
+# ---------------------------------------------------------------------------------------------------
+def ratio_from_f64(v):
+    out = (C.c_int64 * 4)()
+    f = lib().orc_ratio_from_f64(float(v), out)
+    n = (out[0] << 64) | (out[1] & 0xFFFFFFFFFFFFFFFF)
+    d = (out[2] << 64) | (out[3] & 0xFFFFFFFFFFFFFFFF)
+    return n, d, f
+
+
+def srkn_coeffs(name):
+    A = np.zeros(32)
+    B = np.zeros(32)
+    s, f = C.c_int(), C.c_int()
+    if lib().orc_srkn_coeffs(name.encode(), C.byref(s), C.byref(f), _ptr(A), _ptr(B)):
+        raise KeyError(name)
+    return A[: s.value].copy(), B[: s.value].copy(), bool(f.value)
+
+
+def elm2_coeffs(name):
+    wa, wb, cw = np.zeros(16), np.zeros(16), np.zeros(16)
+    o = C.c_int()
+    ib, ic = C.c_double(), C.c_double()
+    if lib().orc_elm2_coeffs(name.encode(), C.byref(o), _ptr(wa), _ptr(wb), C.byref(ib), _ptr(cw), C.byref(ic)):
+        raise KeyError(name)
+    k = o.value
+    return dict(order=k, w_alpha=wa[:k].copy(), w_beta=wb[:k].copy(), inv_beta_d=ib.value,
+                cowell=cw[:k].copy(), inv_cowell_d=ic.value)
+
+
+def erk_coeffs(name):
+    A, B, Cc, E = np.zeros(16 * 16), np.zeros(16), np.zeros(16), np.zeros(16)
+    s, o, oe, f = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if lib().orc_erk_coeffs(name.encode(), C.byref(s), C.byref(o), C.byref(oe), C.byref(f), _ptr(A), _ptr(B),
+                            _ptr(Cc), _ptr(E)):
+        raise KeyError(name)
+    n = s.value
+    rows, k = [], 0
+    for i in range(n):
+        rows.append(A[k : k + i].copy())
+        k += i
+    return dict(stages=n, order=o.value, order_embedded=oe.value, fsal=bool(f.value), A=rows, B=B[:n].copy(),
+                C=Cc[:n].copy(), E=E[:n].copy())
+
+
+def gravity(pos, mu, native=False):
+    pos = _f64(pos)
+    mu = _f64(mu)
+    acc = np.zeros_like(pos)
+    lib(native).orc_newtonian_gravity_eval(len(mu), _ptr(pos), _ptr(mu), _ptr(acc))
+    return acc
+
+
+class NBody:
+    """orc_nbody: Method::integrate(problem) without a solout."""
+
+    def __init__(self, pos, vel, mu, t0, h, method="QuinlanTremaine12", native=False, _handle=None):
+        self.L = lib(native)
+        self.native = native
+        if _handle is not None:
+            self.h, self.n = _handle
+            return
+        pos, vel, mu = _f64(pos), _f64(vel), _f64(mu)
+        self.n = len(mu)
+        self.h = self.L.orc_nbody_new(self.n, _ptr(pos), _ptr(vel), _ptr(mu), float(t0), float(h), method.encode())
+        if not self.h:
+            raise ValueError(f"unknown method {method}")
+
+    def clone(self):
+        return NBody(None, None, None, 0, 0, native=self.native, _handle=(self.L.orc_nbody_clone(self.h), self.n))
+
+    def advance(self, nsteps=1):
+        return self.L.orc_nbody_advance(self.h, int(nsteps))
+
+    def state(self):
+        pos = np.zeros((self.n, 3))
+        vel = np.zeros((self.n, 3))
+        t = C.c_double()
+        sc = C.c_uint32()
+        self.L.orc_nbody_get_state(self.h, _ptr(pos), _ptr(vel), C.byref(t), C.byref(sc))
+        return pos, vel, t.value, sc.value
+
+    def acc(self):
+        a = np.zeros((self.n, 3))
+        self.L.orc_nbody_get_acc(self.h, _ptr(a))
+        return a
+
+    def set_bound(self, b):
+        self.L.orc_nbody_set_bound(self.h, float(b))
+
+    def eval_count(self):
+        return self.L.orc_nbody_eval_count(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_nbody_free(self.h)
+            self.h = None
+
+
+class Solution:
+    """Vec<UniformSpline<DVec3>>"""
+
+    def __init__(self, L, handle):
+        self.L, self.h = L, handle
+        self.n = L.orc_solution_bodies(handle)
+
+    def info(self, body):
+        s, i, n = C.c_double(), C.c_double(), C.c_int64()
+        self.L.orc_solution_info(self.h, body, C.byref(s), C.byref(i), C.byref(n))
+        return s.value, i.value, n.value
+
+    def coeffs(self, body):
+        _, _, n = self.info(body)
+        co = np.zeros((max(n, 1), 8, 3))
+        nc = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_solution_coeffs(self.h, body, _ptr(co), _ptr(nc, _i32p))
+        return co[:n], nc[:n]
+
+    def eval(self, body, at, with_velocity=True):
+        p, v = np.zeros(3), np.zeros(3)
+        ok = self.L.orc_solution_eval(self.h, body, float(at), _ptr(p), _ptr(v) if with_velocity else None)
+        if not ok:
+            return None
+        return (p, v) if with_velocity else p
+
+    def append(self, other, direction=1):
+        return bool(self.L.orc_solution_append(self.h, other.h, direction))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_solution_free(self.h)
+            self.h = None
+
+
+class Propagator:
+    """ephemeris::NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>>"""
+
+    def __init__(self, pos, vel, mu, t0, dt, direction, count, degree, method="QuinlanTremaine12", native=False,
+                 _handle=None):
+        self.L = lib(native)
+        self.native = native
+        if _handle is not None:
+            self.h, self.n = _handle
+            return
+        pos, vel, mu = _f64(pos), _f64(vel), _f64(mu)
+        count = np.ascontiguousarray(count, dtype=np.uint32)
+        degree = np.ascontiguousarray(degree, dtype=np.uint32)
+        self.n = len(mu)
+        self.h = self.L.orc_prop_new(self.n, _ptr(pos), _ptr(vel), _ptr(mu), float(t0), float(dt), int(direction),
+                                     method.encode(), _ptr(count, _u32p), _ptr(degree, _u32p))
+        if not self.h:
+            raise ValueError(f"unknown method {method}")
+
+    def clone(self):
+        return Propagator(None, None, None, 0, 0, 0, None, None, native=self.native,
+                          _handle=(self.L.orc_prop_clone(self.h), self.n))
+
+    def step(self):
+        return self.L.orc_prop_step(self.h)
+
+    def step_to(self, t):
+        return self.L.orc_prop_step_to(self.h, float(t))
+
+    def time(self):
+        return self.L.orc_prop_time(self.h)
+
+    def has_reached(self, t):
+        return bool(self.L.orc_prop_has_reached(self.h, float(t)))
+
+    def integrator_time(self):
+        return self.L.orc_prop_integrator_time(self.h)
+
+    def state(self):
+        pos = np.zeros((self.n, 3))
+        vel = np.zeros((self.n, 3))
+        t = C.c_double()
+        sc = C.c_uint32()
+        self.L.orc_prop_get_state(self.h, _ptr(pos), _ptr(vel), C.byref(t), C.byref(sc))
+        return pos, vel, t.value, sc.value
+
+    def take_solution(self):
+        return Solution(self.L, self.L.orc_prop_take_solution(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_prop_free(self.h)
+            self.h = None
+
+
+def least_squares_fit(degree, ts, xs):
+    ts, xs = _f64(ts), _f64(xs)
+    co = np.zeros((8, 3))
+    n = lib().orc_least_squares_fit(int(degree), len(ts), _ptr(ts), _ptr(xs), _ptr(co))
+    return co, n
+
+
+def poly_eval_and_deriv(coeffs, ncoef, tau):
+    coeffs = _f64(coeffs)
+    v, d = np.zeros(3), np.zeros(3)
+    lib().orc_poly_eval_and_deriv(int(ncoef), _ptr(coeffs), float(tau), _ptr(v), _ptr(d))
+    return v, d
