@@ -1,0 +1,390 @@
+"""ephemeris_explorer_amd -- MI355X-native ephemeris propagator (one hot path of Canleskis/ephemeris-explorer).
+
+Python view of the C ABI in include/ephemeris_amd.h (libephemeris_amd.so, hand-written HIP for gfx950). The class
+and method names mirror the reference's operator surface (paths relative to the reference repository):
+
+    NBodyIntegration   = M::new(FixedMethodParams::new(h)).integrate(NBodyProblem{..})   integration/src/lib.rs
+    NBodyPropagator    = ephemeris::NBodyPropagator<D, DVec3, M, SplineInterpolators<..>>   ephemeris/src/propagators/nbody.rs
+    Solution           = Vec<UniformSpline<DVec3>>                                          ephemeris/src/trajectory.rs
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is visible, every compute call
+raises. (The CPU oracle lives in oracle/ and is test infrastructure only; this package never imports it.)
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import systems  # noqa: F401  (state.json / ephemeris.json / ships readers)
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libephemeris_amd.so"
+
+FORWARD, BACKWARD = 1, -1
+
+OK = 0
+STEP_SIZE_UNDERFLOW, MAX_ITERATIONS_REACHED, BOUND_REACHED, EVAL_FAILED, SOLOUT_EXIT = 1, 2, 3, 4, 5
+ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = -1, -2, -3, -4, -5
+
+# every symbol include/ephemeris_amd.h declares (tests check the .so exports exactly these)
+ABI_SYMBOLS = [
+    "eph_abi_version", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
+    "eph_device_name", "eph_srkn_coeffs", "eph_elm2_coeffs", "eph_accel_eval",
+    "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
+    "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
+    "eph_nbody_enable_timing",
+    "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
+    "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
+    "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
+    "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append",
+    "eph_solution_destroy", "eph_least_squares_fit",
+]
+
+
+class EphemerisError(RuntimeError):
+    """A library / device failure (negative status)."""
+
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = _lib().eph_status_string(status).decode()
+        detail = _lib().eph_last_error().decode()
+        super().__init__(f"{where}: {msg}" + (f" [{detail}]" if detail else ""))
+
+
+class StepError(Exception):
+    """integration::StepError / NBodyPropagatorError (positive status): errors the reference returns as values."""
+
+    NAMES = {1: "StepSizeUnderflow", 2: "MaxIterationsReached", 3: "BoundReached", 4: "EvalFailed", 5: "Solout"}
+
+    def __init__(self, status):
+        self.status = status
+        super().__init__(self.NAMES.get(status, str(status)))
+
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+_L = None
+
+
+def _lib():
+    """Loads libephemeris_amd.so; raises if it has not been built (no fallback of any kind)."""
+    global _L
+    if _L is not None:
+        return _L
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc, gfx950). ephemeris_explorer_amd has no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.eph_abi_version.restype = i32
+    L.eph_status_string.restype = C.c_char_p
+    L.eph_status_string.argtypes = [i32]
+    L.eph_last_error.restype = C.c_char_p
+    L.eph_device_count.argtypes = [_i32p]
+    L.eph_set_device.argtypes = [i32]
+    L.eph_device_name.argtypes = [C.c_char_p, i32]
+    L.eph_srkn_coeffs.argtypes = [C.c_char_p, _i32p, _i32p, _dp, _dp]
+    L.eph_elm2_coeffs.argtypes = [C.c_char_p, _i32p, _dp, _dp, _dp, _dp, _dp]
+    L.eph_accel_eval.argtypes = [i32, _dp, _dp, _dp]
+    L.eph_nbody_create.argtypes = [i32, _dp, _dp, _dp, f64, f64, C.c_char_p, C.POINTER(vp)]
+    L.eph_nbody_advance.argtypes = [vp, i64]
+    L.eph_nbody_get_state.argtypes = [vp, _dp, _dp, _dp, _u32p]
+    L.eph_nbody_get_acc.argtypes = [vp, _dp]
+    L.eph_nbody_set_bound.argtypes = [vp, f64]
+    L.eph_nbody_clone.argtypes = [vp, C.POINTER(vp)]
+    L.eph_nbody_destroy.argtypes = [vp]
+    L.eph_nbody_destroy.restype = None
+    L.eph_nbody_eval_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.eph_nbody_set_path.argtypes = [vp, i32]
+    L.eph_nbody_kernel_time.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
+    L.eph_nbody_enable_timing.argtypes = [vp, i32]
+    L.eph_prop_create.argtypes = [i32, _dp, _dp, _dp, f64, f64, i32, C.c_char_p, _u32p, _u32p, C.POINTER(vp)]
+    L.eph_prop_step.argtypes = [vp]
+    L.eph_prop_step_n.argtypes = [vp, i64]
+    L.eph_prop_step_to.argtypes = [vp, f64]
+    L.eph_prop_time.argtypes = [vp, _dp]
+    L.eph_prop_has_reached.argtypes = [vp, f64, _i32p]
+    L.eph_prop_integrator_time.argtypes = [vp, _dp]
+    L.eph_prop_get_state.argtypes = [vp, _dp, _dp, _dp, _u32p]
+    L.eph_prop_take_solution.argtypes = [vp, C.POINTER(vp)]
+    L.eph_prop_propagate.argtypes = [vp, f64, C.POINTER(vp)]
+    L.eph_prop_clone.argtypes = [vp, C.POINTER(vp)]
+    L.eph_prop_destroy.argtypes = [vp]
+    L.eph_prop_destroy.restype = None
+    L.eph_prop_integrator.argtypes = [vp]
+    L.eph_prop_integrator.restype = vp
+    L.eph_solution_bodies.argtypes = [vp, _i32p]
+    L.eph_solution_info.argtypes = [vp, i32, _dp, _dp, C.POINTER(i64)]
+    L.eph_solution_coeffs.argtypes = [vp, i32, _dp, _i32p]
+    L.eph_solution_eval.argtypes = [vp, i32, i64, _dp, _dp, _dp, _u8p]
+    L.eph_solution_append.argtypes = [vp, vp, i32]
+    L.eph_solution_destroy.argtypes = [vp]
+    L.eph_solution_destroy.restype = None
+    L.eph_least_squares_fit.argtypes = [i32, i32, i64, _dp, _dp, _i32p]
+    if L.eph_abi_version() != 1:
+        raise ImportError("libephemeris_amd.so ABI version mismatch")
+    _L = L
+    return L
+
+
+def _check(st, where):
+    if st < 0:
+        raise EphemerisError(st, where)
+    return st
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    n = C.c_int32()
+    _check(_lib().eph_device_count(C.byref(n)), "eph_device_count")
+    return n.value
+
+
+def set_device(i):
+    _check(_lib().eph_set_device(int(i)), "eph_set_device")
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    _check(_lib().eph_device_name(buf, 256), "eph_device_name")
+    return buf.value.decode()
+
+
+def srkn_coeffs(name):
+    A, B = np.zeros(32), np.zeros(32)
+    s, f = C.c_int32(), C.c_int32()
+    _check(_lib().eph_srkn_coeffs(name.encode(), C.byref(s), C.byref(f), _p(A), _p(B)), "eph_srkn_coeffs")
+    return A[: s.value].copy(), B[: s.value].copy(), bool(f.value)
+
+
+def elm2_coeffs(name):
+    wa, wb, cw = np.zeros(16), np.zeros(16), np.zeros(16)
+    o = C.c_int32()
+    ib, ic = C.c_double(), C.c_double()
+    _check(_lib().eph_elm2_coeffs(name.encode(), C.byref(o), _p(wa), _p(wb), C.byref(ib), _p(cw), C.byref(ic)),
+           "eph_elm2_coeffs")
+    k = o.value
+    return dict(order=k, w_alpha=wa[:k].copy(), w_beta=wb[:k].copy(), inv_beta_d=ib.value, cowell=cw[:k].copy(),
+                inv_cowell_d=ic.value)
+
+
+def accel_eval(pos, mu, acc=None):
+    """SecondOrderODE::eval for NewtonianGravity: returns acc (+= the accelerations, reference summation order)."""
+    pos, mu = _f64(pos), _f64(mu)
+    acc = np.zeros_like(pos) if acc is None else _f64(acc).copy()
+    _check(_lib().eph_accel_eval(len(mu), _p(pos), _p(mu), _p(acc)), "eph_accel_eval")
+    return acc
+
+
+def least_squares_fit(degree, samples, backward=False):
+    """LeastSquaresFit::interpolate on windows of 9 samples: samples [nwin, 9, 3] -> (coeffs [nwin, 8, 3], ncoef)."""
+    samples = _f64(samples).reshape(-1, 9, 3)
+    nwin = samples.shape[0]
+    co = np.zeros((nwin, 8, 3))
+    nc = np.zeros(nwin, dtype=np.int32)
+    _check(_lib().eph_least_squares_fit(int(degree), int(bool(backward)), nwin, _p(samples), _p(co), _p(nc, _i32p)),
+           "eph_least_squares_fit")
+    return co, nc
+
+
+class NBodyIntegration:
+    """Integration<NBodyProblem<DVec3>, M> (no solout). method: "QuinlanTremaine12", "Stormer13" or an SRKN name."""
+
+    def __init__(self, pos, vel, mu, t0, h, method="QuinlanTremaine12", _handle=None, _owned=True):
+        self._L = _lib()
+        self._owned = _owned
+        if _handle is not None:
+            self._h, self.n = _handle
+            return
+        pos, vel, mu = _f64(pos), _f64(vel), _f64(mu)
+        self.n = len(mu)
+        h_ = C.c_void_p()
+        st = self._L.eph_nbody_create(self.n, _p(pos), _p(vel), _p(mu), float(t0), float(h), method.encode(),
+                                      C.byref(h_))
+        _check(st, "eph_nbody_create")
+        self._h = h_
+
+    def advance(self, n_steps=1):
+        """n_steps x Integrator::advance; raises StepError like the reference returns Err."""
+        st = _check(self._L.eph_nbody_advance(self._h, int(n_steps)), "eph_nbody_advance")
+        if st:
+            raise StepError(st)
+
+    def state(self):
+        pos, vel = np.zeros((self.n, 3)), np.zeros((self.n, 3))
+        t, sc = C.c_double(), C.c_uint32()
+        _check(self._L.eph_nbody_get_state(self._h, _p(pos), _p(vel), C.byref(t), C.byref(sc)), "eph_nbody_get_state")
+        return pos, vel, t.value, sc.value
+
+    def acc(self):
+        a = np.zeros((self.n, 3))
+        _check(self._L.eph_nbody_get_acc(self._h, _p(a)), "eph_nbody_get_acc")
+        return a
+
+    def set_bound(self, b):
+        _check(self._L.eph_nbody_set_bound(self._h, float(b)), "eph_nbody_set_bound")
+
+    def set_path(self, path):
+        _check(self._L.eph_nbody_set_path(self._h, int(path)), "eph_nbody_set_path")
+
+    def enable_timing(self, on=True):
+        _check(self._L.eph_nbody_enable_timing(self._h, int(on)), "eph_nbody_enable_timing")
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self._L.eph_nbody_kernel_time(self._h, C.byref(ms), C.byref(n)), "eph_nbody_kernel_time")
+        return ms.value, n.value
+
+    def eval_count(self):
+        n = C.c_uint64()
+        _check(self._L.eph_nbody_eval_count(self._h, C.byref(n)), "eph_nbody_eval_count")
+        return n.value
+
+    def clone(self):
+        h_ = C.c_void_p()
+        _check(self._L.eph_nbody_clone(self._h, C.byref(h_)), "eph_nbody_clone")
+        return NBodyIntegration(None, None, None, 0, 0, _handle=(h_, self.n))
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "_h", None):
+            self._L.eph_nbody_destroy(self._h)
+            self._h = None
+
+
+class Solution:
+    """Vec<UniformSpline<DVec3>>"""
+
+    def __init__(self, handle):
+        self._L = _lib()
+        self._h = handle
+        n = C.c_int32()
+        _check(self._L.eph_solution_bodies(handle, C.byref(n)), "eph_solution_bodies")
+        self.n = n.value
+
+    def info(self, body):
+        s, i, n = C.c_double(), C.c_double(), C.c_int64()
+        _check(self._L.eph_solution_info(self._h, body, C.byref(s), C.byref(i), C.byref(n)), "eph_solution_info")
+        return s.value, i.value, n.value
+
+    def coeffs(self, body):
+        n = self.info(body)[2]
+        co = np.zeros((max(n, 1), 8, 3))
+        nc = np.zeros(max(n, 1), dtype=np.int32)
+        _check(self._L.eph_solution_coeffs(self._h, body, _p(co), _p(nc, _i32p)), "eph_solution_coeffs")
+        return co[:n], nc[:n]
+
+    def eval(self, body, at, with_velocity=True):
+        """EvaluateTrajectory::state_vector / position at many epochs -> (pos, vel|None, inside)."""
+        at = _f64(np.atleast_1d(at))
+        m = len(at)
+        pos = np.zeros((m, 3))
+        vel = np.zeros((m, 3)) if with_velocity else None
+        inside = np.zeros(m, dtype=np.uint8)
+        _check(self._L.eph_solution_eval(self._h, body, m, _p(at), _p(pos), _p(vel) if with_velocity else None,
+                                         _p(inside, _u8p)), "eph_solution_eval")
+        return pos, vel, inside.astype(bool)
+
+    def append(self, tail, direction=FORWARD):
+        st = self._L.eph_solution_append(self._h, tail._h, int(direction))
+        if st == ERR_BAD_ARGUMENT:
+            raise ValueError("splines are not contiguous (UniformSpline::append/prepend assert)")
+        _check(st, "eph_solution_append")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.eph_solution_destroy(self._h)
+            self._h = None
+
+
+class NBodyPropagator:
+    """NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>> on the device."""
+
+    def __init__(self, pos, vel, mu, t0, dt, direction, count, degree, method="QuinlanTremaine12", _handle=None):
+        self._L = _lib()
+        if _handle is not None:
+            self._h, self.n = _handle
+            return
+        pos, vel, mu = _f64(pos), _f64(vel), _f64(mu)
+        count = np.ascontiguousarray(count, dtype=np.uint32)
+        degree = np.ascontiguousarray(degree, dtype=np.uint32)
+        self.n = len(mu)
+        h_ = C.c_void_p()
+        st = self._L.eph_prop_create(self.n, _p(pos), _p(vel), _p(mu), float(t0), float(dt), int(direction),
+                                     method.encode(), _p(count, _u32p), _p(degree, _u32p), C.byref(h_))
+        _check(st, "eph_prop_create")
+        self._h = h_
+
+    @classmethod
+    def from_system(cls, system, direction=FORWARD, method="QuinlanTremaine12"):
+        """CelestialTrajectory::<D>::new_propagator (ephemeris_explorer/src/dynamics/celestial.rs:156-186)."""
+        return cls(system.pos, system.vel, system.mu, system.epoch, system.dt, direction, system.count, system.degree,
+                   method)
+
+    def _step_status(self, st, where):
+        st = _check(st, where)
+        if st:
+            raise StepError(st)
+
+    def step(self):
+        self._step_status(self._L.eph_prop_step(self._h), "eph_prop_step")
+
+    def step_n(self, n):
+        self._step_status(self._L.eph_prop_step_n(self._h, int(n)), "eph_prop_step_n")
+
+    def step_to(self, t):
+        self._step_status(self._L.eph_prop_step_to(self._h, float(t)), "eph_prop_step_to")
+
+    def time(self):
+        t = C.c_double()
+        _check(self._L.eph_prop_time(self._h, C.byref(t)), "eph_prop_time")
+        return t.value
+
+    def has_reached(self, t):
+        f = C.c_int32()
+        _check(self._L.eph_prop_has_reached(self._h, float(t), C.byref(f)), "eph_prop_has_reached")
+        return bool(f.value)
+
+    def integrator_time(self):
+        t = C.c_double()
+        _check(self._L.eph_prop_integrator_time(self._h, C.byref(t)), "eph_prop_integrator_time")
+        return t.value
+
+    def state(self):
+        pos, vel = np.zeros((self.n, 3)), np.zeros((self.n, 3))
+        t, sc = C.c_double(), C.c_uint32()
+        _check(self._L.eph_prop_get_state(self._h, _p(pos), _p(vel), C.byref(t), C.byref(sc)), "eph_prop_get_state")
+        return pos, vel, t.value, sc.value
+
+    def take_solution(self):
+        h_ = C.c_void_p()
+        _check(self._L.eph_prop_take_solution(self._h, C.byref(h_)), "eph_prop_take_solution")
+        return Solution(h_)
+
+    def propagate(self, to):
+        h_ = C.c_void_p()
+        self._step_status(self._L.eph_prop_propagate(self._h, float(to), C.byref(h_)), "eph_prop_propagate")
+        return Solution(h_)
+
+    def integration(self):
+        """the NBodyIntegration inside (borrowed)"""
+        return NBodyIntegration(None, None, None, 0, 0, _handle=(C.c_void_p(self._L.eph_prop_integrator(self._h)), self.n),
+                                _owned=False)
+
+    def clone(self):
+        h_ = C.c_void_p()
+        _check(self._L.eph_prop_clone(self._h, C.byref(h_)), "eph_prop_clone")
+        return NBodyPropagator(None, None, None, 0, 0, 0, None, None, _handle=(h_, self.n))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.eph_prop_destroy(self._h)
+            self._h = None

@@ -1,0 +1,352 @@
+// api.cpp -- the extern "C" boundary (include/ephemeris_amd.h). Thin: argument checks, handle ownership,
+// status codes. No exceptions cross the boundary.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "host.h"
+
+namespace eph {
+namespace {
+thread_local std::string g_last_error;
+}
+void set_last_error(const char *what, hipError_t e) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+void set_last_error_text(const std::string &s) { g_last_error = s; }
+
+// The product path has no CPU fallback: without a HIP device every compute entry point fails loudly.
+int check_device() {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_last_error = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e)
+                                       : std::string("no HIP device visible");
+        (void)hipGetLastError();
+        return EPH_ERR_NO_DEVICE;
+    }
+    return EPH_OK;
+}
+}  // namespace eph
+
+using namespace eph;
+
+struct eph_nbody {
+    std::unique_ptr<NBodyIntegration> own;
+    NBodyIntegration *p = nullptr;
+};
+struct eph_prop {
+    std::unique_ptr<NBodyPropagator> p;
+    eph_nbody view;
+};
+struct eph_solution {
+    Solution s;
+};
+
+#define EPH_GUARD_BEGIN try {
+#define EPH_GUARD_END                                   \
+    }                                                   \
+    catch (const std::bad_alloc &) {                    \
+        return EPH_ERR_OUT_OF_MEMORY;                   \
+    }                                                   \
+    catch (...) {                                       \
+        set_last_error_text("unexpected C++ exception"); \
+        return EPH_ERR_HIP;                             \
+    }
+
+extern "C" {
+
+int32_t eph_abi_version(void) { return EPH_ABI_VERSION; }
+
+const char *eph_status_string(int32_t st) {
+    switch (st) {
+        case EPH_OK: return "ok";
+        case EPH_STEP_SIZE_UNDERFLOW: return "step size underflow";          // lib.rs:323-331
+        case EPH_MAX_ITERATIONS_REACHED: return "max iterations reached";
+        case EPH_BOUND_REACHED: return "integration bound reached";
+        case EPH_EVAL_FAILED: return "failed to evaluate ODE";
+        case EPH_SOLOUT_EXIT: return "solout exit";                          // nbody.rs:52
+        case EPH_ERR_BAD_ARGUMENT: return "bad argument";
+        case EPH_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+        case EPH_ERR_HIP: return "HIP runtime error";
+        case EPH_ERR_UNSUPPORTED: return "unsupported configuration";
+        case EPH_ERR_OUT_OF_MEMORY: return "out of memory";
+        default: return "unknown status";
+    }
+}
+const char *eph_last_error(void) { return g_last_error.c_str(); }
+
+int32_t eph_device_count(int32_t *count) {
+    if (!count) return EPH_ERR_BAD_ARGUMENT;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *count = c;
+    return EPH_OK;
+}
+int32_t eph_set_device(int32_t device) {
+    int st = check_device();
+    if (st) return st;
+    EPH_HIP(hipSetDevice(device));
+    return EPH_OK;
+}
+int32_t eph_device_name(char *buf, int32_t buflen) {
+    if (!buf || buflen <= 0) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    int dev = 0;
+    EPH_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    EPH_HIP(hipGetDeviceProperties(&prop, dev));
+    std::snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return EPH_OK;
+}
+
+int32_t eph_srkn_coeffs(const char *name, int32_t *stages, int32_t *fsal, double *A, double *B) {
+    SrknCoeffs c;
+    if (!name || !stages || !fsal || !A || !B || !find_srkn(name, &c)) return EPH_ERR_BAD_ARGUMENT;
+    *stages = c.stages;
+    *fsal = c.fsal;
+    for (int s = 0; s < c.stages; ++s) { A[s] = c.A[s]; B[s] = c.B[s]; }
+    return EPH_OK;
+}
+int32_t eph_elm2_coeffs(const char *name, int32_t *order, double *wa, double *wb, double *inv_beta_d, double *cw,
+                        double *inv_cowell_d) {
+    Elm2Coeffs c;
+    if (!name || !order || !wa || !wb || !inv_beta_d || !cw || !inv_cowell_d || !find_elm2(name, &c))
+        return EPH_ERR_BAD_ARGUMENT;
+    *order = c.order;
+    for (int j = 0; j < c.order; ++j) { wa[j] = c.wa[j]; wb[j] = c.wb[j]; cw[j] = c.cw[j]; }
+    *inv_beta_d = c.inv_beta_d;
+    *inv_cowell_d = c.inv_cowell_d;
+    return EPH_OK;
+}
+
+int32_t eph_accel_eval(int32_t n, const double *pos, const double *mu, double *acc) {
+    EPH_GUARD_BEGIN
+    return accel_eval_device(n, pos, mu, acc);
+    EPH_GUARD_END
+}
+
+// ---- eph_nbody --------------------------------------------------------------------------------------
+int32_t eph_nbody_create(int32_t n, const double *pos, const double *vel, const double *mu, double t0, double h,
+                         const char *method, eph_nbody **out) {
+    EPH_GUARD_BEGIN
+    if (!out) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<eph_nbody> hnd(new eph_nbody());
+    int st = NBodyIntegration::create(n, pos, vel, mu, t0, h, method, &hnd->own);
+    if (st) return st;
+    hnd->p = hnd->own.get();
+    *out = hnd.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
+int32_t eph_nbody_advance(eph_nbody *h, int64_t n_steps) {
+    EPH_GUARD_BEGIN
+    if (!h || !h->p || n_steps < 0) return EPH_ERR_BAD_ARGUMENT;
+    return h->p->advance(n_steps);
+    EPH_GUARD_END
+}
+int32_t eph_nbody_get_state(eph_nbody *h, double *pos, double *vel, double *t, uint32_t *sc) {
+    EPH_GUARD_BEGIN
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    return h->p->get_state(pos, vel, t, sc);
+    EPH_GUARD_END
+}
+int32_t eph_nbody_get_acc(eph_nbody *h, double *acc) {
+    EPH_GUARD_BEGIN
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    return h->p->get_acc(acc);
+    EPH_GUARD_END
+}
+int32_t eph_nbody_set_bound(eph_nbody *h, double bound) {
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    h->p->set_bound(bound);
+    return EPH_OK;
+}
+int32_t eph_nbody_clone(eph_nbody *h, eph_nbody **out) {
+    EPH_GUARD_BEGIN
+    if (!h || !h->p || !out) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<eph_nbody> c(new eph_nbody());
+    int st = h->p->clone(&c->own);
+    if (st) return st;
+    c->p = c->own.get();
+    *out = c.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
+void eph_nbody_destroy(eph_nbody *h) {
+    if (h && h->own) delete h;   // borrowed views (eph_prop_integrator) are not owned
+}
+int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count) {
+    if (!h || !h->p || !count) return EPH_ERR_BAD_ARGUMENT;
+    *count = h->p->evals();
+    return EPH_OK;
+}
+int32_t eph_nbody_set_path(eph_nbody *h, int32_t path) {
+    if (!h || !h->p || path < 0 || path > 2) return EPH_ERR_BAD_ARGUMENT;
+    h->p->set_path(path);
+    return EPH_OK;
+}
+int32_t eph_nbody_kernel_time(eph_nbody *h, double *total_ms, uint64_t *launches) {
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (total_ms) *total_ms = h->p->kernel_ms();
+    if (launches) *launches = h->p->kernel_launches();
+    return EPH_OK;
+}
+int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on) {
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    h->p->enable_timing(on != 0);
+    return EPH_OK;
+}
+
+// ---- eph_prop ---------------------------------------------------------------------------------------
+int32_t eph_prop_create(int32_t n, const double *pos, const double *vel, const double *mu, double t0, double dt,
+                        int32_t direction, const char *method, const uint32_t *count, const uint32_t *degree,
+                        eph_prop **out) {
+    EPH_GUARD_BEGIN
+    if (!out) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<eph_prop> hnd(new eph_prop());
+    int st = NBodyPropagator::create(n, pos, vel, mu, t0, dt, direction, method, count, degree, &hnd->p);
+    if (st) return st;
+    hnd->view.p = hnd->p->integration();
+    *out = hnd.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
+int32_t eph_prop_step(eph_prop *p) { return eph_prop_step_n(p, 1); }
+int32_t eph_prop_step_n(eph_prop *p, int64_t n) {
+    EPH_GUARD_BEGIN
+    if (!p || n < 0) return EPH_ERR_BAD_ARGUMENT;
+    return p->p->step_n(n);
+    EPH_GUARD_END
+}
+int32_t eph_prop_step_to(eph_prop *p, double t) {
+    EPH_GUARD_BEGIN
+    if (!p) return EPH_ERR_BAD_ARGUMENT;
+    return p->p->step_to(t);
+    EPH_GUARD_END
+}
+int32_t eph_prop_time(eph_prop *p, double *t) {
+    if (!p || !t) return EPH_ERR_BAD_ARGUMENT;
+    *t = p->p->time();
+    return EPH_OK;
+}
+int32_t eph_prop_has_reached(eph_prop *p, double t, int32_t *flag) {
+    if (!p || !flag) return EPH_ERR_BAD_ARGUMENT;
+    *flag = p->p->has_reached(t) ? 1 : 0;
+    return EPH_OK;
+}
+int32_t eph_prop_integrator_time(eph_prop *p, double *t) {
+    if (!p || !t) return EPH_ERR_BAD_ARGUMENT;
+    *t = p->p->integration()->time();
+    return EPH_OK;
+}
+int32_t eph_prop_get_state(eph_prop *p, double *pos, double *vel, double *t, uint32_t *sc) {
+    EPH_GUARD_BEGIN
+    if (!p) return EPH_ERR_BAD_ARGUMENT;
+    return p->p->integration()->get_state(pos, vel, t, sc);
+    EPH_GUARD_END
+}
+int32_t eph_prop_take_solution(eph_prop *p, eph_solution **out) {
+    EPH_GUARD_BEGIN
+    if (!p || !out) return EPH_ERR_BAD_ARGUMENT;
+    std::unique_ptr<Solution> s;
+    int st = p->p->take_solution(&s);
+    if (st) return st;
+    eph_solution *o = new eph_solution();
+    o->s = std::move(*s);
+    *out = o;
+    return EPH_OK;
+    EPH_GUARD_END
+}
+int32_t eph_prop_propagate(eph_prop *p, double to, eph_solution **out) {
+    int32_t st = eph_prop_step_to(p, to);
+    if (st) return st;
+    return eph_prop_take_solution(p, out);
+}
+int32_t eph_prop_clone(eph_prop *p, eph_prop **out) {
+    EPH_GUARD_BEGIN
+    if (!p || !out) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<eph_prop> c(new eph_prop());
+    int st = p->p->clone(&c->p);
+    if (st) return st;
+    c->view.p = c->p->integration();
+    *out = c.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
+void eph_prop_destroy(eph_prop *p) { delete p; }
+eph_nbody *eph_prop_integrator(eph_prop *p) { return p ? &p->view : nullptr; }
+
+// ---- eph_solution -----------------------------------------------------------------------------------
+int32_t eph_solution_bodies(const eph_solution *s, int32_t *n) {
+    if (!s || !n) return EPH_ERR_BAD_ARGUMENT;
+    *n = (int32_t)s->s.splines.size();
+    return EPH_OK;
+}
+int32_t eph_solution_info(const eph_solution *s, int32_t body, double *start, double *interval, int64_t *npoly) {
+    if (!s || body < 0 || (size_t)body >= s->s.splines.size()) return EPH_ERR_BAD_ARGUMENT;
+    const UniformSpline &u = s->s.splines[body];
+    if (start) *start = u.start;
+    if (interval) *interval = u.interval;
+    if (npoly) *npoly = (int64_t)u.polynomials.size();
+    return EPH_OK;
+}
+int32_t eph_solution_coeffs(const eph_solution *s, int32_t body, double *coeffs, int32_t *ncoef) {
+    if (!s || body < 0 || (size_t)body >= s->s.splines.size() || !coeffs || !ncoef) return EPH_ERR_BAD_ARGUMENT;
+    const UniformSpline &u = s->s.splines[body];
+    size_t p = 0;
+    for (const Polynomial &q : u.polynomials) {
+        ncoef[p] = q.ncoef;
+        std::memcpy(coeffs + p * kDiv * 3, &q.c[0][0], sizeof(double) * kDiv * 3);
+        ++p;
+    }
+    return EPH_OK;
+}
+int32_t eph_solution_eval(const eph_solution *s, int32_t body, int64_t m, const double *at, double *pos, double *vel,
+                          uint8_t *inside) {
+    EPH_GUARD_BEGIN
+    if (!s || body < 0 || (size_t)body >= s->s.splines.size()) return EPH_ERR_BAD_ARGUMENT;
+    return spline_eval_device(s->s.splines[body], m, at, pos, vel, inside);
+    EPH_GUARD_END
+}
+int32_t eph_solution_append(eph_solution *s, const eph_solution *tail, int32_t direction) {
+    EPH_GUARD_BEGIN
+    if (!s || !tail || s->s.splines.size() != tail->s.splines.size()) return EPH_ERR_BAD_ARGUMENT;
+    // check every spline first so a failure leaves `s` untouched (the reference would have panicked)
+    for (size_t b = 0; b < s->s.splines.size(); ++b) {
+        const UniformSpline &x = s->s.splines[b], &y = tail->s.splines[b];
+        if (x.interval != y.interval) return EPH_ERR_BAD_ARGUMENT;
+        if (direction > 0 ? (x.end() != y.start) : (x.start != y.end())) return EPH_ERR_BAD_ARGUMENT;
+    }
+    for (size_t b = 0; b < s->s.splines.size(); ++b) {
+        UniformSpline &x = s->s.splines[b];
+        const UniformSpline &y = tail->s.splines[b];
+        if (direction > 0) {   // append  trajectory.rs:528-534
+            x.polynomials.insert(x.polynomials.end(), y.polynomials.begin(), y.polynomials.end());
+        } else {               // prepend trajectory.rs:515-526
+            x.start = y.start;
+            x.polynomials.insert(x.polynomials.begin(), y.polynomials.begin(), y.polynomials.end());
+        }
+    }
+    return EPH_OK;
+    EPH_GUARD_END
+}
+void eph_solution_destroy(eph_solution *s) { delete s; }
+
+int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, const double *samples, double *coeffs,
+                              int32_t *ncoef) {
+    EPH_GUARD_BEGIN
+    return least_squares_fit_device(degree, backward, nwin, samples, coeffs, ncoef);
+    EPH_GUARD_END
+}
+
+}  // extern "C"

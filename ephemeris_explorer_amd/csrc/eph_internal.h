@@ -1,0 +1,99 @@
+// eph_internal.h -- shared declarations of libephemeris_amd (host C++ + HIP kernels for gfx950).
+//
+// Device data layout (all f64, resident in HBM for the life of a handle):
+//   P[2]      : packed bodies {x, y, z, mu} (32 B each, one 2x dwordx4 load per body) -- what the pair kernel
+//               streams; ping-pong so a launch can publish the next positions while its peers still read
+//               the current ones.
+//   Y, A      : history rings [L][3][npad] (level, component, body): positions and accelerations of the last
+//               L = ORDER integrator levels (12 for QuinlanTremaine12). Slot `cur` = newest level,
+//               (cur + j) % L = j levels back.
+//   V         : [3][npad] current velocity.  ASR: [3][npad] SRKN stage acceleration (FSAL carry).
+//   samples   : per-body append log of sampled positions (AoS xyz) for the solout windows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/ephemeris_amd.h"
+
+namespace eph {
+
+constexpr int kMaxOrder = 16;   // ELM2 orders: 12 (QT12), 13 (Stormer13)
+constexpr int kTile = 64;       // one wave64 = one tile of source bodies
+constexpr int kRow = 66;        // LDS row stride in doubles of the contribution tile (16-B aligned, conflict-free)
+constexpr int kDiv = 8;         // ephemeris/src/trajectory.rs:335  (DIV)
+constexpr int kSmallN = 64;     // persistent single-workgroup path handles n <= one tile
+
+struct Body4 { double x, y, z, mu; };
+static_assert(sizeof(Body4) == 32, "Body4 must be 32 bytes");
+
+// thread-local HIP error text
+void set_last_error(const char *what, hipError_t e);
+void set_last_error_text(const std::string &s);
+int check_device();  // EPH_OK or EPH_ERR_NO_DEVICE
+
+#define EPH_HIP(call)                                              \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) {                                    \
+            ::eph::set_last_error(#call, e_);                      \
+            return EPH_ERR_HIP;                                    \
+        }                                                          \
+    } while (0)
+
+// ---- coefficient tables -> the f64 values the reference multiplies with (coeffs.cpp) ------------
+struct SrknCoeffs { int stages = 0; bool fsal = false; double A[32], B[32]; };
+struct Elm2Coeffs {
+    int order = 0;
+    double wa[kMaxOrder], wb[kMaxOrder], cw[kMaxOrder];
+    double inv_beta_d = 0, inv_cowell_d = 0;
+};
+bool find_srkn(const char *name, SrknCoeffs *out);
+bool find_elm2(const char *name, Elm2Coeffs *out);
+
+// ---- kernel argument blocks ---------------------------------------------------------------------
+struct SampleArgs {            // solout sampling schedule for one batch (device arrays, may be null)
+    const uint32_t *period;    // m_b: steps between samples (0 = never)
+    const uint32_t *phase;     // r_b: steps since the last sample at batch start
+    const uint64_t *offset;    // first free slot of body b in `log` (in samples)
+    double *log;               // AoS xyz
+};
+
+struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm_step / k_lm_persistent)
+    int n, npad, L, cur;       // cur = ring slot of the level whose acceleration is evaluated
+    const Body4 *pos_cur;      // packed positions of that level
+    Body4 *pos_next;           // packed positions of the next level (written when do_predict)
+    double *Y, *A, *V;
+    double wa[kMaxOrder], wb[kMaxOrder], cw[kMaxOrder];
+    double h, hh, hc;          // h, h*h*(1/BETA_D), h*(1/COWELL_D)
+    int do_predict;
+    uint32_t step;             // 1-based index of this step inside the batch (for sampling)
+    SampleArgs samp;
+};
+
+// ---- launchers (kernels.hip) --------------------------------------------------------------------
+// a[b] = acc_init[b] (or 0) + sum over the other bodies in the reference order; SoA [3][npad] output
+int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out);
+int launch_pack(hipStream_t s, int n, int npad, const double *Yslot, const double *mu, Body4 *pos);
+int launch_copy3(hipStream_t s, int n, int npad, const double *src, double *dst);
+// SRKN stage update: v += a*hb ; y += v*ha ; also publishes packed positions   (symplectic.rs:90-97)
+int launch_kick_drift(hipStream_t s, int n, int npad, const double *a, double *v, double *y, double hb, double ha,
+                      const double *mu, Body4 *pos_out);
+int launch_lm_predict(hipStream_t s, const LmArgs &a);              // y_{m+1} from the ring (no force)
+int launch_lm_step(hipStream_t s, const LmArgs &a);                 // one fused step, all CUs
+int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps);  // n <= 64: nsteps steps, one workgroup
+int lm_bodies_per_wave(int n);
+int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step);
+// carry: samples [src[b], src[b]+cnt[b]) of body b's region move to its front (src[b] == 0: nothing to do)
+int launch_carry(hipStream_t s, int n, const uint64_t *region, const uint32_t *src, const uint32_t *cnt, double *log);
+// AoS <-> SoA staging
+int launch_aos_to_soa(hipStream_t s, int n, int npad, const double *aos, double *soa);
+int launch_soa_to_aos(hipStream_t s, int n, int npad, const double *soa, double *aos);
+// LeastSquaresFit over windows of 9 samples; window w of the launch reads log[(first[w]) .. +8]
+int launch_lsq_fit(hipStream_t s, int64_t nwin, const uint64_t *first_sample, const uint8_t *degree, int backward,
+                   const double *log, double *coeffs, int32_t *ncoef);
+int launch_spline_eval(hipStream_t s, int64_t m, const double *at, double start, double interval, int64_t npoly,
+                       const double *coeffs, const int32_t *ncoef, double *pos, double *vel, uint8_t *inside);
+
+}  // namespace eph

@@ -1,0 +1,187 @@
+// host.h -- host-side mirror of the reference's operator surface for the hot path (C++; the reference's host
+// language, Rust, is not available in this image -- see DESIGN.md). Names follow the reference:
+//   integration::{Method, Integrator, IntegratorState, Integration, StepError}   integration/src/lib.rs
+//   integration::multistep::{LinearMultistepIntegrator, Substepper, ELM2}         integration/src/multistep/
+//   integration::runge_kutta::{FixedRungeKuttaIntegrator, SRKN}                    integration/src/runge_kutta/
+//   ephemeris::{NBodyPropagator, SplineInterpolators, UniformSpline, Polynomial}   ephemeris/src/
+// All numerical state lives on the device; the host keeps the scalar bookkeeping the reference keeps
+// (time, bound, step counters, sampling counters) and replays it with the reference's f64 operations.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <vector>
+
+#include "eph_internal.h"
+
+namespace eph {
+
+template <typename T>
+struct DevBuf {   // owning device allocation
+    T *p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_last_error("hipMalloc", e);
+            return e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_HIP;
+        }
+        count = n;
+        return EPH_OK;
+    }
+};
+
+// Integration<NBodyProblem<DVec3>, M>: problem + integrator   (integration/src/lib.rs:394-503,
+// ephemeris/src/propagators/nbody.rs:41,93-121)
+class NBodyIntegration {
+public:
+    ~NBodyIntegration();
+    static int create(int n, const double *pos, const double *vel, const double *mu, double t0, double h,
+                      const char *method, std::unique_ptr<NBodyIntegration> *out);
+    int clone(std::unique_ptr<NBodyIntegration> *out);
+
+    // n_steps x Integrator::advance; *done = steps actually taken
+    int advance(int64_t n_steps, int64_t *done = nullptr);
+    int get_state(double *pos, double *vel, double *t, uint32_t *step_count);
+    int get_acc(double *acc);
+    int sync();
+
+    // IntegratorState
+    uint32_t step_count() const { return is_multistep_ ? starter_i_ / (uint32_t)substeps_ + lm_i_ : starter_i_; }
+    double step_size() const { return h_; }
+    // ODEProblem
+    double time() const { return time_; }
+    double bound() const { return bound_; }
+    void set_bound(double b) { bound_ = b; }
+    int n() const { return n_; }
+    bool started() const { return !is_multistep_ || starter_i_ / (uint32_t)substeps_ >= (uint32_t)lm_.order; }
+    uint64_t evals() const { return evals_; }
+    hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
+    void set_path(int p) { path_ = p; }
+    void set_sampling(const SampleArgs &s) { samp_ = s; }   // consumed by the next advance() batch
+    void enable_timing(bool on) { timing_ = on; }
+    double kernel_ms() const { return kernel_ms_; }
+    uint64_t kernel_launches() const { return kernel_launches_; }
+    // how many of the next k advance() calls would succeed before BoundReached / StepSizeUnderflow
+    int64_t steps_available(int64_t k, int *status_after) const;
+
+private:
+    NBodyIntegration() = default;
+    int alloc_buffers();
+    int startup_macro_step();                 // one LinearMultistepIntegrator::advance in the start-up regime
+    int srkn_step(double h, double *y_slot);  // FixedRungeKuttaIntegrator::advance (SRKN)
+    int lm_batch(int64_t k);                  // k steady-state ELM2::advance
+    double *Yslot(int s) { return Y_.p + (size_t)s * 3 * npad_; }
+    double *Aslot(int s) { return A_.p + (size_t)s * 3 * npad_; }
+
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    int n_ = 0, npad_ = 0, L_ = 1;
+    bool is_multistep_ = false;
+    Elm2Coeffs lm_{};
+    SrknCoeffs rk_{};
+    int substeps_ = 1;
+    double h_ = 0, h_sub_ = 0;
+    double time_ = 0, bound_ = 0;
+    uint32_t starter_i_ = 0, lm_i_ = 0;   // SRKN.i (inner RK steps), ELM2.i
+    uint64_t evals_ = 0;
+    int cur_ = 0, pp_ = 0;
+    int path_ = 0;
+    bool timing_ = false;
+    double kernel_ms_ = 0;
+    uint64_t kernel_launches_ = 0;
+    SampleArgs samp_{};
+    DevBuf<Body4> P_[2];
+    DevBuf<double> Y_, A_, V_, ASR_, mu_, stage_;
+};
+
+// Polynomial<DVec3> (SmallVec<[DVec3; 8]>)   ephemeris/src/trajectory.rs:337-396
+struct Polynomial {
+    int32_t ncoef = 0;
+    double c[kDiv][3] = {};
+};
+
+// UniformSpline<DVec3>   ephemeris/src/trajectory.rs:412-633
+struct UniformSpline {
+    double start = 0, interval = 0;
+    std::deque<Polynomial> polynomials;
+    double span() const { return interval * (double)polynomials.size(); }   // interval.scaled(len)
+    double end() const { return start + span(); }
+    void push_back(const Polynomial &p) { polynomials.push_back(p); }
+    void push_front(const Polynomial &p) {
+        polynomials.push_front(p);
+        start -= interval;
+    }
+};
+
+struct Solution {   // Vec<UniformSpline<DVec3>>
+    std::vector<UniformSpline> splines;
+};
+
+// SplineInterpolator   ephemeris/src/propagators/nbody.rs:309-323
+struct SplineInterpolator {
+    double last_sample_time = 0, sample_period = 0;   // Durations
+    uint32_t len = 1;       // PolyonmialInterpolator.index
+    uint32_t degree = 0;    // LeastSquaresFit.degree
+    // derived: after how many `last_sample_time += delta` the `== sample_period` test fires (0 = never),
+    // and how many additions have been made since the last reset
+    uint32_t period_steps = 0, phase = 0;
+    double time() const { return last_sample_time + sample_period * (double)(len > 0 ? len - 1 : 0); }
+};
+
+// NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>>
+class NBodyPropagator {
+public:
+    static int create(int n, const double *pos, const double *vel, const double *mu, double t0, double dt,
+                      int direction, const char *method, const uint32_t *count, const uint32_t *degree,
+                      std::unique_ptr<NBodyPropagator> *out);
+    int clone(std::unique_ptr<NBodyPropagator> *out);
+    int step_n(int64_t k);                    // k x IncrementalPropagator::step
+    int step_to(double t);
+    double time() const;                      // DirectionalSolout::solution_time
+    bool has_reached(double t) const;
+    int take_solution(std::unique_ptr<Solution> *out);
+    NBodyIntegration *integration() { return integ_.get(); }
+
+private:
+    NBodyPropagator() = default;
+    Solution new_solution() const;
+    int run_batch(int64_t k);
+    int64_t steps_until_reached(double t, int64_t cap) const;
+    double bound_of(const UniformSpline &s) const { return direction_ > 0 ? s.end() : s.start; }
+    int ensure_log_capacity(const std::vector<uint64_t> &need);
+
+    std::unique_ptr<NBodyIntegration> integ_;
+    int direction_ = 1;
+    double delta_ = 0;
+    int64_t kmax_ = 1;          // steps per device batch (bounded by the sample-log budget)
+    std::vector<SplineInterpolator> interp_;
+    Solution solution_;
+    // device-side sample logs: body b owns log[log_off_[b] .. log_off_[b] + log_cap_[b]) samples
+    DevBuf<double> log_;
+    std::vector<uint64_t> log_off_, log_cap_;
+    DevBuf<uint32_t> d_period_, d_phase_;
+    DevBuf<uint64_t> d_offset_;
+};
+
+// device evaluation of one UniformSpline at many epochs
+int spline_eval_device(const UniformSpline &s, int64_t m, const double *at, double *pos, double *vel, uint8_t *inside);
+int least_squares_fit_device(int degree, int backward, int64_t nwin, const double *samples, double *coeffs,
+                             int32_t *ncoef);
+int accel_eval_device(int n, const double *pos, const double *mu, double *acc);
+
+}  // namespace eph

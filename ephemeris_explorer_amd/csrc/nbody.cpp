@@ -1,0 +1,342 @@
+// nbody.cpp -- NBodyIntegration: `M::new(FixedMethodParams{h}).integrate(NBodyProblem{..})` on the device.
+//
+// Mirrors, call for call:
+//   LinearMultistepIntegrator::advance          integration/src/multistep/mod.rs:194-224
+//   ELM2::{advance, advance_with}               integration/src/multistep/second_order/mod.rs:90-153
+//   SubstepperIntegrator::advance               integration/src/multistep/mod.rs:97-108
+//   FixedRungeKuttaIntegrator::advance + SRKN   integration/src/runge_kutta/mod.rs:106-126, nystrom/symplectic.rs:69-102
+// The host replays the reference's scalar bookkeeping (time, bound, step counters) with the reference's f64
+// operations; all vector arithmetic runs in the HIP kernels of kernels.hip.
+#include <cmath>
+#include <cstring>
+
+#include "host.h"
+
+namespace eph {
+
+NBodyIntegration::~NBodyIntegration() {
+    if (stream_) {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream_);
+        if (ev0_) (void)hipEventDestroy(ev0_);
+        if (ev1_) (void)hipEventDestroy(ev1_);
+        (void)hipStreamDestroy(stream_);
+    }
+}
+
+int NBodyIntegration::alloc_buffers() {
+    npad_ = ((n_ + 63) / 64) * 64;
+    if (npad_ < 64) npad_ = 64;
+    int st;
+    for (int k = 0; k < 2; ++k)
+        if ((st = P_[k].alloc(npad_))) return st;
+    if ((st = Y_.alloc((size_t)L_ * 3 * npad_))) return st;
+    if ((st = A_.alloc((size_t)L_ * 3 * npad_))) return st;
+    if ((st = V_.alloc((size_t)3 * npad_))) return st;
+    if ((st = ASR_.alloc((size_t)3 * npad_))) return st;
+    if ((st = mu_.alloc(npad_))) return st;
+    if ((st = stage_.alloc((size_t)3 * npad_))) return st;
+    EPH_HIP(hipMemsetAsync(P_[0].p, 0, sizeof(Body4) * npad_, stream_));
+    EPH_HIP(hipMemsetAsync(P_[1].p, 0, sizeof(Body4) * npad_, stream_));
+    EPH_HIP(hipMemsetAsync(Y_.p, 0, sizeof(double) * Y_.count, stream_));
+    EPH_HIP(hipMemsetAsync(A_.p, 0, sizeof(double) * A_.count, stream_));
+    EPH_HIP(hipMemsetAsync(V_.p, 0, sizeof(double) * V_.count, stream_));
+    EPH_HIP(hipMemsetAsync(ASR_.p, 0, sizeof(double) * ASR_.count, stream_));
+    EPH_HIP(hipMemsetAsync(mu_.p, 0, sizeof(double) * mu_.count, stream_));
+    return EPH_OK;
+}
+
+int NBodyIntegration::create(int n, const double *pos, const double *vel, const double *mu, double t0, double h,
+                             const char *method, std::unique_ptr<NBodyIntegration> *out) {
+    if (n < 0 || !method || !out || (n > 0 && (!pos || !vel || !mu))) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    std::unique_ptr<NBodyIntegration> o(new NBodyIntegration());
+    o->n_ = n;
+    if (find_elm2(method, &o->lm_)) {
+        // LinearMultistep::new + Substepper::<4, BlanesMoan6B>::new   multistep/mod.rs:54-57,120-128; methods.rs:37-40
+        o->is_multistep_ = true;
+        o->L_ = o->lm_.order;
+        o->substeps_ = 4;
+        if (!find_srkn("BlanesMoan6B", &o->rk_)) return EPH_ERR_UNSUPPORTED;
+        o->h_sub_ = h * (1.0 / 4.0);   // params.h * Ratio::from_recip(SUBSTEPS)
+    } else if (find_srkn(method, &o->rk_)) {
+        o->is_multistep_ = false;
+        o->L_ = 1;
+        o->substeps_ = 1;
+        o->h_sub_ = h;
+    } else {
+        return EPH_ERR_BAD_ARGUMENT;
+    }
+    o->h_ = h;
+    o->time_ = t0;
+    o->bound_ = INFINITY;   // nbody.rs:111
+    EPH_HIP(hipGetDevice(&o->device_));
+    EPH_HIP(hipStreamCreateWithFlags(&o->stream_, hipStreamNonBlocking));
+    EPH_HIP(hipEventCreate(&o->ev0_));
+    EPH_HIP(hipEventCreate(&o->ev1_));
+    if ((st = o->alloc_buffers())) return st;
+    if (n > 0) {
+        hipStream_t s = o->stream_;
+        EPH_HIP(hipMemcpyAsync(o->mu_.p, mu, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(o->stage_.p, pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+        if ((st = launch_aos_to_soa(s, n, o->npad_, o->stage_.p, o->Yslot(0)))) return st;
+        EPH_HIP(hipStreamSynchronize(s));   // stage_ is reused below
+        EPH_HIP(hipMemcpyAsync(o->stage_.p, vel, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+        if ((st = launch_aos_to_soa(s, n, o->npad_, o->stage_.p, o->V_.p))) return st;
+        if ((st = launch_pack(s, n, o->npad_, o->Yslot(0), o->mu_.p, o->P_[0].p))) return st;
+        if ((st = launch_pack(s, n, o->npad_, o->Yslot(0), o->mu_.p, o->P_[1].p))) return st;
+        EPH_HIP(hipStreamSynchronize(s));
+    }
+    *out = std::move(o);
+    return EPH_OK;
+}
+
+int NBodyIntegration::clone(std::unique_ptr<NBodyIntegration> *out) {
+    EPH_HIP(hipSetDevice(device_));
+    EPH_HIP(hipStreamSynchronize(stream_));
+    std::unique_ptr<NBodyIntegration> o(new NBodyIntegration());
+    o->device_ = device_;
+    o->n_ = n_; o->L_ = L_;
+    o->is_multistep_ = is_multistep_; o->lm_ = lm_; o->rk_ = rk_; o->substeps_ = substeps_;
+    o->h_ = h_; o->h_sub_ = h_sub_; o->time_ = time_; o->bound_ = bound_;
+    o->starter_i_ = starter_i_; o->lm_i_ = lm_i_; o->evals_ = evals_;
+    o->cur_ = cur_; o->pp_ = pp_; o->path_ = path_;
+    EPH_HIP(hipStreamCreateWithFlags(&o->stream_, hipStreamNonBlocking));
+    EPH_HIP(hipEventCreate(&o->ev0_));
+    EPH_HIP(hipEventCreate(&o->ev1_));
+    int st = o->alloc_buffers();
+    if (st) return st;
+    hipStream_t s = o->stream_;
+    for (int k = 0; k < 2; ++k)
+        EPH_HIP(hipMemcpyAsync(o->P_[k].p, P_[k].p, sizeof(Body4) * npad_, hipMemcpyDeviceToDevice, s));
+    EPH_HIP(hipMemcpyAsync(o->Y_.p, Y_.p, sizeof(double) * Y_.count, hipMemcpyDeviceToDevice, s));
+    EPH_HIP(hipMemcpyAsync(o->A_.p, A_.p, sizeof(double) * A_.count, hipMemcpyDeviceToDevice, s));
+    EPH_HIP(hipMemcpyAsync(o->V_.p, V_.p, sizeof(double) * V_.count, hipMemcpyDeviceToDevice, s));
+    EPH_HIP(hipMemcpyAsync(o->ASR_.p, ASR_.p, sizeof(double) * ASR_.count, hipMemcpyDeviceToDevice, s));
+    EPH_HIP(hipMemcpyAsync(o->mu_.p, mu_.p, sizeof(double) * mu_.count, hipMemcpyDeviceToDevice, s));
+    EPH_HIP(hipStreamSynchronize(s));
+    *out = std::move(o);
+    return EPH_OK;
+}
+
+int NBodyIntegration::sync() {
+    EPH_HIP(hipSetDevice(device_));
+    EPH_HIP(hipStreamSynchronize(stream_));
+    return EPH_OK;
+}
+
+// FixedRungeKuttaIntegrator::advance (runge_kutta/mod.rs:112-125) with SRKN::advance (symplectic.rs:69-102)
+int NBodyIntegration::srkn_step(double h, double *y_slot) {
+    if (time_ >= bound_) return EPH_BOUND_REACHED;
+    if (time_ + h == time_) return EPH_STEP_SIZE_UNDERFLOW;
+    int st;
+    for (int s = 0; s < rk_.stages; ++s) {
+        if (!rk_.fsal || s > 0 || starter_i_ == 0) {
+            // problem.ode.eval(t_stage, &problem.state.y, self.ddy.zero())
+            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p))) return st;
+            evals_++;
+        }
+        // *dy = *dy + *ddy * (h * C::B[s]);  *y = *y + *dy * (h * C::A[s])
+        if ((st = launch_kick_drift(stream_, n_, npad_, ASR_.p, V_.p, y_slot, h * rk_.B[s], h * rk_.A[s], mu_.p,
+                                    P_[pp_ ^ 1].p)))
+            return st;
+        pp_ ^= 1;
+    }
+    time_ = time_ + h;
+    starter_i_ += 1;
+    return EPH_OK;
+}
+
+// LinearMultistepIntegrator::advance while `starter.step_count() < ORDER`   multistep/mod.rs:211-218
+//   first call only : lm.advance_with(problem, no-op)   -> current_ddy = f(y0)
+//   every call      : lm.advance_with(problem, starter) -> ring.front = (state, current_ddy); 4 sub-steps;
+//                                                           current_ddy = f(y)
+// Ring convention here: slot cur_ holds the newest level (Y and A); the level under construction is built in
+// place in the slot that will become the new front.
+int NBodyIntegration::startup_macro_step() {
+    if (time_ >= bound_) return EPH_BOUND_REACHED;
+    if (time_ + h_ == time_) return EPH_STEP_SIZE_UNDERFLOW;
+    int st;
+    if (starter_i_ / (uint32_t)substeps_ == 0) {
+        if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_)))) return st;
+        evals_++;
+    }
+    const int nslot = (cur_ + L_ - 1) % L_;
+    if ((st = launch_copy3(stream_, n_, npad_, Yslot(cur_), Yslot(nslot)))) return st;
+    cur_ = nslot;   // from here on the working state is the new front, as in the reference after the clone_from
+    for (int s = 0; s < substeps_; ++s)
+        if ((st = srkn_step(h_sub_, Yslot(nslot)))) return st;
+    if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot)))) return st;
+    evals_++;
+    return EPH_OK;
+}
+
+int64_t NBodyIntegration::steps_available(int64_t k, int *status_after) const {
+    double t = time_;
+    int64_t s = 0;
+    *status_after = EPH_OK;
+    for (; s < k; ++s) {
+        if (t >= bound_) { *status_after = EPH_BOUND_REACHED; break; }
+        if (t + h_ == t) { *status_after = EPH_STEP_SIZE_UNDERFLOW; break; }
+        t = t + h_;
+    }
+    return s;
+}
+
+// k x ELM2::advance   second_order/mod.rs:90-131
+int NBodyIntegration::lm_batch(int64_t k) {
+    LmArgs a{};
+    a.n = n_; a.npad = npad_; a.L = L_;
+    a.Y = Y_.p; a.A = A_.p; a.V = V_.p;
+    for (int j = 0; j < L_; ++j) { a.wa[j] = lm_.wa[j]; a.wb[j] = lm_.wb[j]; a.cw[j] = lm_.cw[j]; }
+    a.h = h_;
+    a.hh = h_ * h_ * lm_.inv_beta_d;     // h * h * Ratio::from_recip(C::BETA_D)
+    a.hc = h_ * lm_.inv_cowell_d;        // h * Ratio::from_recip(Self::BETA_D)
+    a.samp = samp_;
+    int st;
+    const bool persistent = n_ <= kSmallN && path_ != 1;
+    if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
+    if (timing_) EPH_HIP(hipEventRecord(ev0_, stream_));
+    if (persistent) {
+        a.cur = cur_;
+        a.pos_cur = P_[pp_].p;
+        a.pos_next = P_[pp_ ^ 1].p;
+        if ((st = launch_lm_persistent(stream_, a, k))) return st;
+        cur_ = (int)(((int64_t)cur_ - k % L_ + L_) % L_);
+        kernel_launches_ += 1;
+    } else {
+        a.cur = cur_;
+        a.pos_cur = P_[pp_].p;
+        a.pos_next = P_[pp_ ^ 1].p;
+        if ((st = launch_lm_predict(stream_, a))) return st;
+        for (int64_t s = 1; s <= k; ++s) {
+            pp_ ^= 1;
+            cur_ = (cur_ + L_ - 1) % L_;
+            a.cur = cur_;
+            a.pos_cur = P_[pp_].p;
+            a.pos_next = P_[pp_ ^ 1].p;
+            a.do_predict = s < k;
+            a.step = (uint32_t)s;
+            if ((st = launch_lm_step(stream_, a))) return st;
+        }
+        kernel_launches_ += (uint64_t)k;
+    }
+    if (timing_) {
+        EPH_HIP(hipEventRecord(ev1_, stream_));
+        EPH_HIP(hipEventSynchronize(ev1_));
+        float ms = 0;
+        EPH_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+        kernel_ms_ += ms;
+    }
+    for (int64_t s = 0; s < k; ++s) time_ = time_ + h_;   // problem.time = problem.time + h, per step
+    lm_i_ += (uint32_t)k;
+    evals_ += (uint64_t)k;
+    return EPH_OK;
+}
+
+int NBodyIntegration::advance(int64_t n_steps, int64_t *done_out) {
+    EPH_HIP(hipSetDevice(device_));
+    int64_t done = 0;
+    int st = EPH_OK;
+    const SampleArgs samp = samp_;
+    while (done < n_steps) {
+        if (!is_multistep_) {
+            if ((st = srkn_step(h_, Yslot(0)))) break;
+            done++;
+            if ((st = launch_sample(stream_, n_, npad_, Yslot(0), samp, (uint32_t)done))) break;
+        } else if (!started()) {
+            if ((st = startup_macro_step())) break;
+            done++;
+            if ((st = launch_sample(stream_, n_, npad_, Yslot(cur_), samp, (uint32_t)done))) break;
+        } else {
+            int after = EPH_OK;
+            // the persistent kernel takes a 32-bit step index for sampling; keep batches below 2^31
+            int64_t want = n_steps - done;
+            if (want > (int64_t)1 << 30) want = (int64_t)1 << 30;
+            const int64_t k = steps_available(want, &after);
+            if (k > 0) {
+                // sampling phases are relative to the start of this advance(): shift them past the steps
+                // already taken in the other regimes by running the batch with a step offset of `done`
+                if (done > 0 && samp.period) {
+                    // rare (start-up and steady state in one call): finish one step at a time
+                    SampleArgs none{};
+                    samp_ = none;
+                    for (int64_t s = 0; s < k && !st; ++s) {
+                        st = lm_batch(1);
+                        if (!st) {
+                            done++;
+                            st = launch_sample(stream_, n_, npad_, Yslot(cur_), samp, (uint32_t)done);
+                        }
+                    }
+                    samp_ = samp;
+                    if (st) break;
+                } else {
+                    if ((st = lm_batch(k))) break;
+                    done += k;
+                }
+            }
+            if (k < want) { st = after; break; }
+        }
+    }
+    samp_ = SampleArgs{};
+    if (done_out) *done_out = done;
+    return st;
+}
+
+int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *sc) {
+    EPH_HIP(hipSetDevice(device_));
+    int st;
+    if (pos && n_ > 0) {
+        if ((st = launch_soa_to_aos(stream_, n_, npad_, Yslot(is_multistep_ ? cur_ : 0), stage_.p))) return st;
+        EPH_HIP(hipMemcpyAsync(pos, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
+        EPH_HIP(hipStreamSynchronize(stream_));
+    }
+    if (vel && n_ > 0) {
+        if ((st = launch_soa_to_aos(stream_, n_, npad_, V_.p, stage_.p))) return st;
+        EPH_HIP(hipMemcpyAsync(vel, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
+        EPH_HIP(hipStreamSynchronize(stream_));
+    }
+    if (t) *t = time_;
+    if (sc) *sc = step_count();
+    return EPH_OK;
+}
+
+int NBodyIntegration::get_acc(double *acc) {
+    EPH_HIP(hipSetDevice(device_));
+    if (!acc) return EPH_ERR_BAD_ARGUMENT;
+    if (n_ == 0) return EPH_OK;
+    int st;
+    if ((st = launch_soa_to_aos(stream_, n_, npad_, is_multistep_ ? Aslot(cur_) : ASR_.p, stage_.p))) return st;
+    EPH_HIP(hipMemcpyAsync(acc, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
+    EPH_HIP(hipStreamSynchronize(stream_));
+    return EPH_OK;
+}
+
+// seam 1: SecondOrderODE::eval for NewtonianGravity, host buffers in and out
+int accel_eval_device(int n, const double *pos, const double *mu, double *acc) {
+    if (n < 0 || (n > 0 && (!pos || !mu || !acc))) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    if (n == 0) return EPH_OK;
+    const int npad = ((n + 63) / 64) * 64;
+    DevBuf<Body4> P;
+    DevBuf<double> aos, soa, init, out, dmu;
+    if ((st = P.alloc(npad)) || (st = aos.alloc((size_t)3 * npad)) || (st = soa.alloc((size_t)3 * npad)) ||
+        (st = init.alloc((size_t)3 * npad)) || (st = out.alloc((size_t)3 * npad)) || (st = dmu.alloc(npad)))
+        return st;
+    hipStream_t s = nullptr;
+    EPH_HIP(hipMemcpyAsync(dmu.p, mu, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(aos.p, pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+    if ((st = launch_aos_to_soa(s, n, npad, aos.p, soa.p))) return st;
+    if ((st = launch_pack(s, n, npad, soa.p, dmu.p, P.p))) return st;
+    EPH_HIP(hipMemcpyAsync(aos.p, acc, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+    if ((st = launch_aos_to_soa(s, n, npad, aos.p, init.p))) return st;
+    if ((st = launch_accel(s, n, npad, P.p, init.p, out.p))) return st;
+    if ((st = launch_soa_to_aos(s, n, npad, out.p, aos.p))) return st;
+    EPH_HIP(hipMemcpyAsync(acc, aos.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipStreamSynchronize(s));
+    return EPH_OK;
+}
+
+}  // namespace eph

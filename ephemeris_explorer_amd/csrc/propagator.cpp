@@ -1,0 +1,354 @@
+// propagator.cpp -- NBodyPropagator with the SplineInterpolators solout, on the device.
+//
+// Mirrors ephemeris/src/propagators/nbody.rs:65-235 (NBodyPropagator), :243-517 (PolyonmialInterpolator,
+// SplineInterpolator(s), SplineBound, DirectionalSolout) and the app-side LeastSquaresFit
+// (ephemeris_explorer/src/dynamics/celestial.rs:19-186).
+//
+// Division of labour: the integrator kernels append the sampled positions to per-body device logs; after a
+// batch one k_lsq_fit launch turns every complete 9-sample window into a Polynomial. The host keeps exactly
+// the counters the reference keeps per SplineInterpolator (last_sample_time, window fill) and derives from
+// them -- with the reference's f64 operations -- spline starts, bounds, time() and has_reached().
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "host.h"
+
+namespace eph {
+
+namespace {
+// After how many `last_sample_time += delta` does `last_sample_time == sample_period` hold (nbody.rs:389-391)?
+// The test is an exact f64 equality on an accumulated sum; if the sum steps over the period the reference never
+// samples that body again. 0 = never.
+uint32_t trigger_period(double delta, double sample_period, uint32_t count_hint) {
+    double s = 0.0;
+    const uint64_t cap = (uint64_t)count_hint * 2 + 64;
+    for (uint64_t k = 1; k <= cap; ++k) {
+        s += delta;
+        if (s == sample_period) return (uint32_t)k;
+        if (s > sample_period) return 0;
+    }
+    return 0;
+}
+double accumulate(double start, double delta, uint64_t times) {
+    double s = start;
+    for (uint64_t k = 0; k < times; ++k) s += delta;
+    return s;
+}
+// D::offset / D::distance   propagators/mod.rs:49-56,84-91
+inline double dir_offset(int d, double to, double duration) { return d > 0 ? to + duration : to - duration; }
+inline double dir_distance(int d, double from, double to) { return d > 0 ? to - from : from - to; }
+constexpr uint64_t kSampleBudget = 4u << 20;   // samples in the device logs (96 MB)
+}  // namespace
+
+Solution NBodyPropagator::new_solution() const {   // Solout::new_solution  nbody.rs:454-469
+    Solution so;
+    so.splines.resize(interp_.size());
+    const double t = integ_->time();
+    for (size_t b = 0; b < interp_.size(); ++b) {
+        so.splines[b].start = dir_offset(direction_, t, -interp_[b].time());
+        so.splines[b].interval = interp_[b].sample_period * (double)kDiv;
+    }
+    return so;
+}
+
+int NBodyPropagator::create(int n, const double *pos, const double *vel, const double *mu, double t0, double dt,
+                            int direction, const char *method, const uint32_t *count, const uint32_t *degree,
+                            std::unique_ptr<NBodyPropagator> *out) {
+    if (!out || n < 0 || (n > 0 && (!count || !degree)) || !(dt > 0.0) || !std::isfinite(dt) ||
+        (direction != EPH_FORWARD && direction != EPH_BACKWARD))
+        return EPH_ERR_BAD_ARGUMENT;
+    for (int b = 0; b < n; ++b)
+        if (degree[b] > (uint32_t)(kDiv - 1) || count[b] == 0) return EPH_ERR_UNSUPPORTED;
+    std::unique_ptr<NBodyPropagator> p(new NBodyPropagator());
+    p->direction_ = direction;
+    p->delta_ = dt;                                   // SplineInterpolators::new(delta, ..)  celestial.rs:183
+    const double h = direction > 0 ? std::fabs(dt) : -std::fabs(dt);   // signed_delta  mod.rs:44-46,78-82
+    int st = NBodyIntegration::create(n, pos, vel, mu, t0, h, method, &p->integ_);
+    if (st) return st;
+    p->interp_.resize(n);
+    uint64_t total = 0;
+    double rate = 0.0;
+    for (int b = 0; b < n; ++b) {
+        SplineInterpolator &it = p->interp_[b];
+        it.sample_period = dt * (double)count[b];     // load/mod.rs:325
+        it.degree = degree[b];
+        it.period_steps = trigger_period(dt, it.sample_period, count[b]);
+        if (it.period_steps) rate += 1.0 / it.period_steps;
+    }
+    // steps per batch so that the sample logs fit the budget
+    int64_t kmax = 1 << 16;
+    if (rate * kmax + 10.0 * n > (double)kSampleBudget) kmax = (int64_t)(((double)kSampleBudget - 10.0 * n) / rate);
+    if (kmax < 1) return EPH_ERR_OUT_OF_MEMORY;
+    p->kmax_ = kmax;
+    p->log_off_.resize(n);
+    p->log_cap_.resize(n);
+    for (int b = 0; b < n; ++b) {
+        const uint32_t m = p->interp_[b].period_steps;
+        p->log_cap_[b] = 10 + (m ? (uint64_t)(kmax / m) + 1 : 0);
+        p->log_off_[b] = total;
+        total += p->log_cap_[b];
+    }
+    if ((st = p->log_.alloc(total * 3))) return st;
+    if ((st = p->d_period_.alloc(n)) || (st = p->d_phase_.alloc(n)) || (st = p->d_offset_.alloc(n))) return st;
+    if (n > 0) {
+        // PolyonmialInterpolator::new(&position): the window starts with the initial position  nbody.rs:251-259
+        std::vector<double> first(total * 3, 0.0);
+        std::vector<uint32_t> per(n);
+        for (int b = 0; b < n; ++b) {
+            for (int c = 0; c < 3; ++c) first[p->log_off_[b] * 3 + c] = pos[b * 3 + c];
+            per[b] = p->interp_[b].period_steps;
+        }
+        EPH_HIP(hipMemcpy(p->log_.p, first.data(), sizeof(double) * first.size(), hipMemcpyHostToDevice));
+        EPH_HIP(hipMemcpy(p->d_period_.p, per.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    }
+    p->solution_ = p->new_solution();                 // with_solout  lib.rs:441-451
+    *out = std::move(p);
+    return EPH_OK;
+}
+
+int NBodyPropagator::clone(std::unique_ptr<NBodyPropagator> *out) {
+    std::unique_ptr<NBodyPropagator> p(new NBodyPropagator());
+    int st = integ_->clone(&p->integ_);
+    if (st) return st;
+    p->direction_ = direction_;
+    p->delta_ = delta_;
+    p->kmax_ = kmax_;
+    p->interp_ = interp_;
+    p->solution_ = solution_;
+    p->log_off_ = log_off_;
+    p->log_cap_ = log_cap_;
+    const size_t n = interp_.size();
+    if ((st = p->log_.alloc(log_.count)) || (st = p->d_period_.alloc(n)) || (st = p->d_phase_.alloc(n)) ||
+        (st = p->d_offset_.alloc(n)))
+        return st;
+    EPH_HIP(hipMemcpy(p->log_.p, log_.p, sizeof(double) * log_.count, hipMemcpyDeviceToDevice));
+    EPH_HIP(hipMemcpy(p->d_period_.p, d_period_.p, sizeof(uint32_t) * d_period_.count, hipMemcpyDeviceToDevice));
+    *out = std::move(p);
+    return EPH_OK;
+}
+
+// One device batch of k integrator steps + solout   (k x [Integration::advance -> Solout::solout], lib.rs:379-391)
+int NBodyPropagator::run_batch(int64_t k) {
+    const int n = (int)interp_.size();
+    NBodyIntegration &ig = *integ_;
+    hipStream_t s = ig.stream();
+    EPH_HIP(hipSetDevice(ig.device()));
+    std::vector<uint32_t> phase(n);
+    std::vector<uint64_t> offset(n);
+    for (int b = 0; b < n; ++b) {
+        phase[b] = interp_[b].phase;
+        offset[b] = log_off_[b] + interp_[b].len;     // first free slot of the window log
+    }
+    if (n > 0) {
+        EPH_HIP(hipMemcpyAsync(d_phase_.p, phase.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_offset_.p, offset.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipStreamSynchronize(s));   // host vectors go out of scope; the copies are small
+    }
+    SampleArgs sa{d_period_.p, d_phase_.p, d_offset_.p, log_.p};
+    ig.set_sampling(sa);
+    int64_t done = 0;
+    const int st_adv = ig.advance(k, &done);
+
+    // replay the per-step bookkeeping of SplineInterpolators::solout_with (nbody.rs:371-400) for `done` steps
+    std::vector<uint64_t> first;
+    std::vector<uint8_t> deg;
+    std::vector<uint32_t> nwin(n, 0), carry_src(n, 0), carry_cnt(n, 0);
+    for (int b = 0; b < n; ++b) {
+        SplineInterpolator &it = interp_[b];
+        const uint32_t m = it.period_steps;
+        if (m == 0) {
+            it.last_sample_time = accumulate(it.last_sample_time, delta_, (uint64_t)done);
+            continue;
+        }
+        const uint64_t t = (uint64_t)it.phase + (uint64_t)done;
+        const uint64_t fresh = t / m;
+        it.phase = (uint32_t)(t % m);
+        it.last_sample_time = accumulate(0.0, delta_, it.phase);
+        const uint64_t have = it.len + fresh;          // samples now in the log region (>= 1)
+        const uint64_t w = (have - 1) / kDiv;          // complete windows: 9 samples, sharing end points
+        nwin[b] = (uint32_t)w;
+        for (uint64_t q = 0; q < w; ++q) {
+            first.push_back(log_off_[b] + q * kDiv);
+            deg.push_back((uint8_t)it.degree);
+        }
+        it.len = (uint32_t)(have - w * kDiv);           // finish(): last sample becomes the first of the next window
+        if (w > 0) {
+            carry_src[b] = (uint32_t)(w * kDiv);
+            carry_cnt[b] = it.len;
+        }
+    }
+    const int64_t W = (int64_t)first.size();
+    if (W > 0) {
+        DevBuf<uint64_t> d_first;
+        DevBuf<uint8_t> d_deg;
+        DevBuf<double> d_co;
+        DevBuf<int32_t> d_nc;
+        DevBuf<uint32_t> d_src, d_cnt;
+        DevBuf<uint64_t> d_region;
+        int st;
+        if ((st = d_first.alloc(W)) || (st = d_deg.alloc(W)) || (st = d_co.alloc((size_t)W * kDiv * 3)) ||
+            (st = d_nc.alloc(W)) || (st = d_src.alloc(n)) || (st = d_cnt.alloc(n)) || (st = d_region.alloc(n)))
+            return st;
+        EPH_HIP(hipMemcpyAsync(d_first.p, first.data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_deg.p, deg.data(), sizeof(uint8_t) * W, hipMemcpyHostToDevice, s));
+        if ((st = launch_lsq_fit(s, W, d_first.p, d_deg.p, direction_ < 0, log_.p, d_co.p, d_nc.p))) return st;
+        std::vector<double> co((size_t)W * kDiv * 3);
+        std::vector<int32_t> nc(W);
+        EPH_HIP(hipMemcpyAsync(co.data(), d_co.p, sizeof(double) * co.size(), hipMemcpyDeviceToHost, s));
+        EPH_HIP(hipMemcpyAsync(nc.data(), d_nc.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, s));
+        EPH_HIP(hipMemcpyAsync(d_src.p, carry_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_cnt.p, carry_cnt.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_region.p, log_off_.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice, s));
+        if ((st = launch_carry(s, n, d_region.p, d_src.p, d_cnt.p, log_.p))) return st;
+        EPH_HIP(hipStreamSynchronize(s));
+        int64_t q = 0;
+        for (int b = 0; b < n; ++b) {
+            UniformSpline &traj = solution_.splines[b];
+            for (uint32_t w = 0; w < nwin[b]; ++w, ++q) {
+                Polynomial poly;
+                poly.ncoef = nc[q];
+                std::copy(co.begin() + q * kDiv * 3, co.begin() + (q + 1) * kDiv * 3, &poly.c[0][0]);
+                if (direction_ > 0) traj.push_back(poly); else traj.push_front(poly);   // push_at_bound
+            }
+        }
+    }
+    return st_adv;
+}
+
+int NBodyPropagator::step_n(int64_t k) {
+    while (k > 0) {
+        // start-up steps of the multistep method go one at a time (each is many small launches anyway)
+        const int64_t chunk = integ_->started() ? std::min<int64_t>(k, kmax_) : 1;
+        const int st = run_batch(chunk);
+        if (st) return st;   // NBodyPropagatorError::Integration(e)
+        k -= chunk;
+    }
+    return EPH_OK;
+}
+
+double NBodyPropagator::time() const {   // DirectionalSolout::solution_time  nbody.rs:501-508
+    const auto &sp = solution_.splines;
+    if (sp.empty()) return dir_offset(direction_, 0.0, -std::numeric_limits<double>::max());
+    double best = bound_of(sp[0]);
+    for (size_t b = 1; b < sp.size(); ++b) {
+        const double x = bound_of(sp[b]);
+        if (0.0 < dir_distance(direction_, x, best)) best = x;   // min_by(D::cmp), first minimum wins
+    }
+    return best;
+}
+
+bool NBodyPropagator::has_reached(double t) const {   // nbody.rs:510-516
+    for (const UniformSpline &s : solution_.splines)
+        if (0.0 < dir_distance(direction_, bound_of(s), t)) return false;   // !D::cmp(&bound, &time).is_ge()
+    return true;
+}
+
+// smallest number of further step() calls after which has_reached(t) holds (capped)
+int64_t NBodyPropagator::steps_until_reached(double t, int64_t cap) const {
+    int64_t need = 0;
+    for (size_t b = 0; b < interp_.size(); ++b) {
+        const SplineInterpolator &it = interp_[b];
+        UniformSpline s;   // bound arithmetic only
+        s.start = solution_.splines[b].start;
+        s.interval = solution_.splines[b].interval;
+        uint64_t npoly = solution_.splines[b].polynomials.size();
+        uint64_t extra = 0;
+        auto bound = [&]() {
+            return direction_ > 0 ? s.start + s.interval * (double)npoly : s.start;
+        };
+        while (0.0 < dir_distance(direction_, bound(), t)) {
+            if (it.period_steps == 0) return cap;
+            ++extra;
+            ++npoly;
+            if (direction_ < 0) s.start -= s.interval;   // push_front
+            if ((int64_t)(extra * kDiv * it.period_steps) > cap + (int64_t)kDiv * it.period_steps) return cap;
+        }
+        if (extra == 0) continue;
+        const uint64_t samples = extra * kDiv - (it.len - 1);
+        const int64_t steps = (int64_t)(samples * it.period_steps) - (int64_t)it.phase;
+        need = std::max(need, steps);
+    }
+    return std::min(need, cap);
+}
+
+int NBodyPropagator::step_to(double t) {   // IncrementalPropagator::step_to  ephemeris/src/lib.rs:49-60
+    for (;;) {
+        if (has_reached(t)) return EPH_OK;
+        int64_t k = integ_->started() ? steps_until_reached(t, kmax_) : 1;
+        if (k < 1) k = 1;
+        const int st = step_n(k);
+        if (st) return st;
+    }
+}
+
+int NBodyPropagator::take_solution(std::unique_ptr<Solution> *out) {   // nbody.rs:182-189
+    std::unique_ptr<Solution> old(new Solution(std::move(solution_)));
+    solution_ = new_solution();
+    *out = std::move(old);
+    return EPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+int spline_eval_device(const UniformSpline &sp, int64_t m, const double *at, double *pos, double *vel,
+                       uint8_t *inside) {
+    if (m < 0 || (m > 0 && (!at || !pos || !inside))) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    if (m == 0) return EPH_OK;
+    const int64_t np = (int64_t)sp.polynomials.size();
+    std::vector<double> co((size_t)std::max<int64_t>(np, 1) * kDiv * 3, 0.0);
+    std::vector<int32_t> nc(std::max<int64_t>(np, 1), 0);
+    for (int64_t p = 0; p < np; ++p) {
+        nc[p] = sp.polynomials[p].ncoef;
+        std::copy(&sp.polynomials[p].c[0][0], &sp.polynomials[p].c[0][0] + kDiv * 3, co.begin() + p * kDiv * 3);
+    }
+    DevBuf<double> d_co, d_at, d_pos, d_vel;
+    DevBuf<int32_t> d_nc;
+    DevBuf<uint8_t> d_in;
+    if ((st = d_co.alloc(co.size())) || (st = d_nc.alloc(nc.size())) || (st = d_at.alloc(m)) ||
+        (st = d_pos.alloc((size_t)m * 3)) || (st = d_vel.alloc((size_t)m * 3)) || (st = d_in.alloc(m)))
+        return st;
+    hipStream_t s = nullptr;
+    EPH_HIP(hipMemcpyAsync(d_co.p, co.data(), sizeof(double) * co.size(), hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_nc.p, nc.data(), sizeof(int32_t) * nc.size(), hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_at.p, at, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    if ((st = launch_spline_eval(s, m, d_at.p, sp.start, sp.interval, np, d_co.p, d_nc.p, d_pos.p,
+                                 vel ? d_vel.p : nullptr, d_in.p)))
+        return st;
+    EPH_HIP(hipMemcpyAsync(pos, d_pos.p, sizeof(double) * m * 3, hipMemcpyDeviceToHost, s));
+    if (vel) EPH_HIP(hipMemcpyAsync(vel, d_vel.p, sizeof(double) * m * 3, hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipMemcpyAsync(inside, d_in.p, m, hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipStreamSynchronize(s));
+    return EPH_OK;
+}
+
+int least_squares_fit_device(int degree, int backward, int64_t nwin, const double *samples, double *coeffs,
+                             int32_t *ncoef) {
+    if (nwin < 0 || degree < 0 || degree > kDiv - 1 || (nwin > 0 && (!samples || !coeffs || !ncoef)))
+        return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    if (nwin == 0) return EPH_OK;
+    std::vector<uint64_t> first(nwin);
+    std::vector<uint8_t> deg(nwin, (uint8_t)degree);
+    for (int64_t w = 0; w < nwin; ++w) first[w] = (uint64_t)w * (kDiv + 1);
+    DevBuf<uint64_t> d_first;
+    DevBuf<uint8_t> d_deg;
+    DevBuf<double> d_log, d_co;
+    DevBuf<int32_t> d_nc;
+    if ((st = d_first.alloc(nwin)) || (st = d_deg.alloc(nwin)) || (st = d_log.alloc((size_t)nwin * (kDiv + 1) * 3)) ||
+        (st = d_co.alloc((size_t)nwin * kDiv * 3)) || (st = d_nc.alloc(nwin)))
+        return st;
+    hipStream_t s = nullptr;
+    EPH_HIP(hipMemcpyAsync(d_first.p, first.data(), sizeof(uint64_t) * nwin, hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_deg.p, deg.data(), nwin, hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_log.p, samples, sizeof(double) * nwin * (kDiv + 1) * 3, hipMemcpyHostToDevice, s));
+    if ((st = launch_lsq_fit(s, nwin, d_first.p, d_deg.p, backward, d_log.p, d_co.p, d_nc.p))) return st;
+    EPH_HIP(hipMemcpyAsync(coeffs, d_co.p, sizeof(double) * nwin * kDiv * 3, hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipMemcpyAsync(ncoef, d_nc.p, sizeof(int32_t) * nwin, hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipStreamSynchronize(s));
+    return EPH_OK;
+}
+
+}  // namespace eph

@@ -1,0 +1,151 @@
+/* ephemeris_amd.h -- C ABI of the MI355X-native ephemeris propagator (libephemeris_amd.so).
+ *
+ * Drop-in boundary for ONE hot path of Canleskis/ephemeris-explorer: the all-pairs Newtonian acceleration,
+ * the fixed-step high-order integrator that advances the massive bodies, the solout that turns integrator
+ * samples into a piecewise-polynomial ephemeris, and the evaluator / massless-body propagation that sample
+ * it. The reference has no FFI; its seams are Rust traits. Each entry point below names
+ * the trait method(s) it stands in for (paths relative to the reference repository root); INTEGRATION.md
+ * shows the Rust shim (`extern "C"` block + trait impls) a maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; caller owns every host buffer; the library owns all device memory.
+ *  - vectors are AoS xyz f64 (the layout of Vec<glam::DVec3>), units km, km/s, km^3/s^2, seconds.
+ *  - time is f64 seconds since 1958-01-01 TAI (ftime::Epoch::as_offset_seconds, ftime/src/epoch.rs).
+ *  - every function returns an eph_status; errors are values, nothing throws or aborts.
+ *  - a handle is not thread-safe; distinct handles may be used from distinct threads. Each handle owns one
+ *    HIP stream on the device that was current when it was created.
+ *  - results are bit-identical to the reference algorithm's f64 arithmetic (same operation order, no FMA
+ *    contraction); see DESIGN.md for the one unpinned formula (the `particular` pair interaction).
+ */
+#ifndef EPHEMERIS_AMD_H
+#define EPHEMERIS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPH_ABI_VERSION 1
+
+/* integration::StepError (integration/src/lib.rs:312-318), NBodyPropagatorError::Solout
+ * (ephemeris/src/propagators/nbody.rs:43-47); negative values are library / HIP failures. */
+typedef enum eph_status {
+    EPH_OK = 0,
+    EPH_STEP_SIZE_UNDERFLOW = 1,
+    EPH_MAX_ITERATIONS_REACHED = 2,
+    EPH_BOUND_REACHED = 3,
+    EPH_EVAL_FAILED = 4,
+    EPH_SOLOUT_EXIT = 5,
+    EPH_ERR_BAD_ARGUMENT = -1,
+    EPH_ERR_NO_DEVICE = -2,   /* no usable gfx950 device / HIP runtime: the library never falls back to CPU */
+    EPH_ERR_HIP = -3,
+    EPH_ERR_UNSUPPORTED = -4,
+    EPH_ERR_OUT_OF_MEMORY = -5
+} eph_status;
+
+/* PropagationDirection: Forward / Backward (ephemeris/src/propagators/mod.rs:23-93) */
+#define EPH_FORWARD 1
+#define EPH_BACKWARD (-1)
+
+int32_t eph_abi_version(void);
+const char *eph_status_string(int32_t status);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char *eph_last_error(void);
+int32_t eph_device_count(int32_t *count);
+int32_t eph_set_device(int32_t device);
+int32_t eph_device_name(char *buf, int32_t buflen);
+
+/* ---- coefficient tables (integration/src/methods.rs, ratio.rs:221-228) ---------------------------
+ * The f64 value of every coefficient exactly as the reference multiplies with it. */
+int32_t eph_srkn_coeffs(const char *name, int32_t *stages, int32_t *fsal, double *A /*[32]*/, double *B /*[32]*/);
+int32_t eph_elm2_coeffs(const char *name, int32_t *order, double *w_alpha /*[16]*/, double *w_beta /*[16]*/,
+                        double *inv_beta_d, double *cowell /*[16]*/, double *inv_cowell_d);
+
+/* ---- seam 1: the ODE right-hand side -----------------------------------------------------------
+ * SecondOrderODE::eval for NewtonianGravity (ephemeris/src/propagators/nbody.rs:16-39; trait
+ * integration/src/problem.rs:122-125). `acc_xyz` is ACCUMULATED into, like the reference's `ddy` (callers
+ * pass it zeroed); the per-body summation order is the reference's. Host buffers, n >= 0. */
+int32_t eph_accel_eval(int32_t n, const double *pos_xyz, const double *mu, double *acc_xyz);
+
+/* ---- seam 2: Method / Integrator ------------------------------------------------------------------
+ * `M::new(FixedMethodParams::new(h)).integrate(NBodyProblem{time:t0, bound:+inf, ..})`
+ * (integration/src/lib.rs:139-169, ephemeris/src/propagators/nbody.rs:93-121) with
+ * method = "QuinlanTremaine12" | "Stormer13"  (LinearMultistep<_, f64, Substepper<4, BlanesMoan6B>>,
+ *                                              integration/src/methods.rs:37-40), or any SRKN table name
+ *          "BlanesMoan6B" | "BlanesMoan11B" | "BlanesMoan14A" | "ForestRuth" | "McLachlanO4" |
+ *          "McLachlanSS17" | "Pefrl" | "Ruth"  (FixedRungeKutta<SRKN>, methods.rs:22-29).
+ * h is signed (Backward propagation = negative h). */
+typedef struct eph_nbody eph_nbody;
+int32_t eph_nbody_create(int32_t n, const double *pos_xyz, const double *vel_xyz, const double *mu, double t0,
+                         double h, const char *method, eph_nbody **out);
+/* n_steps x Integrator::advance (integration/src/lib.rs:359-360; multistep/mod.rs:201-224;
+ * runge_kutta/mod.rs:112-125). Stops early with the reference's error (BoundReached, StepSizeUnderflow). */
+int32_t eph_nbody_advance(eph_nbody *h, int64_t n_steps);
+/* problem.state.y / .dy, problem.time, IntegratorState::step_count (lib.rs:276-289). Any pointer may be NULL. */
+int32_t eph_nbody_get_state(eph_nbody *h, double *pos_xyz, double *vel_xyz, double *t, uint32_t *step_count);
+/* the acceleration the integrator holds (ELM2.current_ddy / SRKN.ddy) */
+int32_t eph_nbody_get_acc(eph_nbody *h, double *acc_xyz);
+int32_t eph_nbody_set_bound(eph_nbody *h, double bound); /* ODEProblem.bound (problem.rs:2-7) */
+int32_t eph_nbody_clone(eph_nbody *h, eph_nbody **out);   /* #[derive(Clone)] on Integration (lib.rs:409-425) */
+void eph_nbody_destroy(eph_nbody *h);
+/* number of right-hand-side evaluations performed so far */
+int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count);
+/* Which device path `advance` uses: 0 = auto, 1 = one launch per step (all CUs), 2 = persistent single
+ * workgroup (n <= 64 only). For tests and tuning. */
+int32_t eph_nbody_set_path(eph_nbody *h, int32_t path);
+/* device time of the steady-state kernels launched by this handle so far, measured with HIP events on the
+ * handle's stream: total milliseconds and launch count (used by bench.py for the roofline figure) */
+int32_t eph_nbody_kernel_time(eph_nbody *h, double *total_ms, uint64_t *launches);
+int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on);
+
+/* ---- seam 3: Propagator / IncrementalPropagator / DirectionalPropagator / BoundedPropagator -----------
+ * ephemeris::NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>>
+ * (ephemeris/src/lib.rs:9-79, propagators/nbody.rs:65-235,309-517; ephemeris_explorer/src/dynamics/
+ * celestial.rs:19-186). dt > 0; direction = EPH_FORWARD | EPH_BACKWARD; count[b] = sample_period_b / dt
+ * (ephemeris_explorer/src/load/mod.rs:325); degree[b] = LeastSquaresFit.degree (<= 7). */
+typedef struct eph_prop eph_prop;
+typedef struct eph_solution eph_solution; /* Vec<UniformSpline<DVec3>>, ephemeris/src/trajectory.rs:412-633 */
+int32_t eph_prop_create(int32_t n, const double *pos_xyz, const double *vel_xyz, const double *mu, double t0,
+                        double dt, int32_t direction, const char *method, const uint32_t *count,
+                        const uint32_t *degree, eph_prop **out);
+int32_t eph_prop_step(eph_prop *p);                  /* IncrementalPropagator::step  nbody.rs:200-207 */
+int32_t eph_prop_step_n(eph_prop *p, int64_t n);     /* n x step(), batched on the device */
+int32_t eph_prop_step_to(eph_prop *p, double t);     /* IncrementalPropagator::step_to  lib.rs:49-60 */
+int32_t eph_prop_time(eph_prop *p, double *t);       /* DirectionalPropagator::time  nbody.rs:225-227,502-508 */
+int32_t eph_prop_has_reached(eph_prop *p, double t, int32_t *flag); /* nbody.rs:229-232,510-516 */
+int32_t eph_prop_integrator_time(eph_prop *p, double *t);           /* NBodyPropagator::time nbody.rs:150-152 */
+int32_t eph_prop_get_state(eph_prop *p, double *pos_xyz, double *vel_xyz, double *t, uint32_t *step_count);
+int32_t eph_prop_take_solution(eph_prop *p, eph_solution **out);    /* Propagator::take_solution nbody.rs:182-189 */
+int32_t eph_prop_propagate(eph_prop *p, double to, eph_solution **out); /* BoundedPropagator::propagate lib.rs:71-78 */
+int32_t eph_prop_clone(eph_prop *p, eph_prop **out);
+void eph_prop_destroy(eph_prop *p);
+/* the eph_nbody inside (borrowed; do not destroy) -- for timing / path selection */
+eph_nbody *eph_prop_integrator(eph_prop *p);
+
+/* ---- the solution: Vec<UniformSpline<DVec3>> -----------------------------------------------------*/
+int32_t eph_solution_bodies(const eph_solution *s, int32_t *n);
+/* UniformSpline{start, interval, polynomials.len()} */
+int32_t eph_solution_info(const eph_solution *s, int32_t body, double *start, double *interval, int64_t *npoly);
+/* coeffs: npoly*8*3 doubles, coefficient k of polynomial p at [(p*8+k)*3 + c], zero padded;
+ * ncoef[p] = Polynomial length after trim() (trajectory.rs:387-395) */
+int32_t eph_solution_coeffs(const eph_solution *s, int32_t body, double *coeffs, int32_t *ncoef);
+/* EvaluateTrajectory::state_vector / position (trajectory.rs:459-470) for m query times of one body, on the
+ * device. inside[k] = 0 where the reference returns None. vel_xyz may be NULL (position only). */
+int32_t eph_solution_eval(const eph_solution *s, int32_t body, int64_t m, const double *at, double *pos_xyz,
+                          double *vel_xyz, uint8_t *inside);
+/* UniformSpline::append (direction = EPH_FORWARD) / prepend (EPH_BACKWARD), trajectory.rs:515-539; the
+ * reference's assert_eq! contiguity checks become EPH_ERR_BAD_ARGUMENT. `tail` is left unchanged. */
+int32_t eph_solution_append(eph_solution *s, const eph_solution *tail, int32_t direction);
+void eph_solution_destroy(eph_solution *s);
+
+/* LeastSquaresFit::interpolate (ephemeris_explorer/src/dynamics/celestial.rs:24-135) for `nwin` windows of 9
+ * samples each, on the device: samples[(w*9+k)*3+c], backward != 0 selects tau_k = 1-k/8
+ * (nbody.rs:422-442). coeffs[(w*8+k)*3+c] zero padded, ncoef[w] after trim. */
+int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, const double *samples,
+                              double *coeffs, int32_t *ncoef);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPHEMERIS_AMD_H */
