@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted on -- a synthetic
+4096-body Plummer sphere, f64, QuinlanTremaine12 (the reference's N-body method), h = 1/1024 N-body time units
+(SURVEY.md §8(d)3). A "step" is one integrator step of the whole system: one pass of the hot path
+(predictor -> all-pairs acceleration in the reference's summation order -> Cowell velocity) over all bodies.
+Start-up (12 macro steps through 4x BlanesMoan6B sub-steps) happens before the warm-up; state is resident in HBM.
+
+Multi-GPU: the time stepping of one N-body system is serial and every step needs every position, so the path
+does not shard without a per-step exchange (DESIGN.md "Multi-GPU"): `--gpus N` runs N independent replicas
+(weak scaling, e.g. the reference's concurrent forward/backward propagators or an ensemble); value = bodies x
+steps summed over ranks / max-over-ranks time. No data-path collective.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_BODIES = 4096
+H = 1.0 / 1024.0
+# SURVEY.md §8(d) algorithmic counts
+BYTES_PER_BODY_STEP = 680.0            # 12 y + 12 a levels (576) + mu (8) + own position (24) + write y, v, a (72)
+FLOP_PER_INTERACTION = 20.0
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_VECTOR_PEAK_TFLOPS = 78.6         # MI355X vector FP64 (no MFMA on this path)
+
+
+def cpu_baseline(pos, vel, mu, steps):
+    """The oracle (a port of the reference algorithm: single thread, scalar, triangular N(N-1)/2 pair loop) timed
+    on this host on a bounded sample of the same workload. Also returns the oracle state for the parity figure."""
+    from oracle import orc
+    orc.build(native=True)
+    o = orc.NBody(pos, vel, mu, 0.0, H, native=True)
+    t0 = time.perf_counter()
+    assert o.advance(12) == 0
+    t_start = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    assert o.advance(steps) == 0
+    dt = time.perf_counter() - t0
+    pairs = N_BODIES * (N_BODIES - 1) / 2
+    return {
+        "value": N_BODIES * steps / dt, "unit": "body-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{steps} steady-state QuinlanTremaine12 steps of the same 4096-body system "
+                  f"(after the 12-step start-up, {t_start:.1f} s, not counted)",
+        "ns_per_pair": dt / steps / pairs * 1e9, "seconds": dt,
+    }, o
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=60, help="oracle steps timed for cpu_baseline (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bodies", type=int, default=N_BODIES, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+
+    if not torch.cuda.is_available() or ea.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    ea.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.bodies
+    # rank r integrates its own replica (seed + r): independent systems, no exchange
+    pos, vel, mu = plummer(n, seed=20260926 + rank)
+    g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    g.advance(12)                       # multistep start-up, reported separately in DESIGN.md
+    g.advance(args.warmup)
+    g.enable_timing(True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    g.advance(args.steps)               # EXACTLY K steps
+    g.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_kernel, launches = g.kernel_time()
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        launch_s = ms_kernel * 1e-3 / max(launches, 1)      # HIP events on the handle's stream, timed region only
+        achieved_gbs = BYTES_PER_BODY_STEP * n / launch_s / 1e9
+        flops = (FLOP_PER_INTERACTION * (n - 1) + 231.0) * n
+        out = {
+            "metric": "body-steps/s", "value": value, "unit": "body-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"plummer_{n}_f64_qt12 (BASELINE.json configs[2]; h=1/1024, seed 20260926+rank)",
+                       "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_lm_step<4,12>", "launch_us": launch_s * 1e6, "launches": launches,
+                         "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * n,
+                         "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see fp64"},
+            "fp64": {"bound": "fp64_valu", "achieved": flops / launch_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "flop_per_launch": flops},
+        }
+        if world == 1 and not args.no_cpu_baseline and n == N_BODIES:
+            base, o = cpu_baseline(pos, vel, mu, args.cpu_steps)
+            out["cpu_baseline"] = base
+            # parity beside the number: a fresh GPU run of the same steps vs the oracle
+            c = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            c.advance(12 + args.cpu_steps)
+            dp = np.abs(c.state()[0] - o.state()[0]).max()
+            out["parity"] = {"max_abs_dpos": float(dp), "steps": 12 + args.cpu_steps, "vs": "oracle (port)"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

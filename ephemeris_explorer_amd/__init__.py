@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "eph_device_name", "eph_srkn_coeffs", "eph_elm2_coeffs", "eph_accel_eval",
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
-    "eph_nbody_enable_timing",
+    "eph_nbody_enable_timing", "eph_nbody_sync",
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
@@ -100,6 +100,7 @@ def _lib():
     L.eph_nbody_set_path.argtypes = [vp, i32]
     L.eph_nbody_kernel_time.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.eph_nbody_enable_timing.argtypes = [vp, i32]
+    L.eph_nbody_sync.argtypes = [vp]
     L.eph_prop_create.argtypes = [i32, _dp, _dp, _dp, f64, f64, i32, C.c_char_p, _u32p, _u32p, C.POINTER(vp)]
     L.eph_prop_step.argtypes = [vp]
     L.eph_prop_step_n.argtypes = [vp, i64]
@@ -243,6 +244,9 @@ class NBodyIntegration:
         ms, n = C.c_double(), C.c_uint64()
         _check(self._L.eph_nbody_kernel_time(self._h, C.byref(ms), C.byref(n)), "eph_nbody_kernel_time")
         return ms.value, n.value
+
+    def sync(self):
+        _check(self._L.eph_nbody_sync(self._h), "eph_nbody_sync")
 
     def eval_count(self):
         n = C.c_uint64()

@@ -205,6 +205,11 @@ int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on) {
     return EPH_OK;
 }
 
+int32_t eph_nbody_sync(eph_nbody *h) {
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    return h->p->sync();
+}
+
 // ---- eph_prop ---------------------------------------------------------------------------------------
 int32_t eph_prop_create(int32_t n, const double *pos, const double *vel, const double *mu, double t0, double dt,
                         int32_t direction, const char *method, const uint32_t *count, const uint32_t *degree,

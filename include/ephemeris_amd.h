@@ -98,6 +98,8 @@ int32_t eph_nbody_set_path(eph_nbody *h, int32_t path);
  * handle's stream: total milliseconds and launch count (used by bench.py for the roofline figure) */
 int32_t eph_nbody_kernel_time(eph_nbody *h, double *total_ms, uint64_t *launches);
 int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on);
+/* block until every launch queued on the handle's stream has finished */
+int32_t eph_nbody_sync(eph_nbody *h);
 
 /* ---- seam 3: Propagator / IncrementalPropagator / DirectionalPropagator / BoundedPropagator -----------
  * ephemeris::NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>>

@@ -1,0 +1,43 @@
+"""CPU: readers of the reference's on-disk inputs (state.json / ephemeris.json / ships)."""
+import numpy as np
+import pytest
+
+from conftest import SYSTEMS
+from ephemeris_explorer_amd.systems import load_ship, load_system, parse_duration, parse_epoch
+
+
+def test_epoch_parse():
+    assert parse_epoch("1958-01-01 00:00:00") == 0.0
+    assert parse_epoch("1950-01-01 00:00:00") == -252460800.0
+    assert parse_epoch("2000-01-01 12:00:00.5") == (15340 * 86400) + 43200.5   # 15340 days from 1958-01-01
+    assert parse_epoch("1958-01-02 00:00:01.250") == 86401.25
+    assert parse_epoch("1958-01-01 00:00:00.1234") == 0.123            # only 3 fractional digits are read
+    for bad in ("1958-13-01 00:00:00", "1958-01-01", "1958-01-01 24:00:00", "1958-01-01 00:00:00."):
+        with pytest.raises(Exception):
+            parse_epoch(bad)
+
+
+def test_duration_parse():
+    assert parse_duration("6 hour") == 21600.0 and parse_duration("10 min") == 600.0
+    assert parse_duration("5 min 15 s") == 315.0 and parse_duration("- 1 d") == -86400.0
+    assert parse_duration("1 y") == 365.25 * 86400.0 and parse_duration("250 ms") == 0.25
+    with pytest.raises(ValueError):
+        parse_duration("1.5 h")          # integers only (duration.rs:326-329)
+    with pytest.raises(ValueError):
+        parse_duration("3 fortnights")
+
+
+@pytest.mark.parametrize("name,n,dt", [("sun_earth_moon_2433282.5", 3, 21600.0), ("sun_earth_moon_2461041.5", 3, 21600.0),
+                                       ("simple_solar_system_2433282.5", 10, 21600.0),
+                                       ("full_solar_system_2433282.5", 32, 600.0)])
+def test_systems_load(name, n, dt):
+    s = load_system(SYSTEMS / name)
+    assert s.n == n and s.dt == dt and s.pos.shape == (n, 3) and len(s.count) == n and s.names[0] == "Sun"
+    assert (s.degree <= 7).all() and (s.count >= 1).all()
+
+
+def test_ship_load():
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    assert ship.integrator == "Verner87" and ship.tolerance == 1e-3 and len(ship.burns) == 4
+    assert ship.burns[0].reference == "Earth" and ship.burns[0].duration == 315.0
+    assert ship.start == -252460800.0
