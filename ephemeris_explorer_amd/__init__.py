@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append",
-    "eph_solution_destroy", "eph_least_squares_fit",
+    "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
 ]
 
 
@@ -124,6 +124,7 @@ def _lib():
     L.eph_solution_destroy.argtypes = [vp]
     L.eph_solution_destroy.restype = None
     L.eph_least_squares_fit.argtypes = [i32, i32, i64, _dp, _dp, _i32p]
+    L.eph_debug_inv_r3.argtypes = [i64, _dp, _dp, _dp]
     if L.eph_abi_version() != 1:
         raise ImportError("libephemeris_amd.so ABI version mismatch")
     _L = L
@@ -195,6 +196,14 @@ def least_squares_fit(degree, samples, backward=False):
     _check(_lib().eph_least_squares_fit(int(degree), int(bool(backward)), nwin, _p(samples), _p(co), _p(nc, _i32p)),
            "eph_least_squares_fit")
     return co, nc
+
+
+def debug_inv_r3(n2):
+    """test hook: (fast, ieee) device evaluations of 1/(x*sqrt(x))"""
+    n2 = _f64(n2)
+    fast, ieee = np.zeros_like(n2), np.zeros_like(n2)
+    _check(_lib().eph_debug_inv_r3(n2.size, _p(n2), _p(fast), _p(ieee)), "eph_debug_inv_r3")
+    return fast, ieee
 
 
 class NBodyIntegration:

@@ -12,6 +12,7 @@ HEADERS = ["eph_internal.h", "host.h", "coeff_tables.inc", "../../include/epheme
 # -ffp-contract=off is REQUIRED for parity (HIP's default is fast contraction): the reference never fuses a*b+c.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+FLAGS += os.environ.get("EPH_EXTRA_FLAGS", "").split()
 
 
 def hipcc():

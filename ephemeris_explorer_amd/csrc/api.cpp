@@ -354,4 +354,25 @@ int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, co
     EPH_GUARD_END
 }
 
+int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee) {
+    EPH_GUARD_BEGIN
+    if (n < 0 || (n > 0 && (!n2 || !fast || !ieee))) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    if (n == 0) return EPH_OK;
+    DevBuf<double> a, b, c;
+    if ((st = a.alloc(n)) || (st = b.alloc(n)) || (st = c.alloc(n))) return st;
+    EPH_HIP(hipMemcpy(a.p, n2, sizeof(double) * n, hipMemcpyHostToDevice));
+    if ((st = launch_debug_inv_r3(nullptr, n, a.p, b.p, c.p))) return st;
+    EPH_HIP(hipMemcpy(fast, b.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    EPH_HIP(hipMemcpy(ieee, c.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return EPH_OK;
+    EPH_GUARD_END
+}
+
+int32_t eph_debug_wg_cycles(int64_t *out8) {
+    if (!out8) return EPH_ERR_BAD_ARGUMENT;
+    return debug_wg_cycles((long long *)out8);
+}
+
 }  // extern "C"

@@ -87,6 +87,9 @@ int lm_bodies_per_wave(int n);
 int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step);
 // carry: samples [src[b], src[b]+cnt[b]) of body b's region move to its front (src[b] == 0: nothing to do)
 int launch_carry(hipStream_t s, int n, const uint64_t *region, const uint32_t *src, const uint32_t *cnt, double *log);
+// test hook: 1/(x*sqrt(x)) through the in-range fast sequences and through the compiler's IEEE expansions
+int launch_debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee);
+int debug_wg_cycles(long long *out);   // EPH_DEBUG_WG=3 cycle accounting of the workgroup force kernel
 // AoS <-> SoA staging
 int launch_aos_to_soa(hipStream_t s, int n, int npad, const double *aos, double *soa);
 int launch_soa_to_aos(hipStream_t s, int n, int npad, const double *soa, double *aos);

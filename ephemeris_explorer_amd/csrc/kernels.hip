@@ -4,6 +4,9 @@
 // operation order and must stay un-fused.
 //
 // Reference citations are relative to the reference repository root.
+#include <cstdlib>
+#include <utility>
+
 #include "eph_internal.h"
 
 namespace eph {
@@ -14,16 +17,68 @@ namespace eph {
 // (call sites ephemeris/src/propagators/nbody.rs:29, ephemeris_explorer/src/dynamics/spacecraft.rs:73).
 // For the pair (k, i), k < i, the reference computes -(p_i - p_k) * (mu_k * inv); (p_k - p_i) * (mu_k * inv)
 // is the same f64 (negation is exact), so one directed formula serves both triangles.
+//
+//   d = p_j - p_i ; n2 = d.x*d.x + d.y*d.y + d.z*d.z ; inv = 1 / (n2 * sqrt(n2)) ; a = d * (mu_j * inv)
+//
+// sqrt and the reciprocal must be the IEEE correctly rounded results (the CPU's sqrtsd / divsd). The compiler's
+// f64 expansions are: v_rsq_f64 / v_rcp_f64 seed + fma refinement, wrapped in range scaling (v_ldexp,
+// v_div_scale, v_div_fmas, v_div_fixup) that only acts for operands near the ends of the exponent range.
+// `*_inrange` below are exactly those refinement sequences without the scaling wrappers: bit-identical whenever
+// the scaling would have been a no-op, which in_range() guarantees (n2 in [2^-300, 2^300], so
+// n2*sqrt(n2) in [2^-450, 2^450]). Out-of-range tiles take the full IEEE form. 9 fewer VALU ops per pair.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pair_accel(double xi, double yi, double zi, const Body4 &pj, double &cx, double &cy,
-                                           double &cz) {
-    const double dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi;
-    const double n2 = dx * dx + dy * dy + dz * dz;   // glam DVec3::length_squared, left to right
-    const double inv = 1.0 / (n2 * sqrt(n2));        // IEEE correctly rounded f64 sqrt and divide
-    const double s = pj.mu * inv;
-    cx = dx * s;
-    cy = dy * s;
-    cz = dz * s;
+struct PairPre { double dx, dy, dz, n2; };
+
+__device__ __forceinline__ PairPre pair_pre(double xi, double yi, double zi, const Body4 &pj) {
+    PairPre p;
+    p.dx = pj.x - xi;
+    p.dy = pj.y - yi;
+    p.dz = pj.z - zi;
+    p.n2 = p.dx * p.dx + p.dy * p.dy + p.dz * p.dz;   // glam DVec3::length_squared, left to right
+    return p;
+}
+__device__ __forceinline__ bool in_range(double n2) {
+    // biased exponent in [723, 1323)  <=>  2^-300 <= n2 < 2^300  (n2 >= 0; NaN/inf/0/denormals are out)
+    return (unsigned)(__double2hiint(n2) - 0x2D300000) < 0x25800000u;
+}
+__device__ __forceinline__ double sqrt_inrange(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double rcp_inrange(double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-p, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+template <bool FAST>
+__device__ __forceinline__ void pair_finish(const PairPre &p, double mu, double &cx, double &cy, double &cz) {
+    double inv;
+    if (FAST) inv = rcp_inrange(p.n2 * sqrt_inrange(p.n2));
+    else inv = 1.0 / (p.n2 * sqrt(p.n2));   // IEEE correctly rounded f64 sqrt and divide
+    const double s = mu * inv;
+    cx = p.dx * s;
+    cy = p.dy * s;
+    cz = p.dz * s;
+}
+__global__ void k_debug_inv_r3(long long n, const double *__restrict__ n2, double *__restrict__ fast,
+                               double *__restrict__ ieee) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = n2[i];
+    fast[i] = in_range(x) ? rcp_inrange(x * sqrt_inrange(x)) : __builtin_nan("");
+    ieee[i] = 1.0 / (x * sqrt(x));
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -34,17 +89,211 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Ordered accumulation of one 64-wide row of the contribution tile (phase B of wave_force).
+// The row is read with ds_read_b128 in four 16-element chunks, the next chunk's reads in flight while the
+// current one is added, so the dependent v_add_f64 chain never waits on LDS latency.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_chunk(const double *row, int c, double2 (&r)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const double2 *>(row + c * 16 + 2 * k);   // ds_read_b128
+}
+__device__ __forceinline__ double add_chunk(const double2 (&r)[8], double acc) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        acc = acc + r[k].x;
+        acc = acc + r[k].y;
+    }
+    return acc;
+}
+
+// full tile, none of the wave's bodies inside it: 64 plain ordered adds
+__device__ __forceinline__ double chain_full(const double *row, double acc) {
+    double2 ra[8], rb[8];
+    load_chunk(row, 0, ra);
+    load_chunk(row, 1, rb);
+    acc = add_chunk(ra, acc);
+    load_chunk(row, 2, ra);
+    acc = add_chunk(rb, acc);
+    load_chunk(row, 3, rb);
+    acc = add_chunk(ra, acc);
+    return add_chunk(rb, acc);
+}
+
+// The tile that holds the wave's own bodies (and/or the ragged last tile). The wave's BPW bodies are consecutive
+// and BPW-aligned, so they occupy exactly one BPW-wide group `gself` of the tile: groups before it are
+// "sources before the body" for every chain, groups after it "sources after the body"; only inside that one group
+// does a chain skip its own body, close the lower sum and restart from V::default(). cnt = valid sources.
+// li = index of this lane's own body inside the tile.
+template <int BPW>
+__device__ __forceinline__ void chain_masked(const double *row, int cnt, int gself, int li, double &acc,
+                                             double &accL) {
+    double2 ra[8], rb[8];
+    load_chunk(row, 0, ra);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double2(&cur)[8] = (c & 1) ? rb : ra;
+        double2(&nxt)[8] = (c & 1) ? ra : rb;
+        if (c * 16 >= cnt) break;                       // wave-uniform
+        if (c < 3 && (c + 1) * 16 < cnt) load_chunk(row, c + 1, nxt);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int jl = c * 16 + e;
+            const double v = (e & 1) ? cur[e >> 1].y : cur[e >> 1].x;
+            if (jl >= cnt) continue;                    // wave-uniform
+            if (jl / BPW != gself) {                    // wave-uniform
+                acc = acc + v;
+            } else {
+                const bool self = (jl == li);
+                const double t = acc + v;               // NaN on the self lane, discarded
+                accL = self ? acc : accL;               // lower chain complete
+                acc = self ? 0.0 : t;                   // upper chain starts from V::default()
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Software-pipelined tile step. While the ordered sum of tile t (phase B: 64 dependent v_add_f64 fed from LDS)
+// advances, the same wave finishes the pair arithmetic of tile t+1 (22 VALU ops per body: in-range sqrt,
+// reciprocal, scaling) and starts tile t+2 (8 ops per body: differences and squared distance). With one wave per
+// SIMD nothing else can fill the issue slots a dependent add leaves empty, so the two instruction streams are
+// interleaved explicitly, one chain add after every few independent pair ops, and pinned with
+// sched_barrier (VALU may not cross; SALU / VMEM / DS may) -- the compiler's own schedule clusters the chain.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kSchedMask = 0x4 | 0x10 | 0x80;   // SALU, VMEM, DS may cross a sched_barrier; VALU stays pinned
+
+template <int BPW>
+struct TileCtx {                 // registers of the pipelined tile steps
+    PairPre pre[2][BPW];         // ping-pong: differences of the tile being finished / of the one after it
+    double mu[2];                // source mu belonging to pre[k]
+    Body4 src[2];                // prefetched sources, two steps ahead
+    double c[3 * BPW];           // contributions being produced
+    double y[BPW], g[BPW], h[BPW], r[BPW], d[BPW], p[BPW], tmp[BPW];
+    double2 q[4][8];             // the LDS row being summed, four 16-element chunks
+    double acc;
+};
+
+// stage S (0..21) of pair_finish<true> for body B on w.pre[PH]; same operations, same order as sqrt_inrange /
+// rcp_inrange. Returns the value written (for the scheduling anchor).
+template <int BPW, int PH, int S, int B>
+__device__ __forceinline__ double &pair_stage(TileCtx<BPW> &w) {
+    const PairPre &in = w.pre[PH][B];
+    const double x = in.n2;
+    if constexpr (S == 0) { w.y[B] = __builtin_amdgcn_rsq(x); return w.y[B]; }
+    else if constexpr (S == 1) { w.g[B] = x * w.y[B]; return w.g[B]; }
+    else if constexpr (S == 2) { w.h[B] = w.y[B] * 0.5; return w.h[B]; }
+    else if constexpr (S == 3) { w.r[B] = __builtin_fma(-w.h[B], w.g[B], 0.5); return w.r[B]; }
+    else if constexpr (S == 4) { w.g[B] = __builtin_fma(w.g[B], w.r[B], w.g[B]); return w.g[B]; }
+    else if constexpr (S == 5) { w.h[B] = __builtin_fma(w.h[B], w.r[B], w.h[B]); return w.h[B]; }
+    else if constexpr (S == 6) { w.d[B] = __builtin_fma(-w.g[B], w.g[B], x); return w.d[B]; }
+    else if constexpr (S == 7) { w.g[B] = __builtin_fma(w.d[B], w.h[B], w.g[B]); return w.g[B]; }
+    else if constexpr (S == 8) { w.d[B] = __builtin_fma(-w.g[B], w.g[B], x); return w.d[B]; }
+    else if constexpr (S == 9) { w.g[B] = __builtin_fma(w.d[B], w.h[B], w.g[B]); return w.g[B]; }       // sqrt(n2)
+    else if constexpr (S == 10) { w.p[B] = x * w.g[B]; return w.p[B]; }                                 // n2*sqrt(n2)
+    else if constexpr (S == 11) { w.r[B] = __builtin_amdgcn_rcp(w.p[B]); return w.r[B]; }
+    else if constexpr (S == 12) { w.d[B] = __builtin_fma(-w.p[B], w.r[B], 1.0); return w.d[B]; }
+    else if constexpr (S == 13) { w.r[B] = __builtin_fma(w.r[B], w.d[B], w.r[B]); return w.r[B]; }
+    else if constexpr (S == 14) { w.d[B] = __builtin_fma(-w.p[B], w.r[B], 1.0); return w.d[B]; }
+    else if constexpr (S == 15) { w.r[B] = __builtin_fma(w.r[B], w.d[B], w.r[B]); return w.r[B]; }
+    else if constexpr (S == 16) { w.d[B] = __builtin_fma(-w.p[B], w.r[B], 1.0); return w.d[B]; }
+    else if constexpr (S == 17) { w.r[B] = __builtin_fma(w.d[B], w.r[B], w.r[B]); return w.r[B]; }      // 1/(n2*sqrt(n2))
+    else if constexpr (S == 18) { w.h[B] = w.mu[PH] * w.r[B]; return w.h[B]; }
+    else if constexpr (S == 19) { w.c[3 * B + 0] = in.dx * w.h[B]; return w.c[3 * B + 0]; }
+    else if constexpr (S == 20) { w.c[3 * B + 1] = in.dy * w.h[B]; return w.c[3 * B + 1]; }
+    else { w.c[3 * B + 2] = in.dz * w.h[B]; return w.c[3 * B + 2]; }
+}
+// stage S (0..7) of pair_pre for body B: w.src[PH] -> w.pre[PH ^ 1]
+template <int BPW, int PH, int S, int B>
+__device__ __forceinline__ double &pre_stage(TileCtx<BPW> &w, const double (&xi)[BPW], const double (&yi)[BPW],
+                                             const double (&zi)[BPW]) {
+    PairPre &p = w.pre[PH ^ 1][B];
+    const Body4 &pj = w.src[PH];
+    if constexpr (S == 0) { p.dx = pj.x - xi[B]; return p.dx; }
+    else if constexpr (S == 1) { p.dy = pj.y - yi[B]; return p.dy; }
+    else if constexpr (S == 2) { p.dz = pj.z - zi[B]; return p.dz; }
+    else if constexpr (S == 3) { p.n2 = p.dx * p.dx; return p.n2; }
+    else if constexpr (S == 4) { w.tmp[B] = p.dy * p.dy; return w.tmp[B]; }
+    else if constexpr (S == 5) { p.n2 = p.n2 + w.tmp[B]; return p.n2; }
+    else if constexpr (S == 6) { w.tmp[B] = p.dz * p.dz; return w.tmp[B]; }
+    else { p.n2 = p.n2 + w.tmp[B]; return p.n2; }
+}
+// chain adds M0 .. M1-1 of the 64 of this tile, each anchored so no pass can sink it past the next barrier
+template <int BPW, int M0, int M1>
+__device__ __forceinline__ void chain_adds(TileCtx<BPW> &w, const double *row) {
+    if constexpr (M0 < M1) {
+        if constexpr (M0 == 8) load_chunk(row, 2, w.q[2]);
+        if constexpr (M0 == 24) load_chunk(row, 3, w.q[3]);
+        const double2 &e = w.q[M0 / 16][(M0 % 16) / 2];
+        w.acc = w.acc + ((M0 & 1) ? e.y : e.x);
+        asm volatile("" : "+v"(w.acc));
+        chain_adds<BPW, M0 + 1, M1>(w, row);
+    }
+}
+// One slot of the fused instruction stream: op K of the 30*BPW pair ops, then its share of the 64 chain adds.
+// The chain starts a quarter of the way in (the LDS reads issued at the top need ~130 cycles to land, and an
+// in-order wave would otherwise sit on the first add with independent work queued behind it).
+template <int BPW, int PH, int K>
+__device__ __forceinline__ void fused_op(TileCtx<BPW> &w, const double (&xi)[BPW], const double (&yi)[BPW],
+                                         const double (&zi)[BPW], const double *row_cur, double *tile_nxt, int lane) {
+    constexpr int kOps = 30 * BPW;            // 22 finish + 8 pre per body
+    constexpr int kLead = kOps / 4;
+    constexpr int S = K / BPW, B = K % BPW;
+    // every op is anchored with an empty asm: IR passes may otherwise sink pure arithmetic past the barriers
+    // (towards its use in the next loop iteration) and undo the interleave
+    if constexpr (S < 22) {
+        double &v = pair_stage<BPW, PH, S, B>(w);
+        asm volatile("" : "+v"(v));
+        if constexpr (S == 21) {              // body B finished: publish its contributions to the OTHER LDS buffer
+            tile_nxt[(3 * B + 0) * kRow + lane] = w.c[3 * B + 0];
+            tile_nxt[(3 * B + 1) * kRow + lane] = w.c[3 * B + 1];
+            tile_nxt[(3 * B + 2) * kRow + lane] = w.c[3 * B + 2];
+        }
+    } else {
+        double &v = pre_stage<BPW, PH, S - 22, B>(w, xi, yi, zi);
+        asm volatile("" : "+v"(v));
+    }
+    if constexpr (K >= kLead) {
+        constexpr int J = K - kLead, kSpan = kOps - kLead;
+        chain_adds<BPW, J * 64 / kSpan, (J + 1) * 64 / kSpan>(w, row_cur);
+    }
+    __builtin_amdgcn_sched_barrier(kSchedMask);
+}
+template <int BPW, int PH, int... K>
+__device__ __forceinline__ void fused_ops(TileCtx<BPW> &w, const double (&xi)[BPW], const double (&yi)[BPW],
+                                          const double (&zi)[BPW], const double *row_cur, double *tile_nxt, int lane,
+                                          std::integer_sequence<int, K...>) {
+    (fused_op<BPW, PH, K>(w, xi, yi, zi, row_cur, tile_nxt, lane), ...);
+}
+
+// Pipelined step PH (0/1 = ping-pong phase), processing tile t:
+//   in : w.pre[PH], w.mu[PH] = tile t+1 (guarded in range); w.src[PH] = sources of tile t+2;
+//        LDS buffer PH holds the contributions of tile t
+//   out: contributions of tile t+1 in LDS buffer PH^1; w.pre[PH^1], w.mu[PH^1] = tile t+2; w.acc advanced over tile t
+template <int BPW, int PH>
+__device__ __forceinline__ void tile_step_fast(TileCtx<BPW> &w, const double (&xi)[BPW], const double (&yi)[BPW],
+                                               const double (&zi)[BPW], const double *row_cur, double *tile_nxt,
+                                               int lane) {
+    load_chunk(row_cur, 0, w.q[0]);
+    load_chunk(row_cur, 1, w.q[1]);
+    fused_ops<BPW, PH>(w, xi, yi, zi, row_cur, tile_nxt, lane, std::make_integer_sequence<int, 30 * BPW>{});
+    w.mu[PH ^ 1] = w.src[PH].mu;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // wave_force<BPW>: one wave64 computes the accelerations of BPW consecutive bodies i0..i0+BPW-1 in EXACTLY the
 // reference's summation order (NewtonianGravity::eval, nbody.rs:22-38):
 //     ddy[i] = ((init + c(0,i)) + ... + c(i-1,i))  +  ((0 + c(i,i+1)) + ... + c(i,n-1))
 // Phase A: lane = source body j of the current 64-body tile; BPW independent interactions per lane go to a
 //          wave-private LDS tile C[chain][j]  (chain = body*3 + component, row stride kRow doubles).
 // Phase B: lane = chain (< 3*BPW); walks its row in j order with one dependent v_add_f64 per source.
-// The sqrt/divide-heavy phase A is fully parallel; only the 3 adds per interaction are ordered.
+// The sqrt/divide-heavy phase A is fully parallel; only the 3 adds per interaction are ordered. Full tiles away
+// from the wave's own bodies are software-pipelined (A of tile t+1 overlaps B of tile t, sources two tiles ahead
+// in flight); the tile holding the wave's bodies and a ragged last tile take the masked, un-pipelined form.
 // Returns, on lane `ch` < 3*BPW, component ch%3 of body i0 + ch/3.
 // ------------------------------------------------------------------------------------------------------
-template <int BPW, typename PosPtr>
+template <int BPW, bool SINGLE_TILE = false, typename PosPtr>
 __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double init, double *C, int lane) {
+    static_assert(kTile % BPW == 0, "BPW must divide the tile");
     double xi[BPW], yi[BPW], zi[BPW];
 #pragma unroll
     for (int b = 0; b < BPW; ++b) {
@@ -53,44 +302,110 @@ __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double i
         yi[b] = pos[ii].y;
         zi[b] = pos[ii].z;
     }
-    const int ch = lane < 3 * BPW ? lane : 3 * BPW - 1;
-    const int my_i = i0 + ch / 3;
+    const bool chain_lane = lane < 3 * BPW;
+    const int ch = chain_lane ? lane : 3 * BPW - 1;
     const double *row = C + ch * kRow;
+    const int tiles = (n + kTile - 1) / kTile;
+    const int tfull = n / kTile;
+    const int tdiag = i0 / kTile;                     // wave-uniform: i0 % BPW == 0 and BPW divides 64
+    const int gself = (i0 % kTile) / BPW;
+    const int li = (i0 % kTile) + ch / 3;
     double acc = init;   // lower chain (sources before the body), continues from the caller's value
     double accL = 0.0;
 
-    for (int j0 = 0; j0 < n; j0 += kTile) {
-        const int j = j0 + lane;
-        const Body4 pj = pos[j < n ? j : n - 1];
+    auto load_src = [&](int t) -> Body4 {
+        const int j = t * kTile + lane;
+        return pos[j < n ? j : n - 1];
+    };
+    auto store_tile = [&](const double(&c)[3 * BPW]) {
 #pragma unroll
-        for (int b = 0; b < BPW; ++b) {
-            double cx, cy, cz;
-            pair_accel(xi[b], yi[b], zi[b], pj, cx, cy, cz);   // NaN at j == i: never read back
-            C[(b * 3 + 0) * kRow + lane] = cx;
-            C[(b * 3 + 1) * kRow + lane] = cy;
-            C[(b * 3 + 2) * kRow + lane] = cz;
-        }
+        for (int q = 0; q < 3 * BPW; ++q) C[q * kRow + lane] = c[q];
+    };
+    // un-pipelined tile (holds the wave's own bodies and/or is the ragged last one): IEEE arithmetic throughout
+    // (n2 = 0 on the self lane), masked chain
+    auto special = [&](int t) {
+        const Body4 pj = load_src(t);
+        double c[3 * BPW];
+#pragma unroll
+        for (int b = 0; b < BPW; ++b)
+            pair_finish<false>(pair_pre(xi[b], yi[b], zi[b], pj), pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
+        store_tile(c);
         wave_lds_fence();
-        const int cnt = min(kTile, n - j0);
-        const bool diag = (i0 >= j0) && (i0 < j0 + kTile);   // wave-uniform: BPW divides 64 and i0 % BPW == 0
-        if (!diag && cnt == kTile) {
+        if (chain_lane) chain_masked<BPW>(row, min(kTile, n - t * kTile), t == tdiag ? gself : -1, li, acc, accL);
+        wave_lds_fence();
+    };
+    // pipelined run over the full tiles [tb, te), none of which holds the wave's bodies.
+    // LDS is double buffered: step t sums buffer t&1 while the contributions of tile t+1 go to the other one.
+    constexpr int kBuf = 3 * BPW * kRow;
+    auto run = [&](int tb, int te) {
+        if (tb >= te) return;
+        TileCtx<BPW> w;
+        {
+            const Body4 pj = load_src(tb);
+            double c[3 * BPW];
 #pragma unroll
-            for (int jl = 0; jl < kTile; jl += 2) {
-                const double2 c2 = *reinterpret_cast<const double2 *>(row + jl);   // ds_read_b128
-                acc = acc + c2.x;
-                acc = acc + c2.y;
+            for (int b = 0; b < BPW; ++b)
+                pair_finish<false>(pair_pre(xi[b], yi[b], zi[b], pj), pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
+            store_tile(c);                                  // tile tb -> buffer 0
+        }
+        {
+            const Body4 pj = load_src(min(tb + 1, te - 1));
+#pragma unroll
+            for (int b = 0; b < BPW; ++b) w.pre[0][b] = pair_pre(xi[b], yi[b], zi[b], pj);
+            w.mu[0] = pj.mu;
+        }
+        w.src[0] = load_src(min(tb + 2, te - 1));
+        w.src[1] = load_src(min(tb + 3, te - 1));
+        w.acc = acc;
+        wave_lds_fence();
+        // one step: PH = (t - tb) & 1
+        auto step = [&](auto ph, int t) {
+            constexpr int PH = decltype(ph)::value;
+            const double *row_cur = row + PH * kBuf;
+            double *tile_nxt = C + (PH ^ 1) * kBuf;
+            bool bad = false;
+#pragma unroll
+            for (int b = 0; b < BPW; ++b) bad |= !in_range(w.pre[PH][b].n2);
+            if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+                tile_step_fast<BPW, PH>(w, xi, yi, zi, row_cur, tile_nxt, lane);
+            } else {                                        // an operand near the end of the exponent range
+#pragma unroll
+                for (int b = 0; b < BPW; ++b) {
+                    pair_finish<false>(w.pre[PH][b], w.mu[PH], w.c[3 * b], w.c[3 * b + 1], w.c[3 * b + 2]);
+                    w.pre[PH ^ 1][b] = pair_pre(xi[b], yi[b], zi[b], w.src[PH]);
+                }
+#pragma unroll
+                for (int q = 0; q < 3 * BPW; ++q) tile_nxt[q * kRow + lane] = w.c[q];
+                w.mu[PH ^ 1] = w.src[PH].mu;
+                w.acc = chain_full(row_cur, w.acc);
             }
-        } else if (!diag) {
-            for (int jl = 0; jl < cnt; ++jl) acc = acc + row[jl];
+            w.src[PH] = load_src(min(t + 4, te - 1));       // two steps ahead
+            wave_lds_fence();
+        };
+        int t = tb;
+        for (; t + 1 < te - 1; t += 2) {
+            step(std::integral_constant<int, 0>{}, t);
+            step(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (t < te - 1) {                                   // odd number of steps: last tile sits in buffer 1
+            step(std::integral_constant<int, 0>{}, t);
+            w.acc = chain_full(row + kBuf, w.acc);
         } else {
-            for (int jl = 0; jl < cnt; ++jl) {
-                const double c = row[jl];
-                const bool self = (j0 + jl == my_i);
-                accL = self ? acc : accL;          // lower chain complete
-                acc = self ? 0.0 : acc + c;        // upper chain starts from V::default()
-            }
+            w.acc = chain_full(row, w.acc);
         }
+        acc = w.acc;
         wave_lds_fence();
+    };
+
+    if (SINGLE_TILE) {          // n <= 64 (persistent kernel): one masked tile, no pipeline code at all
+        special(0);
+        return accL + acc;
+    }
+    run(0, min(tdiag, tfull));
+    special(tdiag);
+    if (tdiag < tfull) {
+        run(tdiag + 1, tfull);
+        if (tfull < tiles) special(tfull);
     }
     return accL + acc;   // ddy[i] += output_i
 }
@@ -101,7 +416,7 @@ __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double i
 template <int BPW>
 __global__ void __launch_bounds__(64) k_accel(int n, int npad, const Body4 *__restrict__ pos,
                                               const double *__restrict__ acc_init, double *__restrict__ acc_out) {
-    __shared__ __attribute__((aligned(16))) double C[3 * BPW * kRow];
+    __shared__ __attribute__((aligned(16))) double C[2 * 3 * BPW * kRow];   // double buffered contribution tile
     const int lane = threadIdx.x;
     const int i0 = blockIdx.x * BPW;
     const int cb = lane / 3, cc = lane % 3;
@@ -161,7 +476,7 @@ __device__ __forceinline__ void maybe_sample(const SampleArgs &sa, int body, int
 // ------------------------------------------------------------------------------------------------------
 template <int BPW, int L>
 __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
-    __shared__ __attribute__((aligned(16))) double C[3 * BPW * kRow];
+    __shared__ __attribute__((aligned(16))) double C[2 * 3 * BPW * kRow];   // double buffered contribution tile
     const int lane = threadIdx.x;
     const int i0 = blockIdx.x * BPW;
     const int cb = lane / 3, cc = lane % 3;
@@ -174,11 +489,221 @@ __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const int slot = (a.cur + j) % L;
-        yv[j] = owner ? a.Y[slot * lvl + off] : 0.0;
-        av[j] = (owner && j > 0) ? a.A[slot * lvl + off] : 0.0;
+        yv[j] = a.Y[slot * lvl + off];           // non-owner lanes read body 0 (unused): no exec-masked loads
+        av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
     }
 
     const double anew = wave_force<BPW>(a.pos_cur, a.n, i0, 0.0, C, lane);
+    if (!owner) return;
+
+    a.A[(size_t)a.cur * lvl + off] = anew;
+    {
+        double prev[L];
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) prev[j] = av[j + 1];
+        prev[L - 1] = 0.0;
+        a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
+    }
+    maybe_sample(a.samp, my_i, cc, a.step, yv[0]);
+    if (a.do_predict) {
+        av[0] = anew;
+        const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
+        const int nslot = (a.cur + L - 1) % L;
+        a.Y[(size_t)nslot * lvl + off] = ynext;
+        reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wg_force: the all-pairs sum for kWgBodies consecutive bodies by one WORKGROUP of 5 waves with fixed roles.
+//
+// Measured on MI355X (scripts/ubench/lat.hip): a dependent v_add_f64 issues every 8.4 cycles from one wave (two
+// issue slots), v_rsq_f64 / v_rcp_f64 cost ~17 issue cycles each, other f64 ops ~4.1. In the one-wave-per-block
+// form (wave_force) every wave pays the 64 ordered adds and 32 ds_read_b128 of phase B per tile for only 3*BPW
+// useful lanes, and at 4096 bodies there are just enough waves for one per SIMD, so nothing fills the bubbles.
+// Here ONE wave (the chain wave) carries the ordered sums of all 16 bodies of the workgroup -- 48 of its 64 lanes
+// -- while four pair waves produce the contribution tiles through a double-buffered LDS tile, one s_barrier per
+// 64-source tile. The chain wave shares its SIMD with pair wave 0 (waves of a workgroup go to SIMDs round-robin),
+// which therefore gets fewer bodies; the hardware interleaves the two and the adds' bubbles get filled.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kWgBodies = 16;
+constexpr int kWgPairWaves = 4;
+constexpr int kWgThreads = 64 * (kWgPairWaves + 1);  // + 1 chain wave (wave 4: lands on the SIMD of wave 0)
+constexpr int kWgRows = 3 * kWgBodies;
+constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
+constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave
+__device__ long long g_wg_cycles[8];                 // debug (EPH_DEBUG_WG=3): block 0 cycle accounting
+
+// pair wave: NB bodies (local indices b0..) against the 64 sources in pj -> rows of `tile`
+template <int NB>
+__device__ __forceinline__ void wg_pair_tile(const double (&xi)[NB], const double (&yi)[NB], const double (&zi)[NB],
+                                             const Body4 &pj, bool ieee, double *tile, int b0, int lane) {
+    // (forcing a stage-major interleave of the NB interactions with scheduling anchors was measured: no gain
+    // over the compiler's own schedule here, 1380 vs 1400 cycles per 5-body tile)
+    PairPre pre[NB];
+    bool bad = ieee;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        pre[b] = pair_pre(xi[b], yi[b], zi[b], pj);
+        bad |= !in_range(pre[b].n2);
+    }
+    double c[3 * NB];
+    if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) pair_finish<true>(pre[b], pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
+    } else {   // the tile holding the workgroup's own bodies (n2 = 0 on the self lane) or an out-of-range operand
+#pragma unroll
+        for (int b = 0; b < NB; ++b) pair_finish<false>(pre[b], pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) tile[(3 * b0 + q) * kRow + lane] = c[q];
+}
+
+// Barrier schedule (every wave executes tiles+1 barriers): B_0 after tiles 0 and 1 are in LDS; iteration t: pair
+// waves produce tile t+2 into buffer (t+2)%3 while the chain wave sums tile t from buffer t%3; barrier.
+template <int NB, typename PosPtr>
+__device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles,
+                                             int tdiag, int dbg) {
+    double xi[NB], yi[NB], zi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int ii = min(i0 + b0 + b, n - 1);
+        xi[b] = pos[ii].x;
+        yi[b] = pos[ii].y;
+        zi[b] = pos[ii].z;
+    }
+    auto load_src = [&](int t) -> Body4 {
+        const int j = min(t, tiles - 1) * kTile + lane;
+        return pos[j < n ? j : n - 1];
+    };
+    Body4 pj = load_src(0);
+    Body4 pjn = load_src(1);
+    wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == 0, C, b0, lane);
+    pj = pjn;
+    pjn = load_src(2);
+    if (tiles > 1) wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == 1, C + kWgBuf, b0, lane);
+    __syncthreads();
+    long long t_work = 0, t_bar = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const long long c0 = __builtin_readcyclecounter();
+        if (t + 2 < tiles) {
+            pj = pjn;
+            pjn = load_src(t + 3);
+            if (!(dbg & 2))
+                wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == t + 2, C + ((t + 2) % kWgBufs) * kWgBuf, b0, lane);
+        }
+        const long long c1 = __builtin_readcyclecounter();
+        __syncthreads();
+        const long long c2 = __builtin_readcyclecounter();
+        t_work += c1 - c0;
+        t_bar += c2 - c1;
+    }
+    if ((dbg & 4) && blockIdx.x == 7 && lane == 0 && b0 == 7) { g_wg_cycles[0] = t_work; g_wg_cycles[1] = t_bar; }
+    if ((dbg & 4) && blockIdx.x == 7 && lane == 0 && b0 == 0) { g_wg_cycles[2] = t_work; g_wg_cycles[3] = t_bar; }
+}
+
+// chain over a full tile whose first two chunks are already in q[0], q[1]; leaves the first two chunks of the
+// NEXT tile (row_next, complete since the previous barrier) in q[0], q[1]
+__device__ __forceinline__ double chain_full_pf(const double *row, const double *row_next, double2 (&q)[4][8],
+                                                double acc) {
+    load_chunk(row, 2, q[2]);
+    acc = add_chunk(q[0], acc);
+    load_chunk(row, 3, q[3]);
+    acc = add_chunk(q[1], acc);
+    load_chunk(row_next, 0, q[0]);
+    acc = add_chunk(q[2], acc);
+    load_chunk(row_next, 1, q[1]);
+    return add_chunk(q[3], acc);
+}
+
+// Returns on chain-wave lane ch < 48: component ch%3 of body i0 + ch/3. All 320 threads must call it.
+template <typename PosPtr>
+__device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg = 0) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tiles = (n + kTile - 1) / kTile;
+    const int tdiag = i0 / kTile;
+    // Waves of a workgroup are placed on the four SIMDs round-robin, so the chain wave (4) shares a SIMD with pair
+    // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
+    // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
+    // under the denser f64 stream and the step gets slower.)
+    switch (wave) {
+        case 0: wg_pair_wave<2>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+        case 1: wg_pair_wave<5>(pos, n, i0, 2, C, lane, tiles, tdiag, dbg); return 0.0;
+        case 2: wg_pair_wave<5>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg); return 0.0;
+        case 3: wg_pair_wave<4>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+        default: break;
+    }
+    // chain wave (raising its priority with s_setprio was measured: 4-5 us slower per evaluation)
+    const int ch = lane < kWgRows ? lane : kWgRows - 1;
+    const double *row = C + ch * kRow;
+    const int gself = (i0 % kTile) / kWgBodies;
+    const int li = (i0 % kTile) + ch / 3;
+    double acc = init, accL = 0.0;
+    double2 q[4][8];
+    long long t_work = 0, t_bar = 0;
+    const long long c_start = __builtin_readcyclecounter();
+    __syncthreads();                                  // B_0: tiles 0 and 1 ready
+    load_chunk(row, 0, q[0]);
+    load_chunk(row, 1, q[1]);
+    for (int t = 0; t < tiles; ++t) {
+        const long long c0 = __builtin_readcyclecounter();
+        const double *r = row + (t % kWgBufs) * kWgBuf;
+        const double *rn = row + ((t + 1) % kWgBufs) * kWgBuf;   // complete since the previous barrier
+        const int cnt = min(kTile, n - t * kTile);
+        if (dbg & 1) {
+        } else if (t != tdiag && cnt == kTile) {
+            acc = chain_full_pf(r, rn, q, acc);
+        } else {
+            chain_masked<kWgBodies>(r, cnt, t == tdiag ? gself : -1, li, acc, accL);
+            load_chunk(rn, 0, q[0]);
+            load_chunk(rn, 1, q[1]);
+        }
+        const long long c1 = __builtin_readcyclecounter();
+        __syncthreads();                              // tile t consumed, tile t+2 ready
+        const long long c2 = __builtin_readcyclecounter();
+        t_work += c1 - c0;
+        t_bar += c2 - c1;
+    }
+    if ((dbg & 4) && blockIdx.x == 7 && lane == 0) { g_wg_cycles[4] = t_work; g_wg_cycles[5] = t_bar; g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
+    return accL + acc;
+}
+
+__global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
+                                                         const double *__restrict__ acc_init,
+                                                         double *__restrict__ acc_out, int dbg) {
+    __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i0 = blockIdx.x * kWgBodies;
+    const int my_i = i0 + lane / 3, cc = lane % 3;
+    const bool owner = (tid >> 6) == kWgPairWaves && lane < kWgRows && my_i < n;
+    const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
+    const double a = wg_force(pos, n, i0, init, C, tid, dbg);
+    if (owner) acc_out[cc * npad + my_i] = a;
+}
+
+// One launch per integrator step, workgroup-specialised force (see k_lm_step for the step structure).
+template <int L>
+__global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
+    __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool chain_wave = (tid >> 6) == kWgPairWaves;
+    const int i0 = blockIdx.x * kWgBodies;
+    const int cb = lane / 3, cc = lane % 3;
+    const int my_i = i0 + cb;
+    const bool owner = chain_wave && lane < kWgRows && my_i < a.n;
+    const size_t lvl = (size_t)3 * a.npad;
+    const size_t off = (size_t)cc * a.npad + (owner ? my_i : 0);
+
+    double yv[L], av[L];   // history of this lane's (body, component); loaded before the pair loop, used after it
+    if (chain_wave) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int slot = (a.cur + j) % L;
+            yv[j] = a.Y[slot * lvl + off];
+            av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
+        }
+    }
+    const double anew = wg_force(a.pos_cur, a.n, i0, 0.0, C, tid);
     if (!owner) return;
 
     a.A[(size_t)a.cur * lvl + off] = anew;
@@ -223,14 +748,14 @@ __global__ void __launch_bounds__(256) k_lm_predict(const LmArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // k_lm_persistent: n <= 64 (one tile). The whole system lives in one workgroup's LDS and registers and the
 // kernel runs `nsteps` integrator steps per launch (a 32-body step is ~1e3 pair interactions: launch latency
-// would dominate a per-step launch). 16 waves; wave w owns bodies w*BPW..; lane ch of that wave owns the
+// would dominate a per-step launch). 8 waves (two per SIMD, 256 VGPRs each); wave w owns bodies w*BPW..; lane ch of that wave owns the
 // (body, component) chain ch for the force, the velocity, the history ring and the predictor, so the only data
 // shared between threads are the packed positions sP (two barriers per step).
 // On entry slot `cur` is a COMPLETE level (Y, A, V); on exit slot (cur - nsteps) mod L is.
 // ------------------------------------------------------------------------------------------------------
 template <int BPW, int L>
-__global__ void __launch_bounds__(1024) k_lm_persistent(const LmArgs a, long long nsteps) {
-    constexpr int kWaves = 16;
+__global__ void __launch_bounds__(512) k_lm_persistent(const LmArgs a, long long nsteps) {
+    constexpr int kWaves = 8;
     __shared__ __attribute__((aligned(16))) double C[kWaves][3 * BPW * kRow];
     __shared__ __attribute__((aligned(32))) Body4 sP[kTile];
     __shared__ double ringY[L][3 * kTile];   // [slot][body*3 + comp]
@@ -272,7 +797,7 @@ __global__ void __launch_bounds__(1024) k_lm_persistent(const LmArgs a, long lon
             reinterpret_cast<double *>(&sP[my_i])[cc] = ynew;
         }
         __syncthreads();   // new positions visible to every wave
-        const double anew = wave_force<BPW>(sP, a.n, i0, 0.0, C[w], lane);
+        const double anew = wave_force<BPW, true>(sP, a.n, i0, 0.0, C[w], lane);
         if (owner) {
             ringA[nslot][ro] = anew;
             v = lm_cowell<L>(anew, av, ynew, yv[0], a.cw, a.h, a.hc);
@@ -511,23 +1036,44 @@ static int done(const char *what) {
 // bodies per wave: enough waves to cover the 1024 SIMDs of the chip, as many bodies per wave as that allows
 // (phase B's ordered adds cost the same for 1 or 21 chains, so more bodies per wave is cheaper per body)
 int lm_bodies_per_wave(int n) {
-    if (n >= 16 * 1024) return 16;
+    static const int forced = [] {
+        const char *e = getenv("EPH_BPW");             // tuning override (1, 2, 4, 8)
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     if (n >= 8 * 1024) return 8;
     if (n >= 4 * 1024) return 4;
     if (n >= 2 * 1024) return 2;
     return 1;
 }
 
+// which per-step force kernel: 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
+int force_kernel_kind(int n) {
+    static const int forced = [] {
+        const char *e = getenv("EPH_FORCE");           // tuning override: "wave" | "wg"
+        if (!e) return 0;
+        return e[1] == 'a' ? 1 : 2;
+    }();
+    if (forced) return forced;
+    // measured on MI355X (us per step, QT12): n=1024 17 (wg) vs 15 (wave) | 4096: 45-49 vs 56 | 16384: 700 vs 594
+    return (n > 2048 && n < 8192) ? 2 : 1;
+}
+
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out) {
     if (n <= 0) return EPH_OK;
+    if (force_kernel_kind(n) == 2) {
+        static const int dbg = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
+        hipLaunchKernelGGL(k_accel_wg, dim3((n + kWgBodies - 1) / kWgBodies), dim3(kWgThreads), 0, s, n, npad, pos,
+                           acc_init, acc_out, dbg);
+        return done("k_accel_wg");
+    }
     const int bpw = lm_bodies_per_wave(n);
     const dim3 grid((n + bpw - 1) / bpw), block(64);
     switch (bpw) {
         case 1: hipLaunchKernelGGL(k_accel<1>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
         case 2: hipLaunchKernelGGL(k_accel<2>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
         case 4: hipLaunchKernelGGL(k_accel<4>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
-        case 8: hipLaunchKernelGGL(k_accel<8>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
-        default: hipLaunchKernelGGL(k_accel<16>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
+        default: hipLaunchKernelGGL(k_accel<8>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
     }
     return done("k_accel");
 }
@@ -540,13 +1086,19 @@ static int launch_lm_step_L(hipStream_t s, const LmArgs &a) {
         case 1: hipLaunchKernelGGL((k_lm_step<1, L>), grid, block, 0, s, a); break;
         case 2: hipLaunchKernelGGL((k_lm_step<2, L>), grid, block, 0, s, a); break;
         case 4: hipLaunchKernelGGL((k_lm_step<4, L>), grid, block, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((k_lm_step<8, L>), grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_lm_step<16, L>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_lm_step<8, L>), grid, block, 0, s, a); break;
     }
     return done("k_lm_step");
 }
 int launch_lm_step(hipStream_t s, const LmArgs &a) {
     if (a.n <= 0) return EPH_OK;
+    if (force_kernel_kind(a.n) == 2) {
+        const dim3 grid((a.n + kWgBodies - 1) / kWgBodies), block(kWgThreads);
+        if (a.L == 12) hipLaunchKernelGGL(k_lm_step_wg<12>, grid, block, 0, s, a);
+        else if (a.L == 13) hipLaunchKernelGGL(k_lm_step_wg<13>, grid, block, 0, s, a);
+        else return EPH_ERR_UNSUPPORTED;
+        return done("k_lm_step_wg");
+    }
     if (a.L == 12) return launch_lm_step_L<12>(s, a);
     if (a.L == 13) return launch_lm_step_L<13>(s, a);
     return EPH_ERR_UNSUPPORTED;
@@ -561,11 +1113,12 @@ int launch_lm_predict(hipStream_t s, const LmArgs &a) {
 }
 template <int L>
 static int launch_lm_persistent_L(hipStream_t s, const LmArgs &a, int64_t nsteps) {
-    const int per_wave = (a.n + 15) / 16;
-    const dim3 grid(1), block(1024);
+    const int per_wave = (a.n + 7) / 8;
+    const dim3 grid(1), block(512);
     if (per_wave <= 1) hipLaunchKernelGGL((k_lm_persistent<1, L>), grid, block, 0, s, a, (long long)nsteps);
     else if (per_wave <= 2) hipLaunchKernelGGL((k_lm_persistent<2, L>), grid, block, 0, s, a, (long long)nsteps);
-    else hipLaunchKernelGGL((k_lm_persistent<4, L>), grid, block, 0, s, a, (long long)nsteps);
+    else if (per_wave <= 4) hipLaunchKernelGGL((k_lm_persistent<4, L>), grid, block, 0, s, a, (long long)nsteps);
+    else hipLaunchKernelGGL((k_lm_persistent<8, L>), grid, block, 0, s, a, (long long)nsteps);
     return done("k_lm_persistent");
 }
 int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps) {
@@ -601,6 +1154,16 @@ int launch_soa_to_aos(hipStream_t s, int n, int npad, const double *soa, double 
     if (n <= 0) return EPH_OK;
     hipLaunchKernelGGL(k_soa_to_aos, dim3((3 * n + 255) / 256), dim3(256), 0, s, n, npad, soa, aos);
     return done("k_soa_to_aos");
+}
+int debug_wg_cycles(long long *out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_cycles), sizeof(long long) * 8);
+    if (e != hipSuccess) { set_last_error("hipMemcpyFromSymbol", e); return EPH_ERR_HIP; }
+    return EPH_OK;
+}
+int launch_debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee) {
+    if (n <= 0) return EPH_OK;
+    hipLaunchKernelGGL(k_debug_inv_r3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long long)n, n2, fast, ieee);
+    return done("k_debug_inv_r3");
 }
 int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step) {
     if (n <= 0 || !sa.period) return EPH_OK;

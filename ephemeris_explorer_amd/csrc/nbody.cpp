@@ -204,7 +204,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
         a.pos_next = P_[pp_ ^ 1].p;
         if ((st = launch_lm_persistent(stream_, a, k))) return st;
         cur_ = (int)(((int64_t)cur_ - k % L_ + L_) % L_);
-        kernel_launches_ += 1;
+        if (timing_) kernel_launches_ += 1;
     } else {
         a.cur = cur_;
         a.pos_cur = P_[pp_].p;
@@ -220,7 +220,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.step = (uint32_t)s;
             if ((st = launch_lm_step(stream_, a))) return st;
         }
-        kernel_launches_ += (uint64_t)k;
+        if (timing_) kernel_launches_ += (uint64_t)k;
     }
     if (timing_) {
         EPH_HIP(hipEventRecord(ev1_, stream_));

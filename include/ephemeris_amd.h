@@ -147,6 +147,13 @@ void eph_solution_destroy(eph_solution *s);
 int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, const double *samples,
                               double *coeffs, int32_t *ncoef);
 
+/* Test hook: 1/(x*sqrt(x)) for n inputs computed by the kernel's in-range fast sequences (NaN where the range
+ * guard would send the tile to the IEEE form) and by the compiler's IEEE sqrt/divide expansions. */
+int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee);
+/* Tuning hook (EPH_DEBUG_WG=3): s_memtime accounting of one workgroup of the force kernel: {pair wave work,
+ * barrier wait, pair wave 0 work, wait, chain wave work, wait, tiles, 0}. */
+int32_t eph_debug_wg_cycles(int64_t *out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,3 +187,27 @@ def test_least_squares_fit_kernel(gpu):
                 ref, n = orc.least_squares_fit(degree, ts, samples[w])
                 assert n == nc[w], (degree, w)
                 assert_same_bits(co[w], ref, f"fit degree {degree} window {w}")
+
+
+def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu):
+    """The pair kernel's stripped sqrt / reciprocal sequences (no range-scaling wrappers) must give the IEEE
+    correctly rounded results inside the guarded range: compared with the compiler's full expansions on the
+    device AND with the host's sqrt/divide (x86 sqrtsd/divsd), over random mantissas across the whole guarded
+    exponent range plus adversarial mantissas (all ones, 1+ulp, perfect squares, powers of two)."""
+    rng = np.random.default_rng(11)
+    mant = np.concatenate([rng.uniform(1.0, 2.0, 2_000_000), [1.0, np.nextafter(2.0, 0), np.nextafter(1.0, 2),
+                           1.5, 1.25, 1.9999999999999991, 1.0000000000000004]])
+    expo = rng.integers(-299, 299, size=mant.size)
+    x = np.ldexp(mant, expo)
+    x = np.concatenate([x, np.arange(1, 4097, dtype=np.float64) ** 2, np.ldexp(1.0, np.arange(-300, 300)),
+                        np.ldexp(np.nextafter(2.0, 0), np.arange(-300, 299))])
+    fast, ieee = gpu.debug_inv_r3(x)
+    host = 1.0 / (x * np.sqrt(x))
+    ok = ~np.isnan(fast)
+    assert ok.mean() > 0.999                       # only the range ends fall to the IEEE form
+    assert_same_bits(ieee, host, "device IEEE expansions vs host")
+    assert_same_bits(fast[ok], host[ok], "in-range sequences vs host")
+    # outside the guard the fast form is not used
+    out = np.array([0.0, 1e-300, 1e300, np.inf, 5e-324])
+    f2, _ = gpu.debug_inv_r3(out)
+    assert np.isnan(f2).all()
