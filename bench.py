@@ -109,17 +109,22 @@ def main():
     g.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from ephemeris_explorer_amd.parallel import reduce_timing
+    units, elapsed = reduce_timing(elapsed, n * args.steps, dist, device="cuda")   # sum of units, MAX of time
     ms_kernel, launches = g.kernel_time()
 
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        value = units / elapsed
         launch_s = ms_kernel * 1e-3 / max(launches, 1)      # HIP events on the handle's stream, timed region only
         achieved_gbs = BYTES_PER_BODY_STEP * n / launch_s / 1e9
         flops = (FLOP_PER_INTERACTION * (n - 1) + 231.0) * n
+        # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected and corrected
+        # as MI355X_MICROARCH.md prescribes) of this same command, committed under profiles/ -- not measurable live
+        traffic, traffic_src = None, None
+        tj = ROOT / "profiles" / "traffic.json"
+        if tj.exists() and n == N_BODIES:
+            tinfo = json.loads(tj.read_text())
+            traffic, traffic_src = tinfo.get("traffic_bytes_per_launch"), tinfo.get("source")
         out = {
             "metric": "body-steps/s", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -129,8 +134,8 @@ def main():
             "config": {"workload": f"plummer_{n}_f64_qt12 (BASELINE.json configs[2]; h=1/1024, seed 20260926+rank)",
                        "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_lm_step<4,12>", "launch_us": launch_s * 1e6, "launches": launches,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_lm_step_wg<12>", "launch_us": launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * n,
                          "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see fp64"},
             "fp64": {"bound": "fp64_valu", "achieved": flops / launch_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/<tag>/ (rocprofv3 CSVs from scripts/round_profile.sh) into small tracked files under profiles/.
+
+usage: python scripts/summarize_profile.py r01
+writes profiles/<tag>_bench.json, profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, profiles/traffic.json"""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1]
+src = ROOT / "gpurun_out" / tag
+dst = ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+shutil.copy(src / "stats_kernel_stats.csv", dst / f"{tag}_kernel_stats.csv")
+bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
+(dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1) + "\n")
+
+
+def per_dispatch(name):
+    rows = list(csv.DictReader(open(src / f"{name}_counter_collection.csv")))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in rows:
+        k = r["Kernel_Name"]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return {k: {"dispatches": len(disp[k]), **{c: v / len(disp[k]) for c, v in cs.items()}} for k, cs in agg.items()}
+
+
+pmc = {}
+for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    for k, v in per_dispatch(name).items():
+        if "lm_step" in k or "lm_persistent" in k:
+            pmc.setdefault(k, {}).update(v)
+stats = {r["Name"]: r for r in csv.DictReader(open(src / "stats_kernel_stats.csv"))}
+out = {"note": "per-dispatch averages; SQ_* counters are summed over the chip; FETCH_SIZE/WRITE_SIZE in KiB. "
+               "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read, so "
+               "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB; Infinity-Cache hits are counted, so this is an upper "
+               "bound on HBM bytes (the 3.7 MB working set is cache resident).",
+       "kernels": {}}
+for k, v in pmc.items():
+    e = dict(v)
+    if k in stats:
+        e["avg_ns_kernel_trace"] = float(stats[k]["AverageNs"])
+        e["calls"] = int(stats[k]["Calls"])
+    if "FETCH_SIZE" in e:
+        e["traffic_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e.get("WRITE_SIZE", 0.0)) * 1024.0
+    out["kernels"][k] = e
+(dst / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1) + "\n")
+main = max(out["kernels"].items(), key=lambda kv: kv[1].get("calls", 0) * kv[1].get("avg_ns_kernel_trace", 0))
+(dst / "traffic.json").write_text(json.dumps({
+    "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)",
+    "kernel": main[0], "traffic_bytes_per_launch": main[1].get("traffic_bytes_per_launch"),
+    "avg_ns_kernel_trace": main[1].get("avg_ns_kernel_trace")}, indent=1) + "\n")
+print(json.dumps(out, indent=1)[:3000])
+print("bench:", bench["value"], bench["roofline"]["launch_us"])

@@ -1,0 +1,67 @@
+"""CPU, world_size 2 (gloo): the N>1 plumbing bench.py uses -- per-rank replicas, block sharding, max-over-ranks
+timing -- exercised with the oracle standing in for the device on each rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    from oracle import orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert parallel.env_rank() == (rank, rank, world)
+    pos, vel, mu = plummer(64, seed=parallel.replica_seed(20260926, rank))
+    nb = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0)
+    steps = 20
+    dist.barrier()
+    assert nb.advance(12 + steps) == 0
+    elapsed = 0.5 + rank                      # deterministic stand-in for the measured time
+    total, tmax = parallel.reduce_timing(elapsed, 64 * steps, dist)
+    lo, hi = parallel.shard_range(1001, rank, world)
+    out[rank] = (total, tmax, lo, hi, float(nb.state()[0].sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_replicas_and_reduction():
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert set(out.keys()) == {0, 1}
+    for r in range(world):
+        total, tmax, lo, hi, _ = out[r]
+        assert total == 2 * 64 * 20            # units summed over ranks
+        assert tmax == 1.5                      # max over ranks, not the mean
+    assert (out[0][2], out[0][3], out[1][2], out[1][3]) == (0, 501, 501, 1001)
+    assert out[0][4] != out[1][4]               # ranks integrate different replicas
+
+
+def test_shard_range_covers_everything():
+    from ephemeris_explorer_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
