@@ -38,6 +38,9 @@ ABI_SYMBOLS = [
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append",
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
+    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_craft_batch_create", "eph_craft_batch_propagate",
+    "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
 ]
 
 
@@ -65,7 +68,21 @@ _dp = C.POINTER(C.c_double)
 _u32p = C.POINTER(C.c_uint32)
 _i32p = C.POINTER(C.c_int32)
 _u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
 _L = None
+KNOTS_FULL = 6
+
+
+class AdaptiveParams(C.Structure):
+    """eph_adaptive_params = integration::AdaptiveMethodParams; defaults = the app's INITIAL_ADAPTIVE_PARAMS
+    (ephemeris_explorer/src/load/mod.rs:472-486)."""
+    _fields_ = [("h_init", C.c_double), ("h_max", C.c_double), ("tol_position", C.c_double),
+                ("tol_velocity", C.c_double), ("fac_min", C.c_double), ("fac_max", C.c_double), ("fac", C.c_double),
+                ("n_max", C.c_uint32)]
+
+    @classmethod
+    def default(cls, tolerance=1e-3):
+        return cls(60.0, 1.7976931348623157e308, tolerance, tolerance, 1.0 / 5.0, 5.0 / 1.0, 9.0 / 10.0, 1_000_000)
 
 
 def _lib():
@@ -125,6 +142,20 @@ def _lib():
     L.eph_solution_destroy.restype = None
     L.eph_least_squares_fit.argtypes = [i32, i32, i64, _dp, _dp, _i32p]
     L.eph_debug_inv_r3.argtypes = [i64, _dp, _dp, _dp]
+    L.eph_ephemeris_create.argtypes = [vp, _dp, C.POINTER(vp)]
+    L.eph_ephemeris_destroy.argtypes = [vp]
+    L.eph_ephemeris_destroy.restype = None
+    L.eph_craft_batch_create.argtypes = [vp, i64, _dp, _dp, _dp, C.c_char_p, C.POINTER(AdaptiveParams), _i64p, _dp, _dp,
+                                         _dp, _i32p, i32, C.POINTER(vp)]
+    L.eph_craft_batch_propagate.argtypes = [vp, f64]
+    L.eph_craft_batch_status.argtypes = [vp, _i32p, _i32p, _u32p, _u32p]
+    L.eph_craft_batch_state.argtypes = [vp, _dp, _dp, _dp, _dp]
+    L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
+    L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
+    L.eph_craft_batch_destroy.argtypes = [vp]
+    L.eph_craft_batch_destroy.restype = None
+    L.eph_hermite_eval.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _u8p]
+    L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
     if L.eph_abi_version() != 1:
         raise ImportError("libephemeris_amd.so ABI version mismatch")
     _L = L
@@ -401,3 +432,101 @@ class NBodyPropagator:
         if getattr(self, "_h", None):
             self._L.eph_prop_destroy(self._h)
             self._h = None
+
+
+class Ephemeris:
+    """Device-resident table of the massive bodies' UniformSplines (what `Bodies` holds in the app)."""
+
+    def __init__(self, solution, mu):
+        self._L = _lib()
+        mu = _f64(mu)
+        h_ = C.c_void_p()
+        _check(self._L.eph_ephemeris_create(solution._h, _p(mu), C.byref(h_)), "eph_ephemeris_create")
+        self._h = h_
+        self.n_bodies = len(mu)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.eph_ephemeris_destroy(self._h)
+            self._h = None
+
+
+class SpacecraftBatch:
+    """n independent SpacecraftPropagator<[StateVector;1], ReferenceFrame, Bodies, <adaptive ERK pair>,
+    CubicHermiteSplineSolout>, one device thread each. burns[i] = list of (start, end, acc[3], ref_body or -1)."""
+
+    def __init__(self, ephemeris, t0, pos, vel, method="Verner87", params=None, burns=None, max_knots=4096):
+        self._L = _lib()
+        self.ephemeris = ephemeris
+        pos, vel = _f64(pos).reshape(-1, 3), _f64(vel).reshape(-1, 3)
+        self.n = len(pos)
+        t0 = _f64(np.broadcast_to(np.asarray(t0, dtype=np.float64), (self.n,)))
+        self.params = params or AdaptiveParams.default()
+        burns = burns if burns is not None else [[] for _ in range(self.n)]
+        off = np.zeros(self.n + 1, dtype=np.int64)
+        flat = []
+        for i, bl in enumerate(burns):
+            flat.extend(bl)
+            off[i + 1] = len(flat)
+        bs = _f64([b[0] for b in flat] or [0.0])
+        be = _f64([b[1] for b in flat] or [0.0])
+        ba = _f64([b[2] for b in flat] or [[0.0, 0.0, 0.0]])
+        br = np.ascontiguousarray([b[3] for b in flat] or [0], dtype=np.int32)
+        h_ = C.c_void_p()
+        st = self._L.eph_craft_batch_create(ephemeris._h, self.n, _p(t0), _p(pos), _p(vel), method.encode(),
+                                            C.byref(self.params), _p(off, _i64p), _p(bs), _p(be), _p(ba), _p(br, _i32p),
+                                            int(max_knots), C.byref(h_))
+        _check(st, "eph_craft_batch_create")
+        self._h = h_
+
+    def propagate(self, t_end):
+        """step_to(t_end) for every craft; per-craft outcomes in status()"""
+        _check(self._L.eph_craft_batch_propagate(self._h, float(t_end)), "eph_craft_batch_propagate")
+
+    def status(self):
+        st, nk = np.zeros(self.n, np.int32), np.zeros(self.n, np.int32)
+        at, sp = np.zeros(self.n, np.uint32), np.zeros(self.n, np.uint32)
+        _check(self._L.eph_craft_batch_status(self._h, _p(st, _i32p), _p(nk, _i32p), _p(at, _u32p), _p(sp, _u32p)),
+               "eph_craft_batch_status")
+        return dict(status=st, nknots=nk, attempts=at, steps=sp)
+
+    def state(self):
+        t, h = np.zeros(self.n), np.zeros(self.n)
+        p, v = np.zeros((self.n, 3)), np.zeros((self.n, 3))
+        _check(self._L.eph_craft_batch_state(self._h, _p(t), _p(p), _p(v), _p(h)), "eph_craft_batch_state")
+        return dict(t=t, pos=p, vel=v, next_h=h)
+
+    def knots(self, craft, nknots=None):
+        nk = int(self.status()["nknots"][craft]) if nknots is None else int(nknots)
+        t, p, v = np.zeros(nk), np.zeros((nk, 3)), np.zeros((nk, 3))
+        _check(self._L.eph_craft_batch_knots(self._h, int(craft), _p(t), _p(p), _p(v)), "eph_craft_batch_knots")
+        return t, p, v
+
+    def kernel_ms(self):
+        ms = C.c_double()
+        _check(self._L.eph_craft_batch_kernel_time(self._h, C.byref(ms)), "eph_craft_batch_kernel_time")
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.eph_craft_batch_destroy(self._h)
+            self._h = None
+
+
+def hermite_eval(t, pos, vel, at, with_velocity=True):
+    """CubicHermiteSpline::state_vector at many epochs (device)."""
+    t, pos, vel, at = _f64(t), _f64(pos), _f64(vel), _f64(np.atleast_1d(at))
+    m = len(at)
+    op, ov = np.zeros((m, 3)), np.zeros((m, 3))
+    inside = np.zeros(m, dtype=np.uint8)
+    _check(_lib().eph_hermite_eval(len(t), _p(t), _p(pos), _p(vel), m, _p(at), _p(op), _p(ov) if with_velocity else None,
+                                   _p(inside, _u8p)), "eph_hermite_eval")
+    return op, (ov if with_velocity else None), inside.astype(bool)
+
+
+def debug_pow(x, y):
+    """test hook: the controller's correctly rounded pow on the device"""
+    x = _f64(x)
+    out = np.zeros_like(x)
+    _check(_lib().eph_debug_pow(x.size, _p(x), float(y), _p(out)), "eph_debug_pow")
+    return out

@@ -39,9 +39,6 @@ struct eph_prop {
     std::unique_ptr<NBodyPropagator> p;
     eph_nbody view;
 };
-struct eph_solution {
-    Solution s;
-};
 
 #define EPH_GUARD_BEGIN try {
 #define EPH_GUARD_END                                   \

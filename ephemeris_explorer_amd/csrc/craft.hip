@@ -1,0 +1,723 @@
+// craft.hip -- the massless path: a batch of independent spacecraft, one device thread each, propagated with an
+// adaptive embedded explicit Runge-Kutta pair against the massive bodies' piecewise-polynomial ephemeris.
+//
+// Mirrors (paths relative to the reference repository root):
+//   SpacecraftPropagator::{new, step, reset_integrator}, SpacecraftModel, Timeline, CubicHermiteSplineSolout
+//                                                       ephemeris/src/propagators/spacecraft.rs:58-332,415-695
+//   AdaptiveRungeKuttaIntegrator::advance, IController::step, PreviousStep
+//                                                       integration/src/runge_kutta/mod.rs:188-285,396-440
+//   ERK::{advance, error, undo_step}                    integration/src/runge_kutta/explicit.rs:54-141
+//   Bodies::acceleration, GravitationalBody::acceleration_at, TNB, ReferenceFrame, AbsTol
+//                                                       ephemeris_explorer/src/dynamics/spacecraft.rs:70-74,218-293,609-641
+//   UniformSpline::{position, state_vector}             ephemeris/src/trajectory.rs:459-470,551-617
+// glam::DVec3 operations (crate glam 0.30.10, not on disk) are restated from the published crate.
+// Same f64 operations in the same order as the CPU path; the one libm call on the path, powf in the step-size
+// controller, is evaluated correctly rounded in double-double arithmetic on both sides.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "host.h"
+
+namespace eph {
+
+struct BodyEntry {            // one massive body's UniformSpline on the device
+    double start, interval, mu;
+    long long npoly;
+    long long coeff_off;      // index of polynomial 0 in the coefficient / ncoef arrays
+};
+struct SegmentDev {           // Segment<DVec3, ReferenceFrame>
+    double start, end;
+    double ax, ay, az;
+    int is_burn, ref;         // ref: body index, -1 = inertial
+};
+struct CraftArgs {
+    long long n_craft;
+    int n_bodies;
+    const BodyEntry *bodies;
+    const double *coeffs;     // [poly][8][3]
+    const int *ncoef;
+    // per craft (SoA)
+    double *time, *y /*[6][n]*/, *next_h, *klast /*[6][n] FSAL carry*/, *last_knot_t;
+    unsigned *n_attempts, *rk_i, *steps;
+    int *cur_seg, *status, *nknots;
+    const long long *seg_off;
+    const SegmentDev *segs;
+    // knots: [max_knots][n] and [max_knots][6][n]
+    double *knot_t, *knot_y;
+    int max_knots;
+    // method + controller
+    ErkCoeffs rk;
+    double h_init, h_max, tol_pos, tol_vel, fac_min, fac_max, fac;
+    unsigned n_max;
+    double t_end;
+};
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 scale(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+__device__ __forceinline__ double length_recip(V3 a) { return 1.0 / sqrt(dot(a, a)); }
+__device__ __forceinline__ bool try_normalize(V3 a, V3 &out) {
+    const double rcp = length_recip(a);
+    if (isfinite(rcp) && rcp > 0.0) { out = scale(a, rcp); return true; }
+    return false;
+}
+
+
+// ---- powf of the step-size controller ------------------------------------------------------------------------
+// `err.pow(-k.inv())` (integration/src/runge_kutta/mod.rs:239) is the platform libm's pow in the reference -- the only
+// operation on the path whose bits depend on the platform. Evaluated here correctly rounded in double-double
+// arithmetic (log: atanh series, exp: Taylor series, ~100 bits), the same operation sequence the oracle pins.
+struct DD { double hi, lo; };
+__device__ __forceinline__ DD dd_two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ DD dd_quick(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+__device__ __forceinline__ DD dd_two_prod(double a, double b) { const double p = a * b; return {p, __builtin_fma(a, b, -p)}; }
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+    DD s = dd_two_sum(a.hi, b.hi);
+    const DD t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_quick(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_quick(s.hi, s.lo);
+}
+__device__ __forceinline__ DD dd_mul(DD a, DD b) {
+    DD p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick(p.hi, p.lo);
+}
+__device__ __forceinline__ DD dd_mul_d(DD a, double b) {
+    DD p = dd_two_prod(a.hi, b);
+    p.lo += a.lo * b;
+    return dd_quick(p.hi, p.lo);
+}
+__device__ __forceinline__ DD dd_neg(DD a) { return {-a.hi, -a.lo}; }
+__device__ __noinline__ DD dd_div(DD a, DD b) {
+    const double q1 = a.hi / b.hi;
+    DD r = dd_add(a, dd_neg(dd_mul_d(b, q1)));
+    const double q2 = r.hi / b.hi;
+    r = dd_add(r, dd_neg(dd_mul_d(b, q2)));
+    const double q3 = r.hi / b.hi;
+    const DD q = dd_quick(q1, q2);
+    return dd_add(q, DD{q3, 0.0});
+}
+__device__ __noinline__ double cr_pow(double x, double y) {
+    if (isnan(x) || isnan(y)) return __builtin_nan("");
+    if (x == 0.0) return y < 0.0 ? __builtin_inf() : 0.0;
+    if (isinf(x)) return y < 0.0 ? 0.0 : __builtin_inf();
+    if (x < 0.0) return __builtin_nan("");
+    const DD ln2 = {0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56};
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0x1.6a09e667f3bcdp-1) { m *= 2.0; e -= 1; }
+    const DD s = dd_div(DD{m - 1.0, 0.0}, dd_two_sum(m, 1.0));
+    const DD s2 = dd_mul(s, s);
+    DD sum = dd_div(DD{1.0, 0.0}, DD{61.0, 0.0});
+    for (int k = 29; k >= 0; --k) sum = dd_add(dd_mul(sum, s2), dd_div(DD{1.0, 0.0}, DD{(double)(2 * k + 1), 0.0}));
+    DD lg = dd_mul(dd_mul_d(s, 2.0), sum);
+    lg = dd_add(dd_mul_d(ln2, (double)e), lg);
+    const DD z = dd_mul_d(lg, y);
+    if (z.hi > 709.0) return __builtin_inf();
+    if (z.hi < -745.0) return 0.0;
+    const double kf = nearbyint(z.hi / ln2.hi);
+    const DD r = dd_add(z, dd_neg(dd_mul_d(ln2, kf)));
+    DD term = {1.0, 0.0}, ex = {1.0, 0.0};
+    for (int n = 1; n <= 30; ++n) {
+        term = dd_div(dd_mul(term, r), DD{(double)n, 0.0});
+        ex = dd_add(ex, term);
+    }
+    return ldexp(ex.hi + ex.lo, (int)kf);
+}
+__global__ void k_debug_pow(long long n, const double *__restrict__ x, double y, double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cr_pow(x[i], y);
+}
+
+// UniformSpline::get_polynomial: false = None
+__device__ __forceinline__ bool spline_locate(const BodyEntry &b, double at, long long &idx, double &tau) {
+    const double local = at - b.start;
+    const double span = b.interval * (double)b.npoly;
+    if (__builtin_signbit(local) || local > span) return false;
+    const double c = ceil(local / b.interval);
+    const unsigned long long ci = c <= 0.0 ? 0ull : (c >= 18446744073709551616.0 ? ~0ull : (unsigned long long)c);
+    const unsigned long long i = ci == 0 ? 0 : ci - 1;
+    if (i >= (unsigned long long)b.npoly) return false;
+    idx = (long long)i;
+    tau = (local - b.interval * (double)i) / b.interval;
+    return true;
+}
+
+// FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.
+__device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &sg, double t, const double (&y)[6],
+                                          double (&dy)[6]) {
+    const V3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
+    V3 acc = {0.0, 0.0, 0.0};
+    for (int b = 0; b < a.n_bodies; ++b) {            // Bodies::acceleration: index order
+        const BodyEntry be = a.bodies[b];
+        long long idx;
+        double tau;
+        if (!spline_locate(be, t, idx, tau)) return false;
+        const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+        const int nc = a.ncoef[be.coeff_off + idx];
+        V3 bp = {0.0, 0.0, 0.0};                      // eval_slice_horner
+        for (int k = nc - 1; k >= 0; --k) {
+            bp.x = bp.x * tau + co[k * 3 + 0];
+            bp.y = bp.y * tau + co[k * 3 + 1];
+            bp.z = bp.z * tau + co[k * 3 + 2];
+        }
+        const V3 d = sub(bp, pos);                    // acceleration_at::<false>: dir = body - at
+        const double n2 = dot(d, d);
+        const double inv = 1.0 / (n2 * sqrt(n2));
+        acc = add(acc, scale(d, be.mu * inv));
+    }
+    V3 man = {0.0, 0.0, 0.0};
+    if (sg.is_burn) {
+        const V3 thrust = {sg.ax, sg.ay, sg.az};
+        if (sg.ref >= 0) {                            // ReferenceFrame::Relative -> TNB::try_new(sv - ref.state_vector(t))
+            const BodyEntry be = a.bodies[sg.ref];
+            long long idx;
+            double tau;
+            if (!spline_locate(be, t, idx, tau)) return false;
+            const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+            const int nc = a.ncoef[be.coeff_off + idx];
+            double rp[3], rv[3];
+            for (int c = 0; c < 3; ++c) {             // Polynomial::eval_and_deriv
+                const double first = nc ? co[c] : 0.0;
+                const double last = nc ? co[(nc - 1) * 3 + c] : 0.0;
+                double e = last, d = last;
+                for (int k = nc - 2; k >= 1; --k) {
+                    e = e * tau + co[k * 3 + c];
+                    d = d * tau + e;
+                }
+                e = e * tau + first;
+                rp[c] = e;
+                rv[c] = d / be.interval;
+            }
+            const V3 rel_p = sub(pos, V3{rp[0], rp[1], rp[2]}), rel_v = sub(vel, V3{rv[0], rv[1], rv[2]});
+            V3 x, yv;
+            if (!try_normalize(rel_v, x)) return false;
+            if (!try_normalize(cross(rel_p, rel_v), yv)) return false;
+            const V3 xy = cross(x, yv);
+            const V3 z = scale(xy, length_recip(xy));
+            V3 r = scale(x, thrust.x);                // DMat3::from_cols(x, z, y).mul_vec3(thrust)
+            r = add(r, scale(z, thrust.y));
+            r = add(r, scale(yv, thrust.z));
+            man = r;
+        } else {                                      // TNB::IDENTITY.mul_vec3(thrust)
+            V3 r = scale(V3{1.0, 0.0, 0.0}, thrust.x);
+            r = add(r, scale(V3{0.0, 1.0, 0.0}, thrust.y));
+            r = add(r, scale(V3{0.0, 0.0, 1.0}, thrust.z));
+            man = r;
+        }
+    }
+    const V3 tot = add(acc, man);
+    dy[0] = vel.x; dy[1] = vel.y; dy[2] = vel.z;
+    dy[3] = tot.x; dy[4] = tot.y; dy[5] = tot.z;
+    return true;
+}
+
+template <int S, bool FSAL>
+__global__ void __launch_bounds__(64) k_craft_propagate(const CraftArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_craft) return;
+    const long long n = a.n_craft;
+    int status = a.status[i];
+    if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
+    status = EPH_OK;
+
+    double time = a.time[i], y[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) y[d] = a.y[d * n + i];
+    double next_h = a.next_h[i];
+    unsigned n_att = a.n_attempts[i], rk_i = a.rk_i[i], steps = a.steps[i];
+    int cur = a.cur_seg[i], nk = a.nknots[i];
+    double last_knot = a.last_knot_t[i];
+    const SegmentDev *segs = a.segs + a.seg_off[i];
+    SegmentDev sg = segs[cur];
+    double bound = sg.end;
+    double k[S][6];
+    if (FSAL) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) k[S - 1][d] = a.klast[d * n + i];
+    }
+    const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+
+    while (!(last_knot >= a.t_end)) {                 // has_reached: solution.end() >= time
+        if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
+        // SpacecraftPropagator::step: advance_timeline + reset_integrator  spacecraft.rs:606-609
+        if (time >= sg.end) {
+            cur += 1;
+            sg = segs[cur];
+            bound = sg.end;
+            next_h = a.h_init;
+            n_att = 0;
+            rk_i = 0;
+        }
+        // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439
+        const double prev_t = time;
+        double prev_y[6], prev_klast[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? k[S - 1][d] : 0.0; }
+        const unsigned prev_i = rk_i;
+        bool failed = false;
+        for (;;) {
+            if (n_att > a.n_max) { status = EPH_MAX_ITERATIONS_REACHED; failed = true; break; }
+            if (time + next_h > bound) next_h = bound - time;
+            const double h = next_h;
+            if (time >= bound) { status = EPH_BOUND_REACHED; failed = true; break; }
+            if (time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; break; }
+            // ERK::advance  explicit.rs:72-106
+            bool ok = true;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (FSAL && s == 0 && rk_i > 0) {
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) { const double t = k[0][d]; k[0][d] = k[S - 1][d]; k[S - 1][d] = t; }
+                    continue;
+                }
+                if (!ok) continue;
+                const double ti = time + h * a.rk.C[s];
+                double yi[6];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) yi[d] = y[d];
+#pragma unroll
+                for (int j = 0; j < s; ++j) {
+                    const double ha = h * a.rk.A[s][j];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) yi[d] = yi[d] + k[j][d] * ha;
+                }
+                ok = craft_rhs(a, sg, ti, yi, k[s]);
+            }
+            if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const double hb = h * a.rk.B[s];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) y[d] = y[d] + k[s][d] * hb;
+            }
+            time = time + h;
+            rk_i += 1;
+            n_att += 1;
+            // RKEmbedded::error + AbsTol::err_over_tol
+            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const double he = h * a.rk.E[s];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) e[d] = e[d] + k[s][d] * he;
+            }
+            const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
+            const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
+            const double err = fmax(pm, vm);
+            // IController::step  mod.rs:225-243
+            const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
+            const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
+            const double nh = next_h * c;
+            next_h = nh > a.h_max ? a.h_max : nh;
+            if (err <= 1.0) break;
+            time = prev_t;                            // PreviousStep::restore
+#pragma unroll
+            for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+            rk_i = prev_i;
+            if (FSAL) {
+#pragma unroll
+                for (int d = 0; d < 6; ++d) k[S - 1][d] = prev_klast[d];
+            }
+        }
+        if (failed) break;
+        steps += 1;
+        // CubicHermiteSplineSolout::solout: push (t, r, v)
+        a.knot_t[(long long)nk * n + i] = time;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + i] = y[d];
+        nk += 1;
+        last_knot = time;
+    }
+
+    a.time[i] = time;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a.y[d * n + i] = y[d];
+    a.next_h[i] = next_h;
+    a.n_attempts[i] = n_att;
+    a.rk_i[i] = rk_i;
+    a.steps[i] = steps;
+    a.cur_seg[i] = cur;
+    a.nknots[i] = nk;
+    a.last_knot_t[i] = last_knot;
+    a.status[i] = status;
+    if (FSAL) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+    }
+}
+
+// CubicHermiteSpline::state_vector  trajectory.rs:766-797, CubicHermite::{new, eval, eval_derivative} :645-696
+__global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double *__restrict__ t,
+                                                      const double *__restrict__ pos, const double *__restrict__ vel,
+                                                      long long m, const double *__restrict__ at,
+                                                      double *__restrict__ op, double *__restrict__ ov,
+                                                      uint8_t *__restrict__ inside) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const double x = at[q];
+    long long lo = 0, hi = nk;
+    long long hit = -1;
+    while (lo < hi) {                                 // binary_search_by(|(t, _)| t.cmp(&at))
+        const long long mid = lo + (hi - lo) / 2;
+        const double tm = t[mid];
+        if (tm == x) { hit = mid; break; }
+        if (tm < x) lo = mid + 1; else hi = mid;
+    }
+    if (hit >= 0) {
+        for (int c = 0; c < 3; ++c) { op[q * 3 + c] = pos[hit * 3 + c]; if (ov) ov[q * 3 + c] = vel[hit * 3 + c]; }
+        inside[q] = 1;
+        return;
+    }
+    if (lo == 0 || lo >= nk) {                        // i.checked_sub(1)? / self.0.get(i + 1)?
+        for (int c = 0; c < 3; ++c) { op[q * 3 + c] = 0.0; if (ov) ov[q * 3 + c] = 0.0; }
+        inside[q] = 0;
+        return;
+    }
+    const long long i = lo - 1;
+    const double b0 = t[i], dt = t[i + 1] - b0;
+    const double dt_recip = 1.0 / dt;
+    const double dt_recip_2 = dt_recip * dt_recip;
+    const double dt_recip_3 = dt_recip * dt_recip_2;
+    const double s = x - b0;
+    for (int c = 0; c < 3; ++c) {
+        const double v0 = pos[i * 3 + c], v1 = pos[(i + 1) * 3 + c], d0 = vel[i * 3 + c], d1 = vel[(i + 1) * 3 + c];
+        const double dt_val = v1 - v0;
+        const double a2 = dt_val * dt_recip_2 * 3.0 - (d0 * 2.0 + d1) * dt_recip;
+        const double a3 = dt_val * dt_recip_3 * -2.0 + (d0 + d1) * dt_recip_2;
+        op[q * 3 + c] = (((a3 * s + a2) * s) + d0) * s + v0;
+        if (ov) ov[q * 3 + c] = ((a3 * s * 3.0 + a2 * 2.0) * s) + d0;
+    }
+    inside[q] = 1;
+}
+
+static int craft_launch(hipStream_t s, const CraftArgs &a) {
+    const dim3 grid((unsigned)((a.n_craft + 63) / 64)), block(64);
+#define EPH_CRAFT_CASE(S_, F_) hipLaunchKernelGGL((k_craft_propagate<S_, F_>), grid, block, 0, s, a)
+    const int S = a.rk.stages;
+    const bool F = a.rk.fsal != 0;
+    if (S == 6 && !F) EPH_CRAFT_CASE(6, false);
+    else if (S == 7 && F) EPH_CRAFT_CASE(7, true);
+    else if (S == 7 && !F) EPH_CRAFT_CASE(7, false);
+    else if (S == 9 && !F) EPH_CRAFT_CASE(9, false);
+    else if (S == 13 && !F) EPH_CRAFT_CASE(13, false);
+    else if (S == 16 && !F) EPH_CRAFT_CASE(16, false);
+    else return EPH_ERR_UNSUPPORTED;
+#undef EPH_CRAFT_CASE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("k_craft_propagate", e); return EPH_ERR_HIP; }
+    return EPH_OK;
+}
+
+}  // namespace eph
+
+using namespace eph;
+
+struct eph_ephemeris {
+    int device = 0;
+    int n_bodies = 0;
+    DevBuf<BodyEntry> bodies;
+    DevBuf<double> coeffs;
+    DevBuf<int> ncoef;
+    std::vector<BodyEntry> host_bodies;
+};
+
+struct eph_craft_batch {
+    const eph_ephemeris *eph = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    long long n = 0;
+    int max_knots = 0;
+    ErkCoeffs rk{};
+    eph_adaptive_params params{};
+    DevBuf<double> time, y, next_h, klast, last_knot, knot_t, knot_y;
+    DevBuf<unsigned> n_attempts, rk_i, steps;
+    DevBuf<int> cur_seg, status, nknots;
+    DevBuf<long long> seg_off;
+    DevBuf<SegmentDev> segs;
+    double kernel_ms = 0;
+    ~eph_craft_batch() {
+        if (stream) {
+            (void)hipSetDevice(device);
+            (void)hipStreamSynchronize(stream);
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+            (void)hipStreamDestroy(stream);
+        }
+    }
+};
+
+extern "C" {
+
+int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out) {
+    try {
+        if (!s || !mu || !out) return EPH_ERR_BAD_ARGUMENT;
+        int st = check_device();
+        if (st) return st;
+        std::unique_ptr<eph_ephemeris> e(new eph_ephemeris());
+        EPH_HIP(hipGetDevice(&e->device));
+        const int nb = (int)s->s.splines.size();
+        e->n_bodies = nb;
+        long long total = 0;
+        for (int b = 0; b < nb; ++b) {
+            const UniformSpline &u = s->s.splines[b];
+            BodyEntry be{u.start, u.interval, mu[b], (long long)u.polynomials.size(), total};
+            e->host_bodies.push_back(be);
+            total += be.npoly;
+        }
+        std::vector<double> co((size_t)std::max<long long>(total, 1) * kDiv * 3, 0.0);
+        std::vector<int> nc((size_t)std::max<long long>(total, 1), 0);
+        long long q = 0;
+        for (int b = 0; b < nb; ++b)
+            for (const Polynomial &p : s->s.splines[b].polynomials) {
+                nc[q] = p.ncoef;
+                std::memcpy(&co[q * kDiv * 3], &p.c[0][0], sizeof(double) * kDiv * 3);
+                ++q;
+            }
+        if ((st = e->bodies.alloc(std::max(nb, 1))) || (st = e->coeffs.alloc(co.size())) || (st = e->ncoef.alloc(nc.size())))
+            return st;
+        if (nb) EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * nb, hipMemcpyHostToDevice));
+        EPH_HIP(hipMemcpy(e->coeffs.p, co.data(), sizeof(double) * co.size(), hipMemcpyHostToDevice));
+        EPH_HIP(hipMemcpy(e->ncoef.p, nc.data(), sizeof(int) * nc.size(), hipMemcpyHostToDevice));
+        *out = e.release();
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+void eph_ephemeris_destroy(eph_ephemeris *e) { delete e; }
+
+int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const double *t0, const double *pos,
+                               const double *vel, const char *method, const eph_adaptive_params *params,
+                               const int64_t *burn_offset, const double *burn_start, const double *burn_end,
+                               const double *burn_acc, const int32_t *burn_ref, int32_t max_knots,
+                               eph_craft_batch **out) {
+    try {
+        if (!e || n_craft < 0 || !method || !params || !out || max_knots < 1 || (n_craft > 0 && (!t0 || !pos || !vel)))
+            return EPH_ERR_BAD_ARGUMENT;
+        int st = check_device();
+        if (st) return st;
+        std::unique_ptr<eph_craft_batch> b(new eph_craft_batch());
+        if (!find_erk(method, &b->rk) || !b->rk.has_embedded) return EPH_ERR_BAD_ARGUMENT;
+        b->eph = e;
+        b->n = n_craft;
+        b->max_knots = max_knots;
+        b->params = *params;
+        b->device = e->device;
+        EPH_HIP(hipSetDevice(b->device));
+        EPH_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        EPH_HIP(hipEventCreate(&b->ev0));
+        EPH_HIP(hipEventCreate(&b->ev1));
+        const long long n = n_craft;
+        const double EMIN = -1.7976931348623157e308, EMAX = 1.7976931348623157e308;   // Epoch::MIN / MAX
+        // Timeline::new per craft  spacecraft.rs:129-152
+        std::vector<long long> seg_off(n + 1, 0);
+        std::vector<SegmentDev> segs;
+        std::vector<int> cur(n, 0);
+        for (long long i = 0; i < n; ++i) {
+            seg_off[i] = (long long)segs.size();
+            const long long b0 = burn_offset ? burn_offset[i] : 0, b1 = burn_offset ? burn_offset[i + 1] : 0;
+            std::vector<long long> order;
+            for (long long q = b0; q < b1; ++q) order.push_back(q);
+            std::stable_sort(order.begin(), order.end(), [&](long long x, long long y) { return burn_start[x] < burn_start[y]; });
+            double cursor = EMIN;
+            for (long long q : order) {
+                if (burn_ref[q] >= e->n_bodies) return EPH_ERR_BAD_ARGUMENT;
+                if (burn_start[q] > cursor) segs.push_back(SegmentDev{cursor, burn_start[q], 0, 0, 0, 0, -1});
+                cursor = burn_end[q];
+                segs.push_back(SegmentDev{burn_start[q], burn_end[q], burn_acc[3 * q], burn_acc[3 * q + 1],
+                                          burn_acc[3 * q + 2], 1, burn_ref[q]});
+            }
+            if (cursor < EMAX) segs.push_back(SegmentDev{cursor, EMAX, 0, 0, 0, 0, -1});
+            // segment_idx_at(t0): partition_point(seg.end() <= time)
+            int idx = 0;
+            const long long ns = (long long)segs.size() - seg_off[i];
+            while (idx < ns && segs[seg_off[i] + idx].end <= t0[i]) ++idx;
+            cur[i] = idx;
+        }
+        seg_off[n] = (long long)segs.size();
+        const size_t nn = (size_t)std::max<long long>(n, 1);
+        if ((st = b->time.alloc(nn)) || (st = b->y.alloc(6 * nn)) || (st = b->next_h.alloc(nn)) ||
+            (st = b->klast.alloc(6 * nn)) || (st = b->last_knot.alloc(nn)) || (st = b->n_attempts.alloc(nn)) ||
+            (st = b->rk_i.alloc(nn)) || (st = b->steps.alloc(nn)) || (st = b->cur_seg.alloc(nn)) ||
+            (st = b->status.alloc(nn)) || (st = b->nknots.alloc(nn)) || (st = b->seg_off.alloc(n + 1)) ||
+            (st = b->segs.alloc(std::max<size_t>(segs.size(), 1))) || (st = b->knot_t.alloc(nn * max_knots)) ||
+            (st = b->knot_y.alloc(6 * nn * max_knots)))
+            return st;
+        if (n > 0) {
+            std::vector<double> ysoa(6 * n), hs(n, params->h_init);
+            for (long long i = 0; i < n; ++i)
+                for (int d = 0; d < 3; ++d) { ysoa[d * n + i] = pos[3 * i + d]; ysoa[(3 + d) * n + i] = vel[3 * i + d]; }
+            std::vector<int> ones(n, 1), zeros(n, 0);
+            EPH_HIP(hipMemcpy(b->time.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->last_knot.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->y.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->klast.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->next_h.p, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemset(b->n_attempts.p, 0, sizeof(unsigned) * n));
+            EPH_HIP(hipMemset(b->rk_i.p, 0, sizeof(unsigned) * n));
+            EPH_HIP(hipMemset(b->steps.p, 0, sizeof(unsigned) * n));
+            EPH_HIP(hipMemcpy(b->cur_seg.p, cur.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->status.p, zeros.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->nknots.p, ones.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->seg_off.p, seg_off.data(), sizeof(long long) * (n + 1), hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->segs.p, segs.data(), sizeof(SegmentDev) * segs.size(), hipMemcpyHostToDevice));
+            // knot 0 = the initial state (CubicHermiteSplineSolout::new_solution)
+            EPH_HIP(hipMemcpy(b->knot_t.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->knot_y.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+        }
+        *out = b.release();
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+
+int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) {
+    if (!b) return EPH_ERR_BAD_ARGUMENT;
+    if (b->n == 0) return EPH_OK;
+    EPH_HIP(hipSetDevice(b->device));
+    CraftArgs a{};
+    a.n_craft = b->n;
+    a.n_bodies = b->eph->n_bodies;
+    a.bodies = b->eph->bodies.p; a.coeffs = b->eph->coeffs.p; a.ncoef = b->eph->ncoef.p;
+    a.time = b->time.p; a.y = b->y.p; a.next_h = b->next_h.p; a.klast = b->klast.p; a.last_knot_t = b->last_knot.p;
+    a.n_attempts = b->n_attempts.p; a.rk_i = b->rk_i.p; a.steps = b->steps.p;
+    a.cur_seg = b->cur_seg.p; a.status = b->status.p; a.nknots = b->nknots.p;
+    a.seg_off = b->seg_off.p; a.segs = b->segs.p;
+    a.knot_t = b->knot_t.p; a.knot_y = b->knot_y.p; a.max_knots = b->max_knots;
+    a.rk = b->rk;
+    a.h_init = b->params.h_init; a.h_max = b->params.h_max; a.tol_pos = b->params.tol_position;
+    a.tol_vel = b->params.tol_velocity; a.fac_min = b->params.fac_min; a.fac_max = b->params.fac_max;
+    a.fac = b->params.fac; a.n_max = b->params.n_max;
+    a.t_end = t_end;
+    EPH_HIP(hipEventRecord(b->ev0, b->stream));
+    int st = craft_launch(b->stream, a);
+    if (st) return st;
+    EPH_HIP(hipEventRecord(b->ev1, b->stream));
+    EPH_HIP(hipEventSynchronize(b->ev1));
+    float ms = 0;
+    EPH_HIP(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->kernel_ms += ms;
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_status(eph_craft_batch *b, int32_t *status, int32_t *nknots, uint32_t *attempts, uint32_t *steps) {
+    if (!b) return EPH_ERR_BAD_ARGUMENT;
+    EPH_HIP(hipSetDevice(b->device));
+    const size_t n = (size_t)b->n;
+    if (n == 0) return EPH_OK;
+    if (status) EPH_HIP(hipMemcpy(status, b->status.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (nknots) EPH_HIP(hipMemcpy(nknots, b->nknots.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (attempts) EPH_HIP(hipMemcpy(attempts, b->n_attempts.p, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    if (steps) EPH_HIP(hipMemcpy(steps, b->steps.p, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_state(eph_craft_batch *b, double *t, double *pos, double *vel, double *next_h) {
+    if (!b) return EPH_ERR_BAD_ARGUMENT;
+    EPH_HIP(hipSetDevice(b->device));
+    const long long n = b->n;
+    if (n == 0) return EPH_OK;
+    if (t) EPH_HIP(hipMemcpy(t, b->time.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (next_h) EPH_HIP(hipMemcpy(next_h, b->next_h.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (pos || vel) {
+        std::vector<double> y(6 * n);
+        EPH_HIP(hipMemcpy(y.data(), b->y.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+        for (long long i = 0; i < n; ++i)
+            for (int d = 0; d < 3; ++d) {
+                if (pos) pos[3 * i + d] = y[d * n + i];
+                if (vel) vel[3 * i + d] = y[(3 + d) * n + i];
+            }
+    }
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, double *pos, double *vel) {
+    if (!b || craft < 0 || craft >= b->n) return EPH_ERR_BAD_ARGUMENT;
+    EPH_HIP(hipSetDevice(b->device));
+    int nk = 0;
+    EPH_HIP(hipMemcpy(&nk, b->nknots.p + craft, sizeof(int), hipMemcpyDeviceToHost));
+    const long long n = b->n;
+    // strided gather: knot k of craft i sits at [k*n + i]
+    if (t) EPH_HIP(hipMemcpy2D(t, sizeof(double), b->knot_t.p + craft, sizeof(double) * n, sizeof(double), nk,
+                               hipMemcpyDeviceToHost));
+    if (pos || vel) {
+        std::vector<double> y((size_t)nk * 6);
+        EPH_HIP(hipMemcpy2D(y.data(), sizeof(double), b->knot_y.p + craft, sizeof(double) * n, sizeof(double),
+                            (size_t)nk * 6, hipMemcpyDeviceToHost));
+        for (int k = 0; k < nk; ++k)
+            for (int d = 0; d < 3; ++d) {
+                if (pos) pos[3 * k + d] = y[(size_t)k * 6 + d];
+                if (vel) vel[3 * k + d] = y[(size_t)k * 6 + 3 + d];
+            }
+    }
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_kernel_time(eph_craft_batch *b, double *total_ms) {
+    if (!b || !total_ms) return EPH_ERR_BAD_ARGUMENT;
+    *total_ms = b->kernel_ms;
+    return EPH_OK;
+}
+void eph_craft_batch_destroy(eph_craft_batch *b) { delete b; }
+
+int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos, const double *vel, int64_t m,
+                         const double *at, double *op, double *ov, uint8_t *inside) {
+    try {
+        if (nknots < 0 || m < 0 || (m > 0 && (!at || !op || !inside)) || (nknots > 0 && (!t || !pos || !vel)))
+            return EPH_ERR_BAD_ARGUMENT;
+        int st = check_device();
+        if (st) return st;
+        if (m == 0) return EPH_OK;
+        const size_t nk = (size_t)std::max<int64_t>(nknots, 1);
+        DevBuf<double> dt, dp, dv, dat, dop, dov;
+        DevBuf<uint8_t> din;
+        if ((st = dt.alloc(nk)) || (st = dp.alloc(3 * nk)) || (st = dv.alloc(3 * nk)) || (st = dat.alloc(m)) ||
+            (st = dop.alloc(3 * (size_t)m)) || (st = dov.alloc(3 * (size_t)m)) || (st = din.alloc(m)))
+            return st;
+        if (nknots) {
+            EPH_HIP(hipMemcpy(dt.p, t, sizeof(double) * nknots, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(dp.p, pos, sizeof(double) * 3 * nknots, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(dv.p, vel, sizeof(double) * 3 * nknots, hipMemcpyHostToDevice));
+        }
+        EPH_HIP(hipMemcpy(dat.p, at, sizeof(double) * m, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_hermite_eval, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, (long long)nknots,
+                           dt.p, dp.p, dv.p, (long long)m, dat.p, dop.p, ov ? dov.p : nullptr, din.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error("k_hermite_eval", e); return EPH_ERR_HIP; }
+        EPH_HIP(hipMemcpy(op, dop.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
+        if (ov) EPH_HIP(hipMemcpy(ov, dov.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
+        EPH_HIP(hipMemcpy(inside, din.p, m, hipMemcpyDeviceToHost));
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+
+int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out) {
+    try {
+        if (n < 0 || (n > 0 && (!x || !out))) return EPH_ERR_BAD_ARGUMENT;
+        int st = check_device();
+        if (st) return st;
+        if (n == 0) return EPH_OK;
+        DevBuf<double> dx, dout;
+        if ((st = dx.alloc(n)) || (st = dout.alloc(n))) return st;
+        EPH_HIP(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_debug_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (long long)n, dx.p, y, dout.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error("k_debug_pow", e); return EPH_ERR_HIP; }
+        EPH_HIP(hipMemcpy(out, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return EPH_OK;
+    } catch (...) { return EPH_ERR_HIP; }
+}
+
+}  // extern "C"

@@ -49,6 +49,12 @@ struct Elm2Coeffs {
     double wa[kMaxOrder], wb[kMaxOrder], cw[kMaxOrder];
     double inv_beta_d = 0, inv_cowell_d = 0;
 };
+struct ErkCoeffs {             // ERK + embedded pair; A[s][j] for j < s   (integration/src/runge_kutta/explicit.rs:14-38)
+    int stages = 0, order = 0, order_embedded = 0;
+    int fsal = 0, has_embedded = 0;
+    double A[16][16], B[16], C[16], E[16];
+};
+bool find_erk(const char *name, ErkCoeffs *out);
 bool find_srkn(const char *name, SrknCoeffs *out);
 bool find_elm2(const char *name, Elm2Coeffs *out);
 

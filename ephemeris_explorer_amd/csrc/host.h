@@ -178,6 +178,12 @@ private:
     DevBuf<uint64_t> d_offset_;
 };
 
+}  // namespace eph
+struct eph_solution {   // the C ABI's opaque Vec<UniformSpline<DVec3>>
+    eph::Solution s;
+};
+namespace eph {
+
 // device evaluation of one UniformSpline at many epochs
 int spline_eval_device(const UniformSpline &s, int64_t m, const double *at, double *pos, double *vel, uint8_t *inside);
 int least_squares_fit_device(int degree, int backward, int64_t nwin, const double *samples, double *coeffs,

@@ -147,6 +147,56 @@ void eph_solution_destroy(eph_solution *s);
 int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, const double *samples,
                               double *coeffs, int32_t *ncoef);
 
+/* ---- massless bodies: a batch of independent spacecraft propagated against a fixed ephemeris ------------------
+ * ephemeris::SpacecraftPropagator<[StateVector<DVec3>;1], ReferenceFrame, Bodies, AdaptiveRungeKutta<ERK pair>,
+ * CubicHermiteSplineSolout> (ephemeris/src/propagators/spacecraft.rs:224-695) with the app's acceleration model
+ * and burn frames (ephemeris_explorer/src/dynamics/spacecraft.rs:70-74,218-293,609-641), one device thread per
+ * craft. Bodies are visited in index order. */
+typedef struct eph_ephemeris eph_ephemeris;   /* device-resident table of the massive bodies' UniformSplines */
+typedef struct eph_craft_batch eph_craft_batch;
+#define EPH_KNOTS_FULL 6                       /* per-craft status: the knot slab is full (library limit, not a StepError) */
+
+/* uploads the splines of `s` (Vec<UniformSpline>) with the bodies' mu; `s` may be destroyed afterwards */
+int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out);
+void eph_ephemeris_destroy(eph_ephemeris *e);
+
+/* AdaptiveMethodParams (integration/src/lib.rs:171-274); the app's values: h_init 60, h_max f64::MAX, tol 1e-3,
+ * fac_min 1/5, fac_max 5, fac 9/10, n_max 1e6 (ephemeris_explorer/src/load/mod.rs:472-486) */
+typedef struct eph_adaptive_params {
+    double h_init, h_max, tol_position, tol_velocity, fac_min, fac_max, fac;
+    uint32_t n_max;
+} eph_adaptive_params;
+
+/* n_craft spacecraft: t0[i], pos_xyz[3i..], vel_xyz[3i..]; method = an embedded ERK pair name ("Verner87",
+ * "DormandPrince54", "DormandPrince87", "CashKarp45", "Fehlberg45", "Tsitouras75", "Verner98").
+ * Timelines (Timeline::new, spacecraft.rs:129-152) in CSR form: craft i owns burns burn_offset[i] ..
+ * burn_offset[i+1]-1: [burn_start, burn_end), burn_acc_xyz in the burn frame, burn_ref = body index whose TNB frame
+ * the burn is given in, or -1 for the inertial frame. burn_offset may be NULL (no burns). max_knots = slab depth
+ * per craft (CubicHermiteSpline points, including the initial one). */
+int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const double *t0, const double *pos_xyz,
+                               const double *vel_xyz, const char *method, const eph_adaptive_params *params,
+                               const int64_t *burn_offset, const double *burn_start, const double *burn_end,
+                               const double *burn_acc_xyz, const int32_t *burn_ref, int32_t max_knots,
+                               eph_craft_batch **out);
+/* IncrementalPropagator::step_to for every craft: step() until solution.end() >= t_end (spacecraft.rs:598-615,
+ * 691-693) or an error; per-craft outcomes via eph_craft_batch_status. Returns EPH_OK if the sweep ran. */
+int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end);
+/* per craft: status (eph_status or EPH_KNOTS_FULL), knots in the slab, attempts of the current integrator (n),
+ * accepted steps since creation. Any pointer may be NULL. */
+int32_t eph_craft_batch_status(eph_craft_batch *b, int32_t *status, int32_t *nknots, uint32_t *attempts,
+                               uint32_t *steps);
+/* current problem state of every craft: time, position, velocity, next step size */
+int32_t eph_craft_batch_state(eph_craft_batch *b, double *t, double *pos_xyz, double *vel_xyz, double *next_h);
+/* the CubicHermiteSpline of one craft: nknots[craft] x (t, pos, vel) */
+int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, double *pos_xyz, double *vel_xyz);
+int32_t eph_craft_batch_kernel_time(eph_craft_batch *b, double *total_ms);
+void eph_craft_batch_destroy(eph_craft_batch *b);
+/* CubicHermiteSpline::state_vector (ephemeris/src/trajectory.rs:766-797) at m epochs, on the device */
+int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos_xyz, const double *vel_xyz, int64_t m,
+                         const double *at, double *out_pos_xyz, double *out_vel_xyz, uint8_t *inside);
+
+/* Test hook: the step-size controller's correctly rounded pow(x[i], y) on the device */
+int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out);
 /* Test hook: 1/(x*sqrt(x)) for n inputs computed by the kernel's in-range fast sequences (NaN where the range
  * guard would send the tile to the IEEE form) and by the compiler's IEEE sqrt/divide expansions. */
 int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee);

@@ -852,3 +852,501 @@ orc_solution *orc_prop_take_solution(orc_prop *pr) {
     pr->solution = prop_new_solution(pr);
     return old;
 }
+
+/* ================================================================================================== */
+/* Massless path                                                                                      */
+/* ================================================================================================== */
+#define ERK_MAX_STAGES 16
+#define ERK_MAX_DIM 6
+
+/* ODE right-hand side over a flat state of `dim` doubles: returns 0 or ORC_EVAL_FAILED */
+typedef int (*ode_fn)(void *ctx, double t, const double *y, double *dy);
+
+/* ERK<C, [State; STAGES]> + EERK  integration/src/runge_kutta/explicit.rs:40-141 */
+typedef struct {
+    int stages, order, order_embedded, fsal, dim;
+    double A[ERK_MAX_STAGES][ERK_MAX_STAGES], B[ERK_MAX_STAGES], C[ERK_MAX_STAGES], E[ERK_MAX_STAGES];
+    uint32_t i;
+    double k[ERK_MAX_STAGES][ERK_MAX_DIM];
+} erk_t;
+
+static int erk_init(erk_t *r, const char *name, int dim, const double *state) {
+    const EPH_ERK_TABLE *t = find_erk(name);
+    if (!t || t->stages > ERK_MAX_STAGES || dim > ERK_MAX_DIM) return ORC_BAD_ARGUMENT;
+    memset(r, 0, sizeof(*r));
+    r->stages = t->stages; r->order = t->order; r->order_embedded = t->order_embedded; r->fsal = t->fsal; r->dim = dim;
+    int idx = 0;
+    for (int s = 0; s < t->stages; ++s) {
+        for (int j = 0; j < s; ++j) r->A[s][j] = ratio_f64(t->A[idx++]);
+        r->B[s] = ratio_f64(t->B[s]);
+        r->C[s] = ratio_f64(t->C[s]);
+        r->E[s] = t->E ? ratio_f64(t->E[s]) : 0.0;
+    }
+    r->i = 0;
+    for (int s = 0; s < t->stages; ++s)                       /* from_problem: k = [state.clone(); STAGES] :65-69 */
+        for (int d = 0; d < dim; ++d) r->k[s][d] = state[d];
+    return ORC_OK;
+}
+/* ERK::advance  explicit.rs:72-106 */
+static int erk_advance(erk_t *r, double h, double *time, double *state, ode_fn f, void *ctx, uint64_t *evals) {
+    double yi[ERK_MAX_DIM];
+    const int S = r->stages, D = r->dim;
+    for (int s = 0; s < S; ++s) {
+        if (r->fsal && s == 0 && r->i > 0) {                  /* self.k.swap(s, STAGES - 1); continue */
+            for (int d = 0; d < D; ++d) { double t = r->k[0][d]; r->k[0][d] = r->k[S - 1][d]; r->k[S - 1][d] = t; }
+            continue;
+        }
+        const double ti = *time + h * r->C[s];
+        for (int d = 0; d < D; ++d) yi[d] = state[d];
+        for (int j = 0; j < s; ++j) {
+            const double ha = h * r->A[s][j];
+            for (int d = 0; d < D; ++d) yi[d] = yi[d] + r->k[j][d] * ha;
+        }
+        for (int d = 0; d < D; ++d) r->k[s][d] = 0.0;         /* self.k[s].zero() */
+        if (evals) (*evals)++;
+        int st = f(ctx, ti, yi, r->k[s]);
+        if (st) return st;
+    }
+    for (int i = 0; i < S; ++i) {
+        const double hb = h * r->B[i];
+        for (int d = 0; d < D; ++d) state[d] = state[d] + r->k[i][d] * hb;
+    }
+    *time = *time + h;
+    r->i += 1;
+    return ORC_OK;
+}
+/* RKEmbedded::error  explicit.rs:123-132 */
+static void erk_error(const erk_t *r, double h, double *err) {
+    for (int d = 0; d < r->dim; ++d) err[d] = 0.0;
+    for (int i = 0; i < r->stages; ++i) {
+        const double he = h * r->E[i];
+        for (int d = 0; d < r->dim; ++d) err[d] = err[d] + r->k[i][d] * he;
+    }
+}
+
+/* Tolerance models */
+typedef double (*tol_fn)(void *ctx, const double *state, const double *err);
+
+/* AdaptiveRungeKuttaIntegrator + IController + PreviousStep  runge_kutta/mod.rs:188-285,396-440 */
+typedef struct {
+    erk_t rk;                /* frk.rk */
+    double frk_h, next_h;
+    double error[ERK_MAX_DIM];
+    /* PreviousStep */
+    double prev_t, prev_y[ERK_MAX_DIM], prev_klast[ERK_MAX_DIM];
+    uint32_t prev_i;
+    double fac_min, fac_max, fac, h_max;
+    uint32_t n, n_max;
+} adaptive_t;
+
+static int adaptive_init(adaptive_t *a, const char *method, int dim, const double *state, double t, double h_init,
+                         double h_max, double fac_min, double fac_max, double fac, uint32_t n_max) {
+    int st = erk_init(&a->rk, method, dim, state);           /* FixedRungeKutta::new(h_init).init(problem) */
+    if (st) return st;
+    a->frk_h = h_init; a->next_h = h_init;
+    for (int d = 0; d < dim; ++d) { a->error[d] = state[d]; a->prev_y[d] = state[d]; a->prev_klast[d] = state[d]; }
+    a->prev_t = t; a->prev_i = 0;
+    a->fac_min = fac_min; a->fac_max = fac_max; a->fac = fac; a->h_max = h_max;
+    a->n = 0; a->n_max = n_max;
+    return ORC_OK;
+}
+
+/* ---- powf in the step-size controller -------------------------------------------------------------
+ * `err.pow(-k.inv())` is f64::powf, i.e. the platform libm's pow: the one operation on the hot path whose bits
+ * depend on the platform (glibc picks an FMA or non-FMA variant at run time and is documented as < 0.52 ULP, not
+ * correctly rounded). The oracle pins it to the correctly rounded value, computed in double-double arithmetic
+ * (log by the atanh series, exp by Taylor series, ~100 bits); the product evaluates the identical sequence on the
+ * device. tests/test_oracle.py checks it against this host's libm pow (equal on every sampled input) and that the
+ * reference scenarios are unchanged when libm's pow is used instead (orc_set_pow_mode). */
+typedef struct { double hi, lo; } dd_t;
+static inline dd_t dd_two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return (dd_t){s, (a - (s - bb)) + (b - bb)};
+}
+static inline dd_t dd_quick(double a, double b) { const double s = a + b; return (dd_t){s, b - (s - a)}; }
+static inline dd_t dd_two_prod(double a, double b) { const double p = a * b; return (dd_t){p, fma(a, b, -p)}; }
+static inline dd_t dd_add(dd_t a, dd_t b) {
+    dd_t s = dd_two_sum(a.hi, b.hi);
+    const dd_t t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_quick(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_quick(s.hi, s.lo);
+}
+static inline dd_t dd_mul(dd_t a, dd_t b) {
+    dd_t p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick(p.hi, p.lo);
+}
+static inline dd_t dd_mul_d(dd_t a, double b) {
+    dd_t p = dd_two_prod(a.hi, b);
+    p.lo += a.lo * b;
+    return dd_quick(p.hi, p.lo);
+}
+static inline dd_t dd_div(dd_t a, dd_t b) {
+    const double q1 = a.hi / b.hi;
+    dd_t r = dd_add(a, (dd_t){-dd_mul_d(b, q1).hi, -dd_mul_d(b, q1).lo});
+    const double q2 = r.hi / b.hi;
+    r = dd_add(r, (dd_t){-dd_mul_d(b, q2).hi, -dd_mul_d(b, q2).lo});
+    const double q3 = r.hi / b.hi;
+    dd_t q = dd_quick(q1, q2);
+    return dd_add(q, (dd_t){q3, 0.0});
+}
+static const dd_t DD_LN2 = {0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56};
+
+static double cr_pow(double x, double y) {
+    if (isnan(x) || isnan(y)) return NAN;
+    if (x == 0.0) return y < 0.0 ? INFINITY : 0.0;
+    if (isinf(x)) return y < 0.0 ? 0.0 : INFINITY;
+    if (x < 0.0) return NAN;
+    /* log(x) = e*ln2 + 2*atanh(s), s = (m-1)/(m+1), m in [sqrt(1/2), sqrt(2)) */
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0x1.6a09e667f3bcdp-1) { m *= 2.0; e -= 1; }
+    const dd_t s = dd_div((dd_t){m - 1.0, 0.0}, dd_two_sum(m, 1.0));
+    const dd_t s2 = dd_mul(s, s);
+    dd_t sum = dd_div((dd_t){1.0, 0.0}, (dd_t){61.0, 0.0});
+    for (int k = 29; k >= 0; --k) sum = dd_add(dd_mul(sum, s2), dd_div((dd_t){1.0, 0.0}, (dd_t){(double)(2 * k + 1), 0.0}));
+    dd_t lg = dd_mul(dd_mul_d(s, 2.0), sum);
+    lg = dd_add(dd_mul_d(DD_LN2, (double)e), lg);
+    /* z = y*log(x); exp(z) = 2^k * exp(r), r = z - k*ln2 */
+    const dd_t z = dd_mul_d(lg, y);
+    if (z.hi > 709.0) return INFINITY;
+    if (z.hi < -745.0) return 0.0;
+    const double kf = nearbyint(z.hi / DD_LN2.hi);
+    const dd_t r = dd_add(z, (dd_t){-dd_mul_d(DD_LN2, kf).hi, -dd_mul_d(DD_LN2, kf).lo});
+    dd_t term = {1.0, 0.0}, ex = {1.0, 0.0};
+    for (int n = 1; n <= 30; ++n) {
+        term = dd_div(dd_mul(term, r), (dd_t){(double)n, 0.0});
+        ex = dd_add(ex, term);
+    }
+    return ldexp(ex.hi + ex.lo, (int)kf);
+}
+static int g_pow_mode = 0;   /* 0: correctly rounded (the pinned definition), 1: this host's libm pow */
+void orc_set_pow_mode(int mode) { g_pow_mode = mode; }
+double orc_cr_pow(double x, double y) { return cr_pow(x, y); }
+static inline double controller_pow(double x, double y) { return g_pow_mode ? pow(x, y) : cr_pow(x, y); }
+
+/* IController::step  mod.rs:225-243 ; num_traits::clamp / clamp_max */
+static int controller_step(const adaptive_t *a, double err, double *h, int order) {
+    const double k = (double)order;
+    const double m = a->fac * controller_pow(err, -(1.0 / k));   /* err.pow(-k.inv()): f64::powf */
+    const double c = m < a->fac_min ? a->fac_min : (m > a->fac_max ? a->fac_max : m);
+    const double nh = *h * c;
+    *h = nh > a->h_max ? a->h_max : nh;
+    return err <= 1.0;
+}
+/* AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439 */
+static int adaptive_advance(adaptive_t *a, double *time, double bound, double *state, ode_fn f, void *fctx,
+                            tol_fn tol, void *tctx, uint64_t *evals) {
+    const int D = a->rk.dim, S = a->rk.stages;
+    /* prev.store: t, y, rk.undo_step(rk) (i and, if FSAL, the last stage) */
+    a->prev_t = *time;
+    for (int d = 0; d < D; ++d) a->prev_y[d] = state[d];
+    a->prev_i = a->rk.i;
+    if (a->rk.fsal) for (int d = 0; d < D; ++d) a->prev_klast[d] = a->rk.k[S - 1][d];
+    const int lower = a->rk.order < a->rk.order_embedded ? a->rk.order : a->rk.order_embedded;
+    for (;;) {
+        if (a->n > a->n_max) return ORC_MAX_ITERATIONS;
+        if (*time + a->next_h > bound) a->next_h = bound - *time;
+        a->frk_h = a->next_h;
+        /* FixedRungeKuttaIntegrator::advance  mod.rs:112-125 */
+        if (*time >= bound) return ORC_BOUND_REACHED;
+        if (*time + a->frk_h == *time) return ORC_STEP_SIZE_UNDERFLOW;
+        int st = erk_advance(&a->rk, a->frk_h, time, state, f, fctx, evals);
+        if (st) return st;
+        a->n += 1;
+        erk_error(&a->rk, a->frk_h, a->error);
+        const double err = tol(tctx, state, a->error);
+        if (controller_step(a, err, &a->next_h, lower)) break;
+        /* prev.restore */
+        *time = a->prev_t;
+        for (int d = 0; d < D; ++d) state[d] = a->prev_y[d];
+        a->rk.i = a->prev_i;
+        if (a->rk.fsal) for (int d = 0; d < D; ++d) a->rk.k[S - 1][d] = a->prev_klast[d];
+    }
+    return ORC_OK;
+}
+
+/* ---- doc-test known answers: y' = -y  (integration/src/lib.rs:32-93) ---------------------------- */
+static int decay_rhs(void *ctx, double t, const double *y, double *dy) { (void)ctx; (void)t; dy[0] = -y[0]; return 0; }
+typedef struct { double atol, rtol; } scalar_tol_t;
+static double scalar_tol(void *ctx, const double *state, const double *err) {
+    const scalar_tol_t *t = ctx;
+    return fabs(err[0]) / (t->atol + t->rtol * fabs(state[0]));
+}
+double orc_doc_test_decay(const char *method, int adaptive, double h, double h_max, double atol, double rtol,
+                          double t_end, uint32_t *steps) {
+    double time = 0.0, y[1] = {1.0};
+    uint32_t nsteps = 0;
+    if (!adaptive) {
+        erk_t rk;
+        if (erk_init(&rk, method, 1, y)) return NAN;
+        for (;;) {                                           /* Integrator::advance_to_bound lib.rs:362-376 */
+            if (time >= t_end) break;                        /* BoundReached */
+            if (time + h == time) break;
+            if (erk_advance(&rk, h, &time, y, decay_rhs, NULL, NULL)) return NAN;
+            nsteps++;
+            if (time >= t_end) break;
+        }
+    } else {
+        adaptive_t a;
+        /* AdaptiveMethodParams::new(tol, 10_000).h_init(..).h_max(..): fac_min 1/5, fac_max 5, fac 9/10 lib.rs:184-186,230-246 */
+        if (adaptive_init(&a, method, 1, y, 0.0, h, h_max, 1.0 / 5.0, 5.0 / 1.0, 9.0 / 10.0, 10000)) return NAN;
+        scalar_tol_t tol = {atol, rtol};
+        for (;;) {
+            int st = adaptive_advance(&a, &time, t_end, y, decay_rhs, NULL, scalar_tol, &tol, NULL);
+            if (st) break;
+            nsteps++;
+            if (time >= t_end) break;
+        }
+    }
+    if (steps) *steps = nsteps;
+    return y[0];
+}
+
+/* ---- glam::DVec3 pieces the burn frame uses (crate glam 0.30.10, Cargo.lock:2890-2892; source not on disk) */
+static v3 v3_sub(v3 a, v3 b) { return (v3){a.x - b.x, a.y - b.y, a.z - b.z}; }
+static v3 v3_add(v3 a, v3 b) { return (v3){a.x + b.x, a.y + b.y, a.z + b.z}; }
+static v3 v3_scale(v3 a, double s) { return (v3){a.x * s, a.y * s, a.z * s}; }
+static double v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 v3_cross(v3 a, v3 b) {
+    return (v3){a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+static double v3_length_recip(v3 a) { return 1.0 / sqrt(v3_dot(a, a)); }   /* self.length().recip() */
+static int v3_try_normalize(v3 a, v3 *out) {                                /* rcp.is_finite() && rcp > 0.0 */
+    const double rcp = v3_length_recip(a);
+    if (isfinite(rcp) && rcp > 0.0) { *out = v3_scale(a, rcp); return 1; }
+    return 0;
+}
+
+/* ---- Timeline  spacecraft.rs:58-222 ------------------------------------------------------------- */
+typedef struct { double start, end; int is_burn; v3 acc; int ref; } segment_t;
+
+struct orc_craft {
+    const orc_solution *eph;
+    double *mu;
+    int nseg, current_segment;
+    segment_t *seg;
+    /* problem */
+    double time, bound, state[6];
+    /* method parameters (kept: reset_integrator re-creates the integrator from them, spacecraft.rs:479-485) */
+    char method[32];
+    double h_init, h_max, fac_min, fac_max, fac, tol_pos, tol_vel;
+    uint32_t n_max;
+    adaptive_t integ;
+    uint64_t evals;
+    uint32_t steps;
+    /* solution: CubicHermiteSpline */
+    int64_t nk, capk;
+    double *kt, *kp, *kv;
+};
+
+static int timeline_idx_at(const orc_craft *c, double time) {   /* partition_point(|seg| seg.end() <= time) :157-160 */
+    int lo = 0, hi = c->nseg;
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        if (c->seg[mid].end <= time) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* GravitationalBody::acceleration_at  dynamics/spacecraft.rs:70-74 with `particular` acceleration_at::<false>
+ * (source absent, same restated formula as acceleration_paired: dir = body - at). */
+static int craft_rhs(void *ctx, double t, const double *y, double *dy) {
+    orc_craft *c = ctx;
+    const v3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
+    /* Bodies::acceleration  dynamics/spacecraft.rs:222-228 */
+    v3 acc = {0.0, 0.0, 0.0};
+    for (int b = 0; b < c->eph->n; ++b) {
+        double tau;
+        const poly_t *p = spline_get_polynomial(&c->eph->s[b], t, &tau);
+        if (!p) return ORC_EVAL_FAILED;
+        const v3 bp = poly_eval(p, tau);
+        const v3 d = v3_sub(bp, pos);
+        const double n2 = v3_dot(d, d);
+        const double inv = 1.0 / (n2 * sqrt(n2));
+        acc = v3_add(acc, v3_scale(d, c->mu[b] * inv));
+    }
+    /* manoeuvre_acceleration: Segment::acceleration  spacecraft.rs:102-116,272-281 */
+    v3 man = {0.0, 0.0, 0.0};
+    const segment_t *sg = &c->seg[c->current_segment];
+    if (sg->is_burn) {
+        if (sg->ref >= 0) {
+            /* ReferenceFrame::Relative: TNB::try_new(sv - reference.state_vector(t))  dynamics/spacecraft.rs:281-293 */
+            double tau;
+            const spline_t *rs = &c->eph->s[sg->ref];
+            const poly_t *p = spline_get_polynomial(rs, t, &tau);
+            if (!p) return ORC_EVAL_FAILED;
+            v3 rp, rd;
+            poly_eval_and_deriv(p, tau, &rp, &rd);
+            const v3 rv = {rd.x / rs->interval, rd.y / rs->interval, rd.z / rs->interval};
+            const v3 rel_p = v3_sub(pos, rp), rel_v = v3_sub(vel, rv);
+            v3 x, yv, z;
+            if (!v3_try_normalize(rel_v, &x)) return ORC_EVAL_FAILED;             /* TNB::try_new :246-252 */
+            if (!v3_try_normalize(v3_cross(rel_p, rel_v), &yv)) return ORC_EVAL_FAILED;
+            const v3 xy = v3_cross(x, yv);
+            z = v3_scale(xy, v3_length_recip(xy));                                /* normalize() */
+            /* DMat3::from_cols(x, z, y).mul_vec3(a) = x*a.x + z*a.y + y*a.z */
+            v3 r = v3_scale(x, sg->acc.x);
+            r = v3_add(r, v3_scale(z, sg->acc.y));
+            r = v3_add(r, v3_scale(yv, sg->acc.z));
+            man = r;
+        } else {                                                                  /* TNB::IDENTITY.mul_vec3 */
+            v3 r = v3_scale((v3){1.0, 0.0, 0.0}, sg->acc.x);
+            r = v3_add(r, v3_scale((v3){0.0, 1.0, 0.0}, sg->acc.y));
+            r = v3_add(r, v3_scale((v3){0.0, 0.0, 1.0}, sg->acc.z));
+            man = r;
+        }
+    }
+    /* dy.velocity = context + manoeuvre ; dy.position = y.velocity   spacecraft.rs:303-306 */
+    const v3 a = v3_add(acc, man);
+    dy[0] = vel.x; dy[1] = vel.y; dy[2] = vel.z;
+    dy[3] = a.x; dy[4] = a.y; dy[5] = a.z;
+    return ORC_OK;
+}
+/* AbsTol::err_over_tol  dynamics/spacecraft.rs:615-624: max(|e_r / tol_r|.max_element(), |e_v / tol_v|.max_element()) */
+static double abs_tol(void *ctx, const double *state, const double *e) {
+    (void)state;
+    const orc_craft *c = ctx;
+    const double px = fabs(e[0] / c->tol_pos), py = fabs(e[1] / c->tol_pos), pz = fabs(e[2] / c->tol_pos);
+    const double vx = fabs(e[3] / c->tol_vel), vy = fabs(e[4] / c->tol_vel), vz = fabs(e[5] / c->tol_vel);
+    const double pm = fmax(px, fmax(py, pz)), vm = fmax(vx, fmax(vy, vz));   /* max_element: x.max(y.max(z)) */
+    return fmax(pm, vm);
+}
+static void craft_push_knot(orc_craft *c) {                     /* CubicHermiteSpline::push  trajectory.rs:806-809 */
+    if (c->nk == c->capk) {
+        c->capk = c->capk ? c->capk * 2 : 256;
+        c->kt = realloc(c->kt, sizeof(double) * (size_t)c->capk);
+        c->kp = realloc(c->kp, sizeof(double) * 3 * (size_t)c->capk);
+        c->kv = realloc(c->kv, sizeof(double) * 3 * (size_t)c->capk);
+    }
+    c->kt[c->nk] = c->time;
+    memcpy(c->kp + 3 * c->nk, c->state, sizeof(double) * 3);
+    memcpy(c->kv + 3 * c->nk, c->state + 3, sizeof(double) * 3);
+    c->nk++;
+}
+static int craft_reset_integrator(orc_craft *c) {               /* spacecraft.rs:479-485 */
+    return adaptive_init(&c->integ, c->method, 6, c->state, c->time, c->h_init, c->h_max, c->fac_min, c->fac_max,
+                         c->fac, c->n_max);
+}
+
+orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, const double *pos, const double *vel,
+                         const char *method, double h_init, double h_max, double tol_pos, double tol_vel,
+                         double fac_min, double fac_max, double fac, uint32_t n_max, int nburns,
+                         const double *burn_start, const double *burn_end, const double *burn_acc,
+                         const int32_t *burn_ref) {
+    const EPH_ERK_TABLE *tab = find_erk(method);
+    if (!tab || !tab->E || strlen(method) >= 32) return NULL;
+    orc_craft *c = calloc(1, sizeof(*c));
+    c->eph = eph;
+    c->mu = malloc(sizeof(double) * (size_t)(eph->n > 0 ? eph->n : 1));
+    memcpy(c->mu, mu, sizeof(double) * (size_t)eph->n);
+    /* Timeline::new  spacecraft.rs:129-152: stable sort by start, coast segments in the gaps */
+    int *order = malloc(sizeof(int) * (size_t)(nburns > 0 ? nburns : 1));
+    for (int i = 0; i < nburns; ++i) order[i] = i;
+    for (int i = 1; i < nburns; ++i) {                          /* insertion sort = stable */
+        int k = order[i], j = i - 1;
+        while (j >= 0 && burn_start[order[j]] > burn_start[k]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = k;
+    }
+    c->seg = calloc((size_t)(2 * nburns + 1), sizeof(segment_t));
+    const double EMIN = -1.7976931348623157e308, EMAX = 1.7976931348623157e308;   /* Epoch::MIN / MAX */
+    double cursor = EMIN;
+    for (int q = 0; q < nburns; ++q) {
+        const int i = order[q];
+        if (burn_start[i] > cursor) c->seg[c->nseg++] = (segment_t){cursor, burn_start[i], 0, {0, 0, 0}, -1};
+        cursor = burn_end[i];
+        c->seg[c->nseg++] = (segment_t){burn_start[i], burn_end[i], 1,
+                                        {burn_acc[3 * i], burn_acc[3 * i + 1], burn_acc[3 * i + 2]}, burn_ref[i]};
+    }
+    if (cursor < EMAX) c->seg[c->nseg++] = (segment_t){cursor, EMAX, 0, {0, 0, 0}, -1};
+    free(order);
+    /* SpacecraftPropagator::new  spacecraft.rs:446-476 */
+    c->time = t0;
+    memcpy(c->state, pos, sizeof(double) * 3);
+    memcpy(c->state + 3, vel, sizeof(double) * 3);
+    c->current_segment = timeline_idx_at(c, t0);
+    c->bound = c->seg[c->current_segment].end;
+    strcpy(c->method, method);
+    c->h_init = h_init; c->h_max = h_max; c->fac_min = fac_min; c->fac_max = fac_max; c->fac = fac;
+    c->tol_pos = tol_pos; c->tol_vel = tol_vel; c->n_max = n_max;
+    craft_reset_integrator(c);
+    craft_push_knot(c);                                          /* CubicHermiteSplineSolout::new_solution :654-661 */
+    return c;
+}
+void orc_craft_free(orc_craft *c) {
+    if (!c) return;
+    free(c->mu); free(c->seg); free(c->kt); free(c->kp); free(c->kv); free(c);
+}
+int orc_craft_step(orc_craft *c) {                               /* spacecraft.rs:598-615 */
+    /* advance_timeline(self.time())  :250-256 */
+    if (c->time >= c->seg[c->current_segment].end) {
+        c->current_segment += 1;
+        c->bound = c->seg[c->current_segment].end;              /* set_bound(new_end) */
+        craft_reset_integrator(c);
+    }
+    int st = adaptive_advance(&c->integ, &c->time, c->bound, c->state, craft_rhs, c, abs_tol, c, &c->evals);
+    if (st) return st;
+    c->steps++;
+    craft_push_knot(c);                                          /* solout :663-676 */
+    return ORC_OK;
+}
+int orc_craft_step_to(orc_craft *c, double t) {
+    for (;;) {
+        if (c->kt[c->nk - 1] >= t) return ORC_OK;                /* has_reached: solution.end() >= time :691-693 */
+        int st = orc_craft_step(c);
+        if (st) return st;
+    }
+}
+int64_t orc_craft_knots(const orc_craft *c) { return c->nk; }
+void orc_craft_get_knots(const orc_craft *c, double *t, double *pos, double *vel) {
+    memcpy(t, c->kt, sizeof(double) * (size_t)c->nk);
+    memcpy(pos, c->kp, sizeof(double) * 3 * (size_t)c->nk);
+    memcpy(vel, c->kv, sizeof(double) * 3 * (size_t)c->nk);
+}
+void orc_craft_state(const orc_craft *c, double *t, double *pos, double *vel, double *next_h, uint32_t *n,
+                     uint32_t *steps) {
+    if (t) *t = c->time;
+    if (pos) memcpy(pos, c->state, sizeof(double) * 3);
+    if (vel) memcpy(vel, c->state + 3, sizeof(double) * 3);
+    if (next_h) *next_h = c->integ.next_h;
+    if (n) *n = c->integ.n;
+    if (steps) *steps = c->steps;
+}
+uint64_t orc_craft_evals(const orc_craft *c) { return c->evals; }
+
+/* CubicHermiteSpline::state_vector  trajectory.rs:766-797 with CubicHermite::new/eval/eval_derivative :645-696 */
+int orc_hermite_eval(int64_t n, const double *t, const double *pos, const double *vel, double at, double *p, double *v) {
+    /* binary_search_by(|(t, _)| t.cmp(&at)) */
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        if (t[mid] == at) {
+            memcpy(p, pos + 3 * mid, sizeof(double) * 3);
+            if (v) memcpy(v, vel + 3 * mid, sizeof(double) * 3);
+            return 1;
+        }
+        if (t[mid] < at) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return 0;                                       /* i.checked_sub(1)? */
+    const int64_t i = lo - 1;
+    if (i + 1 >= n) return 0;                                    /* self.0.get(i + 1)? */
+    const double b0 = t[i], b1 = t[i + 1];
+    const double dt = b1 - b0;
+    for (int c = 0; c < 3; ++c) {
+        const double v0 = pos[3 * i + c], v1 = pos[3 * (i + 1) + c], d0 = vel[3 * i + c], d1 = vel[3 * (i + 1) + c];
+        double a2, a3;
+        /* the degenerate test is on whole vectors; dt == 0 cannot happen between distinct knots found by the search */
+        const double dt_recip = 1.0 / dt;
+        const double dt_recip_2 = dt_recip * dt_recip;
+        const double dt_recip_3 = dt_recip * dt_recip_2;
+        const double dt_val = v1 - v0;
+        a2 = dt_val * dt_recip_2 * 3.0 - (d0 * 2.0 + d1) * dt_recip;
+        a3 = dt_val * dt_recip_3 * -2.0 + (d0 + d1) * dt_recip_2;
+        const double x = at - b0;
+        p[c] = (((a3 * x + a2) * x) + d0) * x + v0;
+        if (v) v[c] = ((a3 * x * 3.0 + a2 * 2.0) * x) + d0;
+    }
+    return 1;
+}

@@ -102,6 +102,41 @@ int orc_least_squares_fit(int degree, int m, const double *ts, const double *xs,
 /* Polynomial::eval_and_deriv on one 8x3 coefficient block (trajectory.rs:368-385) */
 void orc_poly_eval_and_deriv(int ncoef, const double *coeffs, double tau, double *val, double *deriv);
 
+/* ---- massless path: SpacecraftPropagator<[StateVector;1], ReferenceFrame, Bodies, AdaptiveRungeKutta<ERK>, -----
+ * CubicHermiteSplineSolout>  (ephemeris/src/propagators/spacecraft.rs:224-695; integration/src/runge_kutta/
+ * explicit.rs:54-141, mod.rs:128-440; ephemeris_explorer/src/dynamics/spacecraft.rs:70-74,218-293,609-641).
+ * The bodies are visited in index order (the app's EntityHashMap order is unspecified; the reference test uses an
+ * IndexMap in body order, ephemeris/tests/spacecraft_propagation.rs:226-240). */
+typedef struct orc_craft orc_craft;
+/* eph: the massive bodies' splines (borrowed, must outlive the craft); mu[b]; method: an embedded ERK table name
+ * ("Verner87", "DormandPrince54", ...); burns: [start, end), acceleration in the burn frame, ref body index or -1
+ * for the inertial frame. */
+orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, const double *pos, const double *vel,
+                         const char *method, double h_init, double h_max, double tol_pos, double tol_vel,
+                         double fac_min, double fac_max, double fac, uint32_t n_max, int nburns,
+                         const double *burn_start, const double *burn_end, const double *burn_acc,
+                         const int32_t *burn_ref);
+void orc_craft_free(orc_craft *);
+int orc_craft_step(orc_craft *);              /* IncrementalPropagator::step  spacecraft.rs:598-615 */
+int orc_craft_step_to(orc_craft *, double t); /* step_to: until solution.end() >= t */
+int64_t orc_craft_knots(const orc_craft *);   /* CubicHermiteSpline points of the current solution */
+void orc_craft_get_knots(const orc_craft *, double *t, double *pos, double *vel);
+void orc_craft_state(const orc_craft *, double *t, double *pos, double *vel, double *next_h, uint32_t *n_attempts,
+                     uint32_t *steps);
+uint64_t orc_craft_evals(const orc_craft *);
+/* CubicHermiteSpline::state_vector (trajectory.rs:766-797): returns 0 for None */
+int orc_hermite_eval(int64_t nknots, const double *t, const double *pos, const double *vel, double at, double *p,
+                     double *v);
+/* generic scalar first-order problem y' = lambda*y for the doc-test known answers (integration/src/lib.rs:32-93):
+ * fixed-step ERK (method, h) or adaptive (h_init, h_max, atol, rtol like the doc-test's tolerance closure);
+ * returns y(t_end) */
+/* the controller's powf: 0 = correctly rounded double-double evaluation (default, the pinned definition),
+ * 1 = this host's libm pow (what the Rust reference would call here) */
+void orc_set_pow_mode(int mode);
+double orc_cr_pow(double x, double y);
+double orc_doc_test_decay(const char *method, int adaptive, double h, double h_max, double atol, double rtol,
+                          double t_end, uint32_t *steps);
+
 #ifdef __cplusplus
 }
 #endif

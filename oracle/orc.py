@@ -98,6 +98,28 @@ def lib(native=False):
     L.orc_least_squares_fit.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     L.orc_poly_eval_and_deriv.argtypes = [C.c_int, _dp, C.c_double, _dp, _dp]
     L.orc_poly_eval_and_deriv.restype = None
+    L.orc_craft_new.restype = vp
+    L.orc_craft_new.argtypes = [vp, _dp, C.c_double, _dp, _dp, C.c_char_p] + [C.c_double] * 7 + [C.c_uint32, C.c_int,
+                                _dp, _dp, _dp, _i32p]
+    L.orc_craft_free.argtypes = [vp]
+    L.orc_craft_free.restype = None
+    L.orc_craft_step.argtypes = [vp]
+    L.orc_craft_step_to.argtypes = [vp, C.c_double]
+    L.orc_craft_knots.argtypes = [vp]
+    L.orc_craft_knots.restype = C.c_int64
+    L.orc_craft_get_knots.argtypes = [vp, _dp, _dp, _dp]
+    L.orc_craft_get_knots.restype = None
+    L.orc_craft_state.argtypes = [vp, _dp, _dp, _dp, _dp, _u32p, _u32p]
+    L.orc_craft_state.restype = None
+    L.orc_craft_evals.argtypes = [vp]
+    L.orc_craft_evals.restype = C.c_uint64
+    L.orc_hermite_eval.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_double, _dp, _dp]
+    L.orc_doc_test_decay.restype = C.c_double
+    L.orc_doc_test_decay.argtypes = [C.c_char_p, C.c_int] + [C.c_double] * 5 + [_u32p]
+    L.orc_set_pow_mode.argtypes = [C.c_int]
+    L.orc_set_pow_mode.restype = None
+    L.orc_cr_pow.restype = C.c_double
+    L.orc_cr_pow.argtypes = [C.c_double, C.c_double]
     _libs[native] = L
     return L
 
@@ -302,3 +324,73 @@ def poly_eval_and_deriv(coeffs, ncoef, tau):
     v, d = np.zeros(3), np.zeros(3)
     lib().orc_poly_eval_and_deriv(int(ncoef), _ptr(coeffs), float(tau), _ptr(v), _ptr(d))
     return v, d
+
+
+def doc_test_decay(method, adaptive, h, h_max=0.0, atol=0.0, rtol=0.0, t_end=5.0):
+    steps = C.c_uint32()
+    y = lib().orc_doc_test_decay(method.encode(), int(adaptive), h, h_max, atol, rtol, t_end, C.byref(steps))
+    return y, steps.value
+
+
+class Craft:
+    """SpacecraftPropagator<[StateVector;1], ReferenceFrame, Bodies, <ERK pair>, CubicHermiteSplineSolout>.
+    burns: list of (start, end, acc[3], ref_body_index or -1)."""
+
+    def __init__(self, eph, mu, t0, pos, vel, method="Verner87", h_init=60.0, h_max=1.7976931348623157e308,
+                 tol_pos=1e-3, tol_vel=1e-3, fac_min=1.0 / 5.0, fac_max=5.0 / 1.0, fac=9.0 / 10.0, n_max=1_000_000,
+                 burns=()):
+        self.L = eph.L
+        self.eph = eph          # keep the splines alive
+        mu, pos, vel = _f64(mu), _f64(pos), _f64(vel)
+        nb = len(burns)
+        bs = _f64([b[0] for b in burns] or [0.0])
+        be = _f64([b[1] for b in burns] or [0.0])
+        ba = _f64([b[2] for b in burns] or [[0.0, 0.0, 0.0]])
+        br = np.ascontiguousarray([b[3] for b in burns] or [0], dtype=np.int32)
+        self.h = self.L.orc_craft_new(eph.h, _ptr(mu), float(t0), _ptr(pos), _ptr(vel), method.encode(), h_init, h_max,
+                                      tol_pos, tol_vel, fac_min, fac_max, fac, n_max, nb, _ptr(bs), _ptr(be), _ptr(ba),
+                                      _ptr(br, _i32p))
+        if not self.h:
+            raise ValueError(method)
+
+    def step(self):
+        return self.L.orc_craft_step(self.h)
+
+    def step_to(self, t):
+        return self.L.orc_craft_step_to(self.h, float(t))
+
+    def knots(self):
+        n = self.L.orc_craft_knots(self.h)
+        t, p, v = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 3))
+        self.L.orc_craft_get_knots(self.h, _ptr(t), _ptr(p), _ptr(v))
+        return t, p, v
+
+    def state(self):
+        t, h = C.c_double(), C.c_double()
+        p, v = np.zeros(3), np.zeros(3)
+        n, s = C.c_uint32(), C.c_uint32()
+        self.L.orc_craft_state(self.h, C.byref(t), _ptr(p), _ptr(v), C.byref(h), C.byref(n), C.byref(s))
+        return dict(t=t.value, pos=p, vel=v, next_h=h.value, attempts=n.value, steps=s.value)
+
+    def evals(self):
+        return self.L.orc_craft_evals(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_craft_free(self.h)
+            self.h = None
+
+
+def hermite_eval(t, pos, vel, at):
+    t, pos, vel = _f64(t), _f64(pos), _f64(vel)
+    p, v = np.zeros(3), np.zeros(3)
+    ok = lib().orc_hermite_eval(len(t), _ptr(t), _ptr(pos), _ptr(vel), float(at), _ptr(p), _ptr(v))
+    return (p, v) if ok else None
+
+
+def set_pow_mode(mode):
+    lib().orc_set_pow_mode(int(mode))
+
+
+def cr_pow(x, y):
+    return lib().orc_cr_pow(float(x), float(y))

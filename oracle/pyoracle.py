@@ -301,3 +301,172 @@ class Propagator:
     def take_solution(self):
         old, self.solution = self.solution, self._new_solution()
         return old
+
+
+# =====================================================================================================
+# Massless path (independent restatement; float mode only)
+# =====================================================================================================
+def spline_position(start, interval, polys, at):
+    """UniformSpline::position: eval_slice_horner (ephemeris/src/trajectory.rs:398-410,459-462,551-561)."""
+    local = at - start
+    if math.copysign(1.0, local) < 0 or local > interval * float(len(polys)):
+        return None
+    idx = max(int(math.ceil(local / interval)) - 1, 0)
+    if idx >= len(polys):
+        return None
+    tau = (local - interval * float(idx)) / interval
+    r = Vec(0.0, 0.0, 0.0)
+    for c in reversed(polys[idx]):
+        r = r * tau + c
+    return r
+
+
+class Erk:
+    """ERK + embedded error (integration/src/runge_kutta/explicit.rs:54-141)."""
+
+    def __init__(self, name, state):
+        t = tables()["methods"][name]
+        self.A = [[_ratio(r) for r in row] for row in t["A"]["ratio"]]
+        self.B = [_ratio(r) for r in t["B"]["ratio"]]
+        self.C = [_ratio(r) for r in t["C"]["ratio"]]
+        self.E = [_ratio(r) for r in t["E"]["ratio"]]
+        self.fsal = t["FSAL"]
+        self.lower = min(int(t["ORDER"]), int(t["ORDER_EMBEDDED"]))
+        self.i = 0
+        self.k = [list(state) for _ in self.B]
+
+    def advance(self, h, t, y, f):
+        S = len(self.B)
+        for s in range(S):
+            if self.fsal and s == 0 and self.i > 0:
+                self.k[0], self.k[S - 1] = self.k[S - 1], self.k[0]
+                continue
+            ti = t + h * self.C[s]
+            yi = list(y)
+            for j in range(s):
+                ha = h * self.A[s][j]
+                yi = [a + kk * ha for a, kk in zip(yi, self.k[j])]
+            self.k[s] = f(ti, yi)
+            if self.k[s] is None:
+                return None
+        for i in range(S):
+            hb = h * self.B[i]
+            y = [a + kk * hb for a, kk in zip(y, self.k[i])]
+        self.i += 1
+        return t + h, y
+
+    def error(self, h):
+        e = [0.0] * len(self.k[0])
+        for i in range(len(self.B)):
+            he = h * self.E[i]
+            e = [a + kk * he for a, kk in zip(e, self.k[i])]
+        return e
+
+
+class Craft:
+    """SpacecraftPropagator with an adaptive ERK pair and the CubicHermiteSpline solout
+    (ephemeris/src/propagators/spacecraft.rs:415-695, integration/src/runge_kutta/mod.rs:188-285,396-440,
+    ephemeris_explorer/src/dynamics/spacecraft.rs:70-74,218-293,609-641). `eph` = list of dicts
+    {start, interval, polys} per body; burns = (start, end, acc, ref_index or -1)."""
+
+    EMIN, EMAX = -1.7976931348623157e308, 1.7976931348623157e308
+
+    def __init__(self, eph, mu, t0, pos, vel, method, tol, burns, h_init=60.0, n_max=1_000_000):
+        self.eph, self.mu, self.method, self.tol = eph, list(mu), method, tol
+        self.h_init, self.n_max = h_init, n_max
+        self.fac_min, self.fac_max, self.fac, self.h_max = 1.0 / 5.0, 5.0 / 1.0, 9.0 / 10.0, self.EMAX
+        segs, cursor = [], self.EMIN
+        for s, e, acc, ref in sorted(burns, key=lambda b: b[0]):
+            if s > cursor:
+                segs.append((cursor, s, None, -1))
+            cursor = e
+            segs.append((s, e, Vec(*acc), ref))
+        if cursor < self.EMAX:
+            segs.append((cursor, self.EMAX, None, -1))
+        self.segs = segs
+        self.t = t0
+        self.y = list(pos) + list(vel)
+        self.cur = next(i for i, sg in enumerate(segs) if not sg[1] <= t0)
+        self.bound = segs[self.cur][1]
+        self.reset()
+        self.knots = [(self.t, tuple(self.y))]
+
+    def reset(self):
+        self.rk = Erk(self.method, self.y)
+        self.next_h = self.h_init
+        self.n = 0
+
+    def rhs(self, t, y):
+        pos, vel = Vec(*y[:3]), Vec(*y[3:])
+        acc = Vec(0.0, 0.0, 0.0)
+        for b, e in enumerate(self.eph):
+            bp = spline_position(e["start"], e["interval"], e["polys"], t)
+            if bp is None:
+                return None
+            d = bp - pos
+            n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+            acc = acc + d * (self.mu[b] * (1.0 / (n2 * math.sqrt(n2))))
+        man = Vec(0.0, 0.0, 0.0)
+        _, _, bacc, ref = self.segs[self.cur]
+        if bacc is not None:
+            if ref >= 0:
+                e = self.eph[ref]
+                sv = spline_eval(e["start"], e["interval"], e["polys"], t)
+                if sv is None:
+                    return None
+                rp, rv = pos - sv[0], vel - sv[1]
+
+                def norm(v):
+                    rcp = 1.0 / math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+                    return v * rcp if math.isfinite(rcp) and rcp > 0.0 else None
+
+                def cross(a, b):
+                    return Vec(a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1])
+
+                x = norm(rv)
+                yv = norm(cross(rp, rv)) if x is not None else None
+                if x is None or yv is None:
+                    return None
+                xy = cross(x, yv)
+                z = xy * (1.0 / math.sqrt(xy[0] * xy[0] + xy[1] * xy[1] + xy[2] * xy[2]))
+                man = x * bacc[0] + z * bacc[1] + yv * bacc[2]
+            else:
+                man = Vec(1.0, 0.0, 0.0) * bacc[0] + Vec(0.0, 1.0, 0.0) * bacc[1] + Vec(0.0, 0.0, 1.0) * bacc[2]
+        a = acc + man
+        return [vel[0], vel[1], vel[2], a[0], a[1], a[2]]
+
+    def step(self):
+        if self.t >= self.segs[self.cur][1]:
+            self.cur += 1
+            self.bound = self.segs[self.cur][1]
+            self.reset()
+        prev = (self.t, list(self.y), self.rk.i, list(self.rk.k[-1]))
+        while True:
+            if self.n > self.n_max:
+                return 2
+            if self.t + self.next_h > self.bound:
+                self.next_h = self.bound - self.t
+            h = self.next_h
+            if self.t >= self.bound:
+                return 3
+            if self.t + h == self.t:
+                return 1
+            r = self.rk.advance(h, self.t, self.y, self.rhs)
+            if r is None:
+                return 4
+            self.t, self.y = r
+            self.n += 1
+            e = self.rk.error(h)
+            err = max(max(abs(e[0] / self.tol), max(abs(e[1] / self.tol), abs(e[2] / self.tol))),
+                      max(abs(e[3] / self.tol), max(abs(e[4] / self.tol), abs(e[5] / self.tol))))
+            m = self.fac * math.pow(err, -(1.0 / float(self.rk.lower))) if err != 0.0 else math.inf
+            c = self.fac_min if m < self.fac_min else (self.fac_max if m > self.fac_max else m)
+            nh = self.next_h * c
+            self.next_h = self.h_max if nh > self.h_max else nh
+            if err <= 1.0:
+                break
+            self.t, self.y, self.rk.i = prev[0], list(prev[1]), prev[2]
+            if self.rk.fsal:
+                self.rk.k[-1] = list(prev[3])
+        self.knots.append((self.t, tuple(self.y)))
+        return 0

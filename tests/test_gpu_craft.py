@@ -1,0 +1,169 @@
+"""-m gpu: the massless sweep (one device thread per spacecraft) against the CPU oracle, through the C ABI.
+
+Every f64 operation on this path is performed in the oracle's order; the single libm call of the reference, powf in
+the step-size controller (integration/src/runge_kutta/mod.rs:239), is evaluated correctly rounded by the same
+double-double sequence on both sides. Knots (times, positions, velocities) must be bit-identical."""
+import numpy as np
+import pytest
+
+from conftest import SYSTEMS, load_system
+from ephemeris_explorer_amd.systems import load_ship, parse_epoch
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def simple_system(gpu):
+    """10-body 1950 system, QuinlanTremaine12 6 h, two years of ephemeris: on the GPU and in the oracle (bit-identical,
+    test_gpu_parity.py), like ephemeris/tests/spacecraft_propagation.rs:401-409."""
+    s = load_system("simple_solar_system_2433282.5")
+    end = parse_epoch("1952-01-01 00:00:00")
+    g = gpu.NBodyPropagator.from_system(s)
+    sol = g.propagate(end)
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert o.step_to(end) == 0
+    osol = o.take_solution()
+    for b in range(s.n):
+        assert sol.info(b) == osol.info(b)
+    return s, sol, gpu.Ephemeris(sol, s.mu), osol
+
+
+def ship_burns(ship, names):
+    return [(b.start, b.start + b.duration, b.acceleration, names.index(b.reference) if b.reference else -1)
+            for b in ship.burns]
+
+
+def compare_knots(g, o, what):
+    gt, gp, gv = g
+    ot, op, ov = o
+    assert len(gt) == len(ot), f"{what}: {len(gt)} vs {len(ot)} knots"
+    exact = (np.array_equal(bits(gt), bits(ot)) and np.array_equal(bits(gp), bits(op)) and
+             np.array_equal(bits(gv), bits(ov)))
+    if not exact:
+        first = int(np.argmax((bits(gt) != bits(ot)) | (bits(gp) != bits(op)).any(axis=1)))
+        raise AssertionError(f"{what}: knots differ from #{first}: t {gt[first]!r} vs {ot[first]!r}")
+    return exact
+
+
+def test_mars_transfer_scenario(gpu, simple_system):
+    """The reference's own spacecraft test re-expressed on committed fixtures: Verner87, tol 1e-3, four burns in the
+    Earth / Sun / Mars TNB frames; asserts of ephemeris/tests/spacecraft_propagation.rs:476-480."""
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    burns = ship_burns(ship, s.names)
+    end = parse_epoch("1951-01-01 00:00:00")
+    params = gpu.AdaptiveParams.default(ship.tolerance)
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator, params, [burns], max_knots=20000)
+    batch.propagate(end)
+    st = batch.status()
+    assert st["status"][0] == 0
+    c = orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, ship.integrator, tol_pos=ship.tolerance,
+                  tol_vel=ship.tolerance, burns=burns)
+    assert c.step_to(end) == 0
+    assert st["steps"][0] == c.state()["steps"] and st["attempts"][0] == c.state()["attempts"]
+    kt, kp, kv = batch.knots(0)
+    assert compare_knots((kt, kp, kv), c.knots(), "Mars transfer"), "knots are expected to be bit-identical"
+    gs = batch.state()
+    assert gs["t"][0] == c.state()["t"] and gs["next_h"][0] == c.state()["next_h"]
+
+    def distance(body, when):
+        t = parse_epoch(when)
+        p, _, inside = gpu.hermite_eval(kt, kp, kv, [t])
+        bp, _, ins2 = sol.eval(s.names.index(body), [t], with_velocity=False)
+        assert inside[0] and ins2[0]
+        return np.linalg.norm(p[0] - bp[0])
+
+    assert distance("Earth", "1950-01-01 00:00:00") < 10_000.0
+    assert distance("Earth", "1950-01-01 00:15:00") < 10_000.0
+    assert distance("Mars", "1950-07-27 15:45:00") < 10_000.0       # enters and stays in Mars' orbit
+    assert distance("Mars", "1951-01-01 00:00:00") < 10_000.0
+
+
+@pytest.mark.parametrize("method", ["CashKarp45", "DormandPrince54", "DormandPrince87", "Fehlberg45", "Tsitouras75",
+                                    "Verner87", "Verner98"])
+def test_every_embedded_pair(gpu, simple_system, method):
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    burns = ship_burns(ship, s.names)[:2]
+    end = ship.start + 3 * 86400.0
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], method, gpu.AdaptiveParams.default(1e-3),
+                                [burns], max_knots=20000)
+    batch.propagate(end)
+    assert batch.status()["status"][0] == 0
+    c = orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, method, burns=burns)
+    assert c.step_to(end) == 0
+    assert compare_knots(batch.knots(0), c.knots(), method)
+
+
+def test_batch_of_perturbed_craft_and_resume(gpu, simple_system):
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    rng = np.random.default_rng(20260926)
+    n = 96
+    pos = ship.pos + rng.normal(0.0, 100.0, size=(n, 3))
+    vel = ship.vel + rng.normal(0.0, 0.01, size=(n, 3))
+    burns = [ship_burns(ship, s.names)[:1] if i % 3 == 0 else [] for i in range(n)]
+    batch = gpu.SpacecraftBatch(eph, ship.start, pos, vel, "Verner87", burns=burns, max_knots=8192)
+    mid, end = ship.start + 2 * 86400.0, ship.start + 5 * 86400.0   # low Earth orbit: ~50 accepted steps per revolution
+    batch.propagate(mid)            # step_to(mid), then resume to `end`: same knots as going straight through
+    batch.propagate(end)
+    st = batch.status()
+    assert (st["status"] == 0).all()
+    exact = 0
+    for i in range(n):
+        c = orc.Craft(osol, s.mu, ship.start, pos[i], vel[i], "Verner87", burns=burns[i])
+        assert c.step_to(mid) == 0 and c.step_to(end) == 0
+        exact += compare_knots(batch.knots(i, st["nknots"][i]), c.knots(), f"craft {i}")
+    assert exact == n
+
+
+def test_errors_are_per_craft_values(gpu, simple_system):
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    # craft 1 runs past the end of the ephemeris -> EvalFailed (spacecraft.rs:264-281); craft 0 is fine;
+    # craft 2 fills its knot slab
+    far = parse_epoch("1953-01-01 00:00:00")
+    burns = ship_burns(ship, s.names)          # the transfer leaves Earth orbit, so steps grow to hours
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos] * 2, [ship.vel] * 2, "Verner87", burns=[burns, burns],
+                                max_knots=100000)
+    batch.propagate(ship.start + 86400.0)
+    assert (batch.status()["status"] == 0).all()
+    batch.propagate(far)
+    assert (batch.status()["status"] == gpu.EVAL_FAILED).all()
+    c = orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, "Verner87", burns=burns)
+    assert c.step_to(far) == orc.EVAL_FAILED
+    assert batch.status()["nknots"][0] == len(c.knots()[0])
+    assert compare_knots(batch.knots(0), c.knots(), "up to the failure")
+    small = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], "Verner87", max_knots=16)
+    small.propagate(ship.start + 86400.0)
+    assert small.status()["status"][0] == gpu.KNOTS_FULL and small.status()["nknots"][0] == 16
+    with pytest.raises(gpu.EphemerisError):
+        gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], "RK4")          # no embedded pair
+
+
+def test_hermite_eval_kernel(gpu):
+    rng = np.random.default_rng(4)
+    t = np.cumsum(rng.uniform(1.0, 100.0, 50))
+    p, v = rng.normal(size=(50, 3)) * 1e6, rng.normal(size=(50, 3))
+    at = np.concatenate([t, rng.uniform(t[0] - 10, t[-1] + 10, 500), [t[0], t[-1]]])
+    op, ov, inside = gpu.hermite_eval(t, p, v, at)
+    for k, x in enumerate(at):
+        r = orc.hermite_eval(t, p, v, x)
+        assert (r is not None) == bool(inside[k])
+        if r is not None:
+            assert np.array_equal(bits(op[k]), bits(r[0])) and np.array_equal(bits(ov[k]), bits(r[1]))
+
+
+def test_controller_pow_is_the_same_correctly_rounded_value(gpu):
+    rng = np.random.default_rng(8)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-16), np.log(1e10), 200000)), [0.0, 1.0, np.inf, 1e-300, 5e-324]])
+    for k in (4, 5, 7, 8):
+        y = -(1.0 / k)
+        dev = gpu.debug_pow(x, y)
+        ref = np.array([orc.cr_pow(v, y) for v in x])
+        assert np.array_equal(bits(dev), bits(ref))

@@ -1,0 +1,114 @@
+"""CPU: pins the massless-path oracle: the reference's doc-test known answers, its spacecraft test re-expressed on the
+committed fixtures (same assertions), an independent Python restatement (bit for bit), and the pinned definition of
+the controller's powf."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import SYSTEMS, load_system
+from ephemeris_explorer_amd.systems import load_ship, parse_epoch
+from oracle import orc, pyoracle as po
+
+
+def test_doc_test_known_answers():
+    """integration/src/lib.rs:32-56 (RK4, h = 1e-3) and :60-93 (DormandPrince54, atol 1e-8 / rtol 1e-10, h_init 1e-3,
+    h_max 0.2): y' = -y, y(0) = 1 integrated to the bound t = 5; both assert |y - e^-5| < 1e-6."""
+    y, steps = orc.doc_test_decay("RK4", False, 0.001)
+    assert steps == 5000 and abs(y - math.exp(-5.0)) < 1e-6
+    y, steps = orc.doc_test_decay("DormandPrince54", True, 1e-3, 0.2, 1e-8, 1e-10)
+    assert abs(y - math.exp(-5.0)) < 1e-6 and 20 < steps < 100
+    for name in ("CashKarp45", "Fehlberg45", "Tsitouras75", "Verner87", "Verner98", "DormandPrince87"):
+        y, _ = orc.doc_test_decay(name, True, 1e-3, 0.2, 1e-8, 1e-10)
+        assert abs(y - math.exp(-5.0)) < 1e-6, name
+
+
+@pytest.fixture(scope="module")
+def scenario():
+    s = load_system("simple_solar_system_2433282.5")
+    pr = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert pr.step_to(parse_epoch("1952-01-01 00:00:00")) == 0
+    eph = pr.take_solution()
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    burns = [(b.start, b.start + b.duration, b.acceleration, s.names.index(b.reference) if b.reference else -1)
+             for b in ship.burns]
+    return s, eph, ship, burns
+
+
+def test_reference_spacecraft_scenario(scenario):
+    """ephemeris/tests/spacecraft_propagation.rs:401-483 on the committed 10-body 1950 system: Verner87, tol 1e-3 km,
+    four burns in Earth / Sun / Mars TNB frames; the spacecraft must be within 10 000 km of Earth at t0 and +15 min and
+    of Mars at 1950-07-27 15:45 and 1951-01-01 (:476-480)."""
+    s, eph, ship, burns = scenario
+    for mode in (0, 1):                      # pinned correctly rounded powf, then this host's libm pow
+        orc.set_pow_mode(mode)
+        try:
+            c = orc.Craft(eph, s.mu, ship.start, ship.pos, ship.vel, ship.integrator, tol_pos=ship.tolerance,
+                          tol_vel=ship.tolerance, burns=burns)
+            assert c.step_to(parse_epoch("1951-01-01 00:00:00")) == 0
+        finally:
+            orc.set_pow_mode(0)
+        kt, kp, kv = c.knots()
+        assert 10000 < len(kt) < 20000
+
+        def distance(body, when):
+            t = parse_epoch(when)
+            return np.linalg.norm(orc.hermite_eval(kt, kp, kv, t)[0] - eph.eval(s.names.index(body), t)[0])
+
+        assert distance("Earth", "1950-01-01 00:00:00") < 10_000.0
+        assert distance("Earth", "1950-01-01 00:15:00") < 10_000.0
+        assert distance("Mars", "1950-07-27 15:45:00") < 10_000.0
+        assert distance("Mars", "1951-01-01 00:00:00") < 10_000.0
+
+
+@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "CashKarp45"])
+def test_c_oracle_equals_python_restatement_massless(scenario, method):
+    s, eph, ship, burns = scenario
+    pe = []
+    for b in range(s.n):
+        st, iv, n = eph.info(b)
+        co, nc = eph.coeffs(b)
+        pe.append({"start": st, "interval": iv, "polys": [[po.Vec(*co[p, k]) for k in range(nc[p])] for p in range(n)]})
+    orc.set_pow_mode(1)                      # the Python restatement calls math.pow (libm)
+    try:
+        c = orc.Craft(eph, s.mu, ship.start, ship.pos, ship.vel, method, tol_pos=1e-3, tol_vel=1e-3, burns=burns)
+        p = po.Craft(pe, s.mu, ship.start, ship.pos, ship.vel, method, 1e-3, burns)
+        for _ in range(400):                 # crosses the first two burns (integrator resets) and rejections
+            assert c.step() == 0 and p.step() == 0
+    finally:
+        orc.set_pow_mode(0)
+    kt, kp, kv = c.knots()
+    assert len(p.knots) == len(kt)
+    for i, (t, y) in enumerate(p.knots):
+        assert kt[i] == t and tuple(kp[i]) == y[:3] and tuple(kv[i]) == y[3:], (method, i)
+
+
+def test_controller_pow_is_correctly_rounded():
+    """The pinned powf: equal to the exact power rounded to nearest (mpmath, 200 bits); this host's libm differs from
+    that in a small fraction of calls (glibc documents < 0.52 ULP), which is why the definition is pinned."""
+    import mpmath as mp
+    mp.mp.prec = 200
+    rng = np.random.default_rng(2)
+    xs = np.exp(rng.uniform(np.log(1e-14), np.log(1e8), 3000))
+    libm_diff = 0
+    for k in (4, 5, 7, 8):
+        y = -(1.0 / k)
+        for x in xs:
+            v = orc.cr_pow(x, y)
+            assert v == float(mp.power(mp.mpf(float(x)), mp.mpf(y)))
+            libm_diff += v != math.pow(x, y)
+    assert libm_diff < 0.01 * 4 * len(xs)
+    assert orc.cr_pow(0.0, -1 / 7) == math.inf and orc.cr_pow(math.inf, -0.2) == 0.0 and orc.cr_pow(1.0, -0.2) == 1.0
+
+
+def test_hermite_spline_restatement():
+    t = np.array([0.0, 1.0, 3.0])
+    p = np.array([[0.0, 0, 0], [1.0, 2, 3], [5.0, 1, 0]])
+    v = np.array([[1.0, 0, 0], [1.0, 1, 1], [0.0, 0, 0]])
+    for k in range(3):                       # exact at the knots (binary_search Ok branch)
+        r = orc.hermite_eval(t, p, v, t[k])
+        assert np.array_equal(r[0], p[k]) and np.array_equal(r[1], v[k])
+    assert orc.hermite_eval(t, p, v, -0.1) is None and orc.hermite_eval(t, p, v, 3.1) is None
+    r = orc.hermite_eval(t, p, v, 0.5)       # cubic through (0,1) with end slopes: position 0.5 + ... closed form
+    h00, h10, h01, h11 = 0.5, 0.125, 0.5, -0.125
+    assert np.allclose(r[0], h00 * p[0] + h10 * v[0] + h01 * p[1] + h11 * v[1], atol=1e-15)
