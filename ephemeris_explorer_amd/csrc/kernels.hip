@@ -821,6 +821,148 @@ __global__ void __launch_bounds__(512) k_lm_persistent(const LmArgs a, long long
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_lm_small: n <= 64, the whole system in ONE workgroup, `nsteps` integrator steps per launch (second design
+// of the persistent kernel; k_lm_persistent above is the first and stays selectable for comparison).
+// Inside one workgroup the pair symmetry the reference uses CAN be shared: thread p owns the unordered pair
+// (i, j), i < j, computes d, n2, 1/(n2*sqrt(n2)) once and writes both directed contributions
+//     c(i<-j) =  d * (mu_j * inv)  -> U[i][j]   ("sources after the body")
+//     c(j<-i) = -d * (mu_i * inv)  -> Lw[j][i]  ("sources before the body")
+// exactly the reference's acceleration_paired halves. Rows of U / Lw are zero outside those ranges (written once
+// at kernel start), so the two ordered chains of a body are plain in-order sums over a row (adding +0.0 is exact;
+// the accumulators start at +0.0 and never become -0.0), one thread per (body, component, half):
+//     ddy[i] = (0 + c(0,i) + ... + c(i-1,i)) + (0 + c(i,i+1) + ... + c(i,n-1)).
+// Two barriers per step; history ring, velocity, predictor and Cowell formula live in the (body, component) thread.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kSmallMaxN = 40;           // two zero-padded contribution arrays must fit 160 KiB of LDS
+constexpr int kSmallRow = 48 + 2;        // doubles per row (n <= 40 -> 48 walked): 16-byte aligned, conflict-free
+template <int L>
+__global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nsteps) {
+    __shared__ __attribute__((aligned(16))) double U[3 * kSmallMaxN][kSmallRow];    // [body*3 + comp][source]
+    __shared__ __attribute__((aligned(16))) double Lw[3 * kSmallMaxN][kSmallRow];
+    __shared__ __attribute__((aligned(32))) Body4 sP[kTile];
+
+    const int tid = threadIdx.x, n = a.n;
+    // chain threads: tid = (body*3 + comp)*2 + half   (half 0 = sources before, 1 = sources after)
+    const int chain = tid >> 1, half = tid & 1;
+    const bool chain_thread = chain < 3 * n;
+    const bool owner = chain_thread && half == 0;     // the (body, comp) thread: history, velocity, predictor
+    const int my_i = chain_thread ? chain / 3 : 0, cc = chain_thread ? chain % 3 : 0;
+    const size_t lvl = (size_t)3 * a.npad;
+    const size_t off = (size_t)cc * a.npad + my_i;
+    const int npairs = n * (n - 1) / 2;
+    const int nrow = (n + 15) & ~15;   // row length the chains walk (the padding holds zeros)
+
+    for (int k = tid; k < 3 * kSmallMaxN * kSmallRow; k += blockDim.x) { (&U[0][0])[k] = 0.0; (&Lw[0][0])[k] = 0.0; }
+    if (tid < kTile) sP[tid] = a.pos_cur[tid < n ? tid : n - 1];
+    // history and coefficients live in VGPRs for the whole launch: yv[j] / av[j] = level (newest - j).
+    // (Kernel arguments would otherwise be re-fetched through the scalar cache every step.)
+    double yv[L], av[L], wa[L], wb[L], cw[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int slot = (a.cur + j) % L;
+        yv[j] = a.Y[slot * lvl + off];
+        av[j] = a.A[slot * lvl + off];
+        wa[j] = a.wa[j]; wb[j] = a.wb[j]; cw[j] = a.cw[j];
+        asm volatile("" : "+v"(wa[j]), "+v"(wb[j]), "+v"(cw[j]));
+    }
+    double hh = a.hh, hc = a.hc, h = a.h;
+    asm volatile("" : "+v"(hh), "+v"(hc), "+v"(h));
+    double v = owner ? a.V[off] : 0.0;
+    // solout sampling schedule of this thread's body, read once (maybe_sample would fetch it every step)
+    uint32_t samp_m = 0, samp_phase = 0;
+    uint64_t samp_base = 0;
+    if (owner && a.samp.period) {
+        samp_m = a.samp.period[my_i];
+        samp_phase = a.samp.phase[my_i];
+        samp_base = a.samp.offset[my_i];
+    }
+    // this thread's unordered pairs (i < j), row-major over the strict upper triangle, 2 per thread at most for
+    // n <= 40 (780 pairs over 512 threads): decode once
+    int pi0 = -1, pj0 = 0, pi1 = -1, pj1 = 0;
+    for (int q = 0; q < 2; ++q) {
+        const int p = tid + q * (int)blockDim.x;
+        if (p < npairs) {
+            int i = 0;
+            while ((i + 1) * (2 * n - i - 2) / 2 <= p) ++i;
+            const int j = i + 1 + (p - i * (2 * n - i - 1) / 2);
+            if (q == 0) { pi0 = i; pj0 = j; } else { pi1 = i; pj1 = j; }
+        }
+    }
+    __syncthreads();
+
+    auto pair = [&](int i, int j) {
+        const Body4 bi = sP[i], bj = sP[j];
+        const double dx = bj.x - bi.x, dy = bj.y - bi.y, dz = bj.z - bi.z;
+        const double n2 = dx * dx + dy * dy + dz * dz;
+        const double inv = 1.0 / (n2 * sqrt(n2));
+        const double si = bj.mu * inv, sj = bi.mu * inv;
+        U[i * 3 + 0][j] = dx * si;
+        U[i * 3 + 1][j] = dy * si;
+        U[i * 3 + 2][j] = dz * si;
+        Lw[j * 3 + 0][i] = -dx * sj;
+        Lw[j * 3 + 1][i] = -dy * sj;
+        Lw[j * 3 + 2][i] = -dz * sj;
+    };
+
+    for (long long s = 1; s <= nsteps; ++s) {
+        // ---- predictor (ELM2::advance) in the (body, comp) threads
+        double ynew = 0.0;
+        if (owner) {
+            ynew = lm_predict<L>(yv, av, wa, wb, hh);
+            reinterpret_cast<double *>(&sP[my_i])[cc] = ynew;
+        }
+        __syncthreads();   // positions of the new level visible
+        // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
+        if (pi0 >= 0) pair(pi0, pj0);
+        if (pi1 >= 0) pair(pi1, pj1);
+        __syncthreads();   // contributions visible
+        // ---- ordered chains: plain in-order sums over the rows (zeros outside each chain's range)
+        double acc = 0.0;
+        if (chain_thread) {
+            const double *row = half ? &U[chain][0] : &Lw[chain][0];
+            for (int c = 0; c < nrow; c += 16) {
+                double2 r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const double2 *>(row + c + 2 * k);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    acc = acc + r[k].x;
+                    acc = acc + r[k].y;
+                }
+            }
+        }
+        const double other = __shfl_xor(acc, 1);          // the partner half (adjacent lane, same wave)
+        if (owner) {
+            const double anew = acc + other;               // ddy[i] (lower sum) += output_i (upper sum)
+            v = lm_cowell<L>(anew, av, ynew, yv[0], cw, h, hc);
+            if (samp_m) {                                  // SplineInterpolators::solout_with  nbody.rs:389-397
+                const uint32_t t = samp_phase + (uint32_t)s;
+                if (t % samp_m == 0) a.samp.log[(samp_base + (uint64_t)(t / samp_m - 1)) * 3 + cc] = ynew;
+            }
+#pragma unroll
+            for (int j = L - 1; j > 0; --j) { yv[j] = yv[j - 1]; av[j] = av[j - 1]; }
+            yv[0] = ynew;
+            av[0] = anew;
+        }
+        // no barrier needed here: the next predictor writes sP only after every pair thread of this step passed the
+        // barrier above, and U / Lw are rewritten only after the next "positions visible" barrier
+    }
+
+    if (owner) {
+        const int cur = (int)(((long long)a.cur - nsteps % L + L) % L);   // slot of the newest level after nsteps
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int slot = (cur + j) % L;
+            a.Y[slot * lvl + off] = yv[j];
+            a.A[slot * lvl + off] = av[j];
+        }
+        a.V[off] = v;
+        reinterpret_cast<double *>(a.pos_next + my_i)[cc] = yv[0];
+        reinterpret_cast<double *>(const_cast<Body4 *>(a.pos_cur) + my_i)[cc] = yv[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // small element-wise kernels (start-up path, staging)
 // ------------------------------------------------------------------------------------------------------
 __global__ void k_pack(int n, int npad, const double *__restrict__ Y, const double *__restrict__ mu, Body4 *pos) {
@@ -1113,6 +1255,11 @@ int launch_lm_predict(hipStream_t s, const LmArgs &a) {
 }
 template <int L>
 static int launch_lm_persistent_L(hipStream_t s, const LmArgs &a, int64_t nsteps) {
+    static const int old_design = [] { const char *e = getenv("EPH_SMALL"); return e && e[0] == '1'; }();
+    if (!old_design && a.n <= kSmallMaxN) {
+        hipLaunchKernelGGL(k_lm_small<L>, dim3(1), dim3(512), 0, s, a, (long long)nsteps);
+        return done("k_lm_small");
+    }
     const int per_wave = (a.n + 7) / 8;
     const dim3 grid(1), block(512);
     if (per_wave <= 1) hipLaunchKernelGGL((k_lm_persistent<1, L>), grid, block, 0, s, a, (long long)nsteps);
