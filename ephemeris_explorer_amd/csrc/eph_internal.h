@@ -75,12 +75,15 @@ struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm
     double h, hh, hc;          // h, h*h*(1/BETA_D), h*(1/COWELL_D)
     int do_predict;
     uint32_t step;             // 1-based index of this step inside the batch (for sampling)
+    int kind;                  // force kernel: 0 auto, 1 wave, 2 workgroup
     SampleArgs samp;
 };
 
 // ---- launchers (kernels.hip) --------------------------------------------------------------------
 // a[b] = acc_init[b] (or 0) + sum over the other bodies in the reference order; SoA [3][npad] output
-int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out);
+// kind: 0 = auto by n, 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
+int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out,
+                 int kind = 0);
 int launch_pack(hipStream_t s, int n, int npad, const double *Yslot, const double *mu, Body4 *pos);
 int launch_copy3(hipStream_t s, int n, int npad, const double *src, double *dst);
 // SRKN stage update: v += a*hb ; y += v*ha ; also publishes packed positions   (symplectic.rs:90-97)

@@ -71,6 +71,8 @@ public:
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
     void set_path(int p) { path_ = p; }
+    // path 1 -> per-step launches with the one-wave-per-block force, 3 -> with the workgroup-specialised force
+    int force_kind() const { return path_ == 1 ? 1 : (path_ == 3 ? 2 : 0); }
     void set_sampling(const SampleArgs &s) { samp_ = s; }   // consumed by the next advance() batch
     void enable_timing(bool on) { timing_ = on; }
     double kernel_ms() const { return kernel_ms_; }

@@ -1190,7 +1190,8 @@ int lm_bodies_per_wave(int n) {
 }
 
 // which per-step force kernel: 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
-int force_kernel_kind(int n) {
+int force_kernel_kind(int n, int requested) {
+    if (requested == 1 || requested == 2) return requested;
     static const int forced = [] {
         const char *e = getenv("EPH_FORCE");           // tuning override: "wave" | "wg"
         if (!e) return 0;
@@ -1201,9 +1202,9 @@ int force_kernel_kind(int n) {
     return (n > 2048 && n < 8192) ? 2 : 1;
 }
 
-int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out) {
+int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind) {
     if (n <= 0) return EPH_OK;
-    if (force_kernel_kind(n) == 2) {
+    if (force_kernel_kind(n, kind) == 2) {
         static const int dbg = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
         hipLaunchKernelGGL(k_accel_wg, dim3((n + kWgBodies - 1) / kWgBodies), dim3(kWgThreads), 0, s, n, npad, pos,
                            acc_init, acc_out, dbg);
@@ -1234,7 +1235,7 @@ static int launch_lm_step_L(hipStream_t s, const LmArgs &a) {
 }
 int launch_lm_step(hipStream_t s, const LmArgs &a) {
     if (a.n <= 0) return EPH_OK;
-    if (force_kernel_kind(a.n) == 2) {
+    if (force_kernel_kind(a.n, a.kind) == 2) {
         const dim3 grid((a.n + kWgBodies - 1) / kWgBodies), block(kWgThreads);
         if (a.L == 12) hipLaunchKernelGGL(k_lm_step_wg<12>, grid, block, 0, s, a);
         else if (a.L == 13) hipLaunchKernelGGL(k_lm_step_wg<13>, grid, block, 0, s, a);

@@ -134,7 +134,7 @@ int NBodyIntegration::srkn_step(double h, double *y_slot) {
     for (int s = 0; s < rk_.stages; ++s) {
         if (!rk_.fsal || s > 0 || starter_i_ == 0) {
             // problem.ode.eval(t_stage, &problem.state.y, self.ddy.zero())
-            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p))) return st;
+            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind()))) return st;
             evals_++;
         }
         // *dy = *dy + *ddy * (h * C::B[s]);  *y = *y + *dy * (h * C::A[s])
@@ -159,7 +159,7 @@ int NBodyIntegration::startup_macro_step() {
     if (time_ + h_ == time_) return EPH_STEP_SIZE_UNDERFLOW;
     int st;
     if (starter_i_ / (uint32_t)substeps_ == 0) {
-        if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_)))) return st;
+        if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_), force_kind()))) return st;
         evals_++;
     }
     const int nslot = (cur_ + L_ - 1) % L_;
@@ -167,7 +167,7 @@ int NBodyIntegration::startup_macro_step() {
     cur_ = nslot;   // from here on the working state is the new front, as in the reference after the clone_from
     for (int s = 0; s < substeps_; ++s)
         if ((st = srkn_step(h_sub_, Yslot(nslot)))) return st;
-    if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot)))) return st;
+    if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot), force_kind()))) return st;
     evals_++;
     return EPH_OK;
 }
@@ -194,8 +194,9 @@ int NBodyIntegration::lm_batch(int64_t k) {
     a.hh = h_ * h_ * lm_.inv_beta_d;     // h * h * Ratio::from_recip(C::BETA_D)
     a.hc = h_ * lm_.inv_cowell_d;        // h * Ratio::from_recip(Self::BETA_D)
     a.samp = samp_;
+    a.kind = force_kind();
     int st;
-    const bool persistent = n_ <= kSmallN && path_ != 1;
+    const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3;
     if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
     if (timing_) EPH_HIP(hipEventRecord(ev0_, stream_));
     if (persistent) {

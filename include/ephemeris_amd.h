@@ -91,8 +91,9 @@ int32_t eph_nbody_clone(eph_nbody *h, eph_nbody **out);   /* #[derive(Clone)] on
 void eph_nbody_destroy(eph_nbody *h);
 /* number of right-hand-side evaluations performed so far */
 int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count);
-/* Which device path `advance` uses: 0 = auto, 1 = one launch per step (all CUs), 2 = persistent single
- * workgroup (n <= 64 only). For tests and tuning. */
+/* Which device path `advance` uses: 0 = auto, 1 = one launch per step with the one-wave-per-block force kernel,
+ * 2 = persistent single workgroup (n <= 64 only), 3 = one launch per step with the workgroup-specialised force
+ * kernel. All paths produce identical bits; for tests and tuning. */
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path);
 /* device time of the steady-state kernels launched by this handle so far, measured with HIP events on the
  * handle's stream: total milliseconds and launch count (used by bench.py for the roofline figure) */
