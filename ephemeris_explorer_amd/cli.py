@@ -1,0 +1,92 @@
+"""Headless driver for the reference's on-disk formats: load a system directory -> +-N years of
+ephemeris (forward and backward propagators, as `compute_ephemerides_bodies` does,
+ephemeris_explorer/src/load/mod.rs:673-687) -> every ship under ships/ -> summary JSON; optional state.json export
+at an epoch (ephemeris_explorer/src/ui/windows/export.rs:222-256).
+
+    python -m ephemeris_explorer_amd.cli tests/golden/systems/full_solar_system_2433282.5 --years 2
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+from . import BACKWARD, FORWARD, AdaptiveParams, Ephemeris, NBodyPropagator, SpacecraftBatch
+from .systems import format_epoch, load_ship, load_system
+
+SEC_PER_YEAR = 365.0 * 86400.0      # Duration::from_days(365.0 * 2.0) for two years (load/mod.rs:674)
+
+
+def export_state(system, solution, at, path):
+    """state.json of the massive bodies at `at` (export.rs:222-256): name, mu, position, velocity per body."""
+    bodies = []
+    for b, name in enumerate(system.names):
+        pos, vel, inside = solution.eval(b, [at])
+        if not inside[0]:
+            raise ValueError(f"{name}: epoch outside the computed ephemeris")
+        bodies.append({"name": name, "mu": float(system.mu[b]), "position": [float(x) for x in pos[0]],
+                       "velocity": [float(x) for x in vel[0]]})
+    Path(path).write_text(json.dumps({"name": system.name, "epoch": format_epoch(at), "bodies": bodies}, indent=4))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("system", type=Path)
+    ap.add_argument("--years", type=float, default=2.0)
+    ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--export-state", nargs=2, metavar=("EPOCH", "PATH"),
+                    help='write a state.json at "YYYY-MM-DD HH:MM:SS" from the forward ephemeris')
+    args = ap.parse_args(argv)
+
+    system = load_system(args.system)
+    out = {"system": system.name, "bodies": system.n, "dt_s": system.dt, "epoch": format_epoch(system.epoch)}
+    t0 = time.time()
+    fwd = NBodyPropagator.from_system(system, FORWARD)
+    sol_f = fwd.propagate(system.epoch + args.years * SEC_PER_YEAR)
+    out["forward"] = {"reached": format_epoch(fwd.time()), "steps": fwd.state()[3],
+                      "polynomials": int(sum(sol_f.info(b)[2] for b in range(system.n)))}
+    if not args.no_backward:
+        bwd = NBodyPropagator.from_system(system, BACKWARD)
+        sol_b = bwd.propagate(system.epoch - args.years * SEC_PER_YEAR)
+        out["backward"] = {"reached": format_epoch(bwd.time()), "steps": bwd.state()[3],
+                           "polynomials": int(sum(sol_b.info(b)[2] for b in range(system.n)))}
+    out["ephemeris_seconds"] = time.time() - t0
+
+    ships = sorted((args.system / "ships").glob("*.json")) if (args.system / "ships").is_dir() else []
+    eph = Ephemeris(sol_f, system.mu) if ships else None
+    out["ships"] = []
+    for path in ships:
+        ship = load_ship(path)
+        entry = {"name": ship.name, "integrator": ship.integrator}
+        if ship.integrator == "Fine45":
+            entry["skipped"] = "ERKNG (Fine45) is not built yet"
+            out["ships"].append(entry)
+            continue
+        try:
+            burns = [(b.start, b.start + b.duration, b.acceleration,
+                      system.names.index(b.reference) if b.reference else -1) for b in ship.burns]
+        except ValueError as e:
+            entry["skipped"] = f"burn reference not in this system: {e}"
+            out["ships"].append(entry)
+            continue
+        batch = SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator,
+                                AdaptiveParams.default(ship.tolerance), [burns], max_knots=1 << 18)
+        batch.propagate(ship.end)
+        st = batch.status()
+        fin = batch.state()
+        entry.update({"status": int(st["status"][0]), "knots": int(st["nknots"][0]), "steps": int(st["steps"][0]),
+                      "final_epoch": format_epoch(fin["t"][0]), "final_position_km": [float(x) for x in fin["pos"][0]]})
+        out["ships"].append(entry)
+    if args.export_state:
+        from .systems import parse_epoch
+        export_state(system, sol_f, parse_epoch(args.export_state[0]), args.export_state[1])
+        out["exported"] = args.export_state[1]
+    json.dump(out, sys.stdout, indent=1)
+    print()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

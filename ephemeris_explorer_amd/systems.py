@@ -43,6 +43,30 @@ def parse_epoch(s):
     return float(secs) + float(millis) / 1000.0
 
 
+def _civil_from_days(z):
+    z += 719468
+    era = (z if z >= 0 else z - 146096) // 146097
+    doe = z - era * 146097
+    yoe = (doe - doe // 1460 + doe // 36524 - doe // 146096) // 365
+    y = yoe + era * 400
+    doy = doe - (365 * yoe + yoe // 4 - yoe // 100)
+    mp = (5 * doy + 2) // 153
+    d = doy - (153 * mp + 2) // 5 + 1
+    m = mp + (3 if mp < 10 else -9)
+    return y + (m <= 2), m, d
+
+
+def format_epoch(seconds):
+    """f64 seconds since 1958-01-01 TAI -> "YYYY-MM-DD HH:MM:SS.mmm" (the form state.json / ships use)."""
+    ms_total = int(round(seconds * 1000.0))
+    days, ms = divmod(ms_total, 86400000)
+    y, m, d = _civil_from_days(days + _days_from_civil(1958, 1, 1))
+    h, ms = divmod(ms, 3600000)
+    mi, ms = divmod(ms, 60000)
+    sec, ms = divmod(ms, 1000)
+    return f"{y:04d}-{m:02d}-{d:02d} {h:02d}:{mi:02d}:{sec:02d}.{ms:03d}"
+
+
 _UNITS_MS = {}
 for _names, _ms in (
     (("y", "yr", "yrs", "year", "years"), int(365.25 * 86400.0 * 1000.0)),

@@ -167,3 +167,22 @@ def test_controller_pow_is_the_same_correctly_rounded_value(gpu):
         dev = gpu.debug_pow(x, y)
         ref = np.array([orc.cr_pow(v, y) for v in x])
         assert np.array_equal(bits(dev), bits(ref))
+
+
+def test_headless_cli_on_a_reference_system(gpu, tmp_path, capsys):
+    """system directory -> +-ephemeris -> ships, plus a state.json export that loads back."""
+    import json
+    from ephemeris_explorer_amd import cli
+    from ephemeris_explorer_amd.systems import load_system as ls
+    out_state = tmp_path / "state.json"
+    rc = cli.main([str(SYSTEMS / "sun_earth_moon_2433282.5"), "--years", "0.2", "--export-state",
+                   "1950-02-01 00:00:00", str(out_state)])
+    assert rc == 0
+    rep = json.loads(capsys.readouterr().out)
+    assert rep["bodies"] == 3 and rep["forward"]["polynomials"] > 0 and rep["backward"]["polynomials"] > 0
+    ship = rep["ships"][0]
+    assert ship["name"] == "Earth Station" and ship["status"] == 0 and ship["knots"] > 10
+    (tmp_path / "ephemeris.json").write_text((SYSTEMS / "sun_earth_moon_2433282.5" / "ephemeris.json").read_text())
+    back = ls(tmp_path)
+    assert back.n == 3 and back.epoch == parse_epoch("1950-02-01 00:00:00")
+    assert np.linalg.norm(back.pos[1] - back.pos[0]) > 1.4e8        # Earth is 1 au from the Sun
