@@ -225,7 +225,9 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     return true;
 }
 
-template <int S, bool FSAL>
+// NYS = false: ERK pair on the 6-vector (explicit.rs).  NYS = true: ERKNG pair on SecondOrderState<[DVec3; 1]>
+// (nystrom/explicit_generalized.rs:97-170, the app's Fine45): k[s][0..2] hold dk[s].
+template <int S, bool FSAL, bool NYS = false>
 __global__ void __launch_bounds__(64) k_craft_propagate(const CraftArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_craft) return;
@@ -287,6 +289,25 @@ __global__ void __launch_bounds__(64) k_craft_propagate(const CraftArgs a) {
                 if (!ok) continue;
                 const double ti = time + h * a.rk.C[s];
                 double yi[6];
+                if (NYS) {
+                    const double hc = h * a.rk.C[s];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { yi[d] = y[d] + y[3 + d] * hc; yi[3 + d] = y[3 + d]; }
+#pragma unroll
+                    for (int j = 0; j < s; ++j) {
+                        const double hhap = h * h * a.rk.A[s][j], hav = h * a.rk.A2[s & 7][j & 7];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            yi[d] = yi[d] + k[j][d] * hhap;
+                            yi[3 + d] = yi[3 + d] + k[j][d] * hav;
+                        }
+                    }
+                    double out[6];
+                    ok = craft_rhs(a, sg, ti, yi, out);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) k[s][d] = out[3 + d];
+                    continue;
+                }
 #pragma unroll
                 for (int d = 0; d < 6; ++d) yi[d] = y[d];
 #pragma unroll
@@ -298,23 +319,47 @@ __global__ void __launch_bounds__(64) k_craft_propagate(const CraftArgs a) {
                 ok = craft_rhs(a, sg, ti, yi, k[s]);
             }
             if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
+            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (NYS) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const double hb = h * a.rk.B[s];
+                for (int d = 0; d < 3; ++d) y[d] = y[d] + y[3 + d] * h;
 #pragma unroll
-                for (int d = 0; d < 6; ++d) y[d] = y[d] + k[s][d] * hb;
+                for (int s = 0; s < S; ++s) {
+                    const double hhbp = h * h * a.rk.B[s], hbv = h * a.rk.B2[s & 7];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        y[d] = y[d] + k[s][d] * hhbp;
+                        y[3 + d] = y[3 + d] + k[s][d] * hbv;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double hhep = h * h * a.rk.E[s], hev = h * a.rk.E2[s & 7];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        e[d] = e[d] + k[s][d] * hhep;
+                        e[3 + d] = e[3 + d] + k[s][d] * hev;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double hb = h * a.rk.B[s];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) y[d] = y[d] + k[s][d] * hb;
+                }
+                // RKEmbedded::error
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double he = h * a.rk.E[s];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) e[d] = e[d] + k[s][d] * he;
+                }
             }
             time = time + h;
             rk_i += 1;
             n_att += 1;
-            // RKEmbedded::error + AbsTol::err_over_tol
-            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const double he = h * a.rk.E[s];
-#pragma unroll
-                for (int d = 0; d < 6; ++d) e[d] = e[d] + k[s][d] * he;
-            }
+            // AbsTol::err_over_tol
             const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
             const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
             const double err = fmax(pm, vm);
@@ -409,7 +454,10 @@ static int craft_launch(hipStream_t s, const CraftArgs &a) {
 #define EPH_CRAFT_CASE(S_, F_) hipLaunchKernelGGL((k_craft_propagate<S_, F_>), grid, block, 0, s, a)
     const int S = a.rk.stages;
     const bool F = a.rk.fsal != 0;
-    if (S == 6 && !F) EPH_CRAFT_CASE(6, false);
+    if (a.rk.nystrom) {
+        if (S == 7 && F) hipLaunchKernelGGL((k_craft_propagate<7, true, true>), grid, block, 0, s, a);
+        else return EPH_ERR_UNSUPPORTED;
+    } else if (S == 6 && !F) EPH_CRAFT_CASE(6, false);
     else if (S == 7 && F) EPH_CRAFT_CASE(7, true);
     else if (S == 7 && !F) EPH_CRAFT_CASE(7, false);
     else if (S == 9 && !F) EPH_CRAFT_CASE(9, false);

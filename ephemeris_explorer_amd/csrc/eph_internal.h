@@ -53,6 +53,10 @@ struct ErkCoeffs {             // ERK + embedded pair; A[s][j] for j < s   (inte
     int stages = 0, order = 0, order_embedded = 0;
     int fsal = 0, has_embedded = 0;
     double A[16][16], B[16], C[16], E[16];
+    // nystrom = 1: ERKNG pair (runge_kutta/nystrom/explicit_generalized.rs:14-41), at most 8 stages:
+    // A = AP, A2 = AV, B = BP, B2 = BV, E = EP, E2 = EV
+    int nystrom = 0;
+    double A2[8][8], B2[8], E2[8];
 };
 bool find_erk(const char *name, ErkCoeffs *out);
 bool find_srkn(const char *name, SrknCoeffs *out);

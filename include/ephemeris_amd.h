@@ -169,7 +169,8 @@ typedef struct eph_adaptive_params {
 } eph_adaptive_params;
 
 /* n_craft spacecraft: t0[i], pos_xyz[3i..], vel_xyz[3i..]; method = an embedded ERK pair name ("Verner87",
- * "DormandPrince54", "DormandPrince87", "CashKarp45", "Fehlberg45", "Tsitouras75", "Verner98").
+ * "DormandPrince54", "DormandPrince87", "CashKarp45", "Fehlberg45", "Tsitouras75", "Verner98") or the embedded
+ * ERKNG pair "Fine45" (runge_kutta/nystrom/explicit_generalized.rs; dynamics/spacecraft.rs:797) -- the app's eight.
  * Timelines (Timeline::new, spacecraft.rs:129-152) in CSR form: craft i owns burns burn_offset[i] ..
  * burn_offset[i+1]-1: [burn_start, burn_end), burn_acc_xyz in the burn frame, burn_ref = body index whose TNB frame
  * the burn is given in, or -1 for the inertial frame. burn_offset may be NULL (no burns). max_knots = slab depth

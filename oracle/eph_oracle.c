@@ -865,12 +865,37 @@ typedef int (*ode_fn)(void *ctx, double t, const double *y, double *dy);
 /* ERK<C, [State; STAGES]> + EERK  integration/src/runge_kutta/explicit.rs:40-141 */
 typedef struct {
     int stages, order, order_embedded, fsal, dim;
+    /* nystrom = 0: ERK (A, B, C, E). nystrom = 1: ERKNG on a SecondOrderState (y = state[0..2], dy = state[3..5]):
+     * A = AP, A2 = AV, B = BP, B2 = BV, E = EP, E2 = EV; k[s][0..2] = dk[s] */
+    int nystrom;
     double A[ERK_MAX_STAGES][ERK_MAX_STAGES], B[ERK_MAX_STAGES], C[ERK_MAX_STAGES], E[ERK_MAX_STAGES];
+    double A2[ERK_MAX_STAGES][ERK_MAX_STAGES], B2[ERK_MAX_STAGES], E2[ERK_MAX_STAGES];
     uint32_t i;
     double k[ERK_MAX_STAGES][ERK_MAX_DIM];
 } erk_t;
+static const EPH_ERKNG_TABLE *find_erkng(const char *name) {
+    for (int i = 0; i < EPH_N_ERKNG_TABLES; ++i)
+        if (!strcmp(eph_erkng_tables[i].name, name)) return &eph_erkng_tables[i];
+    return NULL;
+}
 
 static int erk_init(erk_t *r, const char *name, int dim, const double *state) {
+    const EPH_ERKNG_TABLE *g = find_erkng(name);
+    if (g) {                                                  /* ERKNG<C, [V; STAGES], V>::from_problem  explicit_generalized.rs:87-95 */
+        if (g->stages > ERK_MAX_STAGES || dim != 6) return ORC_BAD_ARGUMENT;
+        memset(r, 0, sizeof(*r));
+        r->nystrom = 1;
+        r->stages = g->stages; r->order = g->order; r->order_embedded = g->order_embedded; r->fsal = g->fsal; r->dim = 6;
+        int idx = 0;
+        for (int s = 0; s < g->stages; ++s) {
+            for (int j = 0; j < s; ++j) { r->A[s][j] = ratio_f64(g->AP[idx]); r->A2[s][j] = ratio_f64(g->AV[idx]); ++idx; }
+            r->B[s] = ratio_f64(g->BP[s]); r->B2[s] = ratio_f64(g->BV[s]); r->C[s] = ratio_f64(g->C[s]);
+            r->E[s] = ratio_f64(g->EP[s]); r->E2[s] = ratio_f64(g->EV[s]);
+        }
+        for (int s = 0; s < g->stages; ++s)                   /* dk = [state.dy.clone(); STAGES] */
+            for (int d = 0; d < 3; ++d) r->k[s][d] = state[3 + d];
+        return ORC_OK;
+    }
     const EPH_ERK_TABLE *t = find_erk(name);
     if (!t || t->stages > ERK_MAX_STAGES || dim > ERK_MAX_DIM) return ORC_BAD_ARGUMENT;
     memset(r, 0, sizeof(*r));
@@ -888,7 +913,45 @@ static int erk_init(erk_t *r, const char *name, int dim, const double *state) {
     return ORC_OK;
 }
 /* ERK::advance  explicit.rs:72-106 */
+/* ERKNG::advance  integration/src/runge_kutta/nystrom/explicit_generalized.rs:97-143 (SecondOrderODEGeneral) */
+static int erkng_advance(erk_t *r, double h, double *time, double *state, ode_fn f, void *ctx, uint64_t *evals) {
+    const int S = r->stages;
+    double *y = state, *dy = state + 3;
+    for (int s = 0; s < S; ++s) {
+        if (r->fsal && s == 0 && r->i > 0) {                  /* self.dk.swap(s, STAGES - 1); continue */
+            for (int d = 0; d < 3; ++d) { double t = r->k[0][d]; r->k[0][d] = r->k[S - 1][d]; r->k[S - 1][d] = t; }
+            continue;
+        }
+        const double ti = *time + h * r->C[s];
+        double sv[6], out[6];
+        const double hc = h * r->C[s];
+        for (int d = 0; d < 3; ++d) { sv[d] = y[d]; sv[d] = sv[d] + dy[d] * hc; sv[3 + d] = dy[d]; }
+        for (int j = 0; j < s; ++j) {
+            const double hhap = h * h * r->A[s][j], hav = h * r->A2[s][j];
+            for (int d = 0; d < 3; ++d) {
+                sv[d] = sv[d] + r->k[j][d] * hhap;
+                sv[3 + d] = sv[3 + d] + r->k[j][d] * hav;
+            }
+        }
+        if (evals) (*evals)++;
+        int st = f(ctx, ti, sv, out);                         /* ddy = context + manoeuvre (spacecraft.rs:319-331) */
+        if (st) return st;
+        for (int d = 0; d < 3; ++d) r->k[s][d] = out[3 + d];
+    }
+    for (int d = 0; d < 3; ++d) y[d] = y[d] + dy[d] * h;
+    for (int i = 0; i < S; ++i) {
+        const double hhbp = h * h * r->B[i], hbv = h * r->B2[i];
+        for (int d = 0; d < 3; ++d) {
+            y[d] = y[d] + r->k[i][d] * hhbp;
+            dy[d] = dy[d] + r->k[i][d] * hbv;
+        }
+    }
+    *time = *time + h;
+    r->i += 1;
+    return ORC_OK;
+}
 static int erk_advance(erk_t *r, double h, double *time, double *state, ode_fn f, void *ctx, uint64_t *evals) {
+    if (r->nystrom) return erkng_advance(r, h, time, state, f, ctx, evals);
     double yi[ERK_MAX_DIM];
     const int S = r->stages, D = r->dim;
     for (int s = 0; s < S; ++s) {
@@ -918,6 +981,16 @@ static int erk_advance(erk_t *r, double h, double *time, double *state, ode_fn f
 /* RKEmbedded::error  explicit.rs:123-132 */
 static void erk_error(const erk_t *r, double h, double *err) {
     for (int d = 0; d < r->dim; ++d) err[d] = 0.0;
+    if (r->nystrom) {                                         /* explicit_generalized.rs:153-170 */
+        for (int i = 0; i < r->stages; ++i) {
+            const double hhep = h * h * r->E[i], hev = h * r->E2[i];
+            for (int d = 0; d < 3; ++d) {
+                err[d] = err[d] + r->k[i][d] * hhep;
+                err[3 + d] = err[3 + d] + r->k[i][d] * hev;
+            }
+        }
+        return;
+    }
     for (int i = 0; i < r->stages; ++i) {
         const double he = h * r->E[i];
         for (int d = 0; d < r->dim; ++d) err[d] = err[d] + r->k[i][d] * he;
@@ -1237,7 +1310,7 @@ orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, c
                          const double *burn_start, const double *burn_end, const double *burn_acc,
                          const int32_t *burn_ref) {
     const EPH_ERK_TABLE *tab = find_erk(method);
-    if (!tab || !tab->E || strlen(method) >= 32) return NULL;
+    if (!((tab && tab->E) || find_erkng(method)) || strlen(method) >= 32) return NULL;
     orc_craft *c = calloc(1, sizeof(*c));
     c->eph = eph;
     c->mu = malloc(sizeof(double) * (size_t)(eph->n > 0 ? eph->n : 1));

@@ -363,6 +363,58 @@ class Erk:
         return e
 
 
+class Erkng:
+    """ERKNG + embedded error on SecondOrderState<[DVec3; 1]> (nystrom/explicit_generalized.rs:59-170); state = y(3) + dy(3),
+    k[s] = dk[s] (3 values). Same interface as Erk; f returns the 6-vector derivative, whose last three are ddy."""
+
+    def __init__(self, name, state):
+        t = tables()["methods"][name]
+        self.AP = [[_ratio(r) for r in row] for row in t["AP"]["ratio"]]
+        self.AV = [[_ratio(r) for r in row] for row in t["AV"]["ratio"]]
+        self.BP, self.BV = [_ratio(r) for r in t["BP"]["ratio"]], [_ratio(r) for r in t["BV"]["ratio"]]
+        self.EP, self.EV = [_ratio(r) for r in t["EP"]["ratio"]], [_ratio(r) for r in t["EV"]["ratio"]]
+        self.C = [_ratio(r) for r in t["C"]["ratio"]]
+        self.fsal = t["FSAL"]
+        self.lower = min(int(t["ORDER"]), int(t["ORDER_EMBEDDED"]))
+        self.i = 0
+        self.k = [list(state[3:]) for _ in self.C]
+
+    def advance(self, h, t, state, f):
+        S = len(self.C)
+        y, dy = list(state[:3]), list(state[3:])
+        for s in range(S):
+            if self.fsal and s == 0 and self.i > 0:
+                self.k[0], self.k[S - 1] = self.k[S - 1], self.k[0]
+                continue
+            ti = t + h * self.C[s]
+            hc = h * self.C[s]
+            yi = [a + v * hc for a, v in zip(y, dy)]
+            dyi = list(dy)
+            for j in range(s):
+                hhap, hav = h * h * self.AP[s][j], h * self.AV[s][j]
+                yi = [a + kk * hhap for a, kk in zip(yi, self.k[j])]
+                dyi = [a + kk * hav for a, kk in zip(dyi, self.k[j])]
+            out = f(ti, yi + dyi)
+            if out is None:
+                return None
+            self.k[s] = out[3:]
+        y = [a + v * h for a, v in zip(y, dy)]
+        for i in range(S):
+            hhbp, hbv = h * h * self.BP[i], h * self.BV[i]
+            y = [a + kk * hhbp for a, kk in zip(y, self.k[i])]
+            dy = [a + kk * hbv for a, kk in zip(dy, self.k[i])]
+        self.i += 1
+        return t + h, y + dy
+
+    def error(self, h):
+        ey, edy = [0.0] * 3, [0.0] * 3
+        for i in range(len(self.C)):
+            hhep, hev = h * h * self.EP[i], h * self.EV[i]
+            ey = [a + kk * hhep for a, kk in zip(ey, self.k[i])]
+            edy = [a + kk * hev for a, kk in zip(edy, self.k[i])]
+        return ey + edy
+
+
 class Craft:
     """SpacecraftPropagator with an adaptive ERK pair and the CubicHermiteSpline solout
     (ephemeris/src/propagators/spacecraft.rs:415-695, integration/src/runge_kutta/mod.rs:188-285,396-440,
@@ -392,7 +444,7 @@ class Craft:
         self.knots = [(self.t, tuple(self.y))]
 
     def reset(self):
-        self.rk = Erk(self.method, self.y)
+        self.rk = (Erkng if "AP" in tables()["methods"][self.method] else Erk)(self.method, self.y)
         self.next_h = self.h_init
         self.n = 0
 

@@ -85,7 +85,7 @@ def test_mars_transfer_scenario(gpu, simple_system):
 
 
 @pytest.mark.parametrize("method", ["CashKarp45", "DormandPrince54", "DormandPrince87", "Fehlberg45", "Tsitouras75",
-                                    "Verner87", "Verner98"])
+                                    "Verner87", "Verner98", "Fine45"])
 def test_every_embedded_pair(gpu, simple_system, method):
     s, sol, eph, osol = simple_system
     ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")

@@ -61,7 +61,7 @@ def test_reference_spacecraft_scenario(scenario):
         assert distance("Mars", "1951-01-01 00:00:00") < 10_000.0
 
 
-@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "CashKarp45"])
+@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "CashKarp45", "Fine45"])
 def test_c_oracle_equals_python_restatement_massless(scenario, method):
     s, eph, ship, burns = scenario
     pe = []
