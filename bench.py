@@ -132,15 +132,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-steps", type=int, default=60, help="oracle steps timed for cpu_baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bodies", type=int, default=N_BODIES, help=argparse.SUPPRESS)
-    ap.add_argument("--workload", choices=["nbody", "craft"], default="nbody",
-                    help="nbody (default, the BASELINE metric) or craft: the massless sweep of configs[3], sharded "
-                         "over the ranks (steps = sweeps of `--craft-days` days over `--craft` spacecraft)")
+    ap.add_argument("--bodies", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--workload", choices=["nbody", "craft", "nbody-sharded"], default="nbody",
+                    help="nbody (default, the BASELINE metric: per-rank replicas) | craft: the massless sweep of "
+                         "configs[3], sharded over the ranks (steps = sweeps of `--craft-days` days over `--craft` "
+                         "spacecraft) | nbody-sharded: ONE system of --bodies (default 65536, configs[4] in f64) "
+                         "partitioned by target body over the ranks, one RCCL all-gather per step (strong scaling)")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl", help="nbody-sharded exchange")
     ap.add_argument("--craft", type=int, default=262144)
     ap.add_argument("--craft-days", type=float, default=0.25)
     args = ap.parse_args()
     if args.workload == "craft":
         return craft_main(args)
+    sharded = args.workload == "nbody-sharded"
+    if args.bodies is None:
+        args.bodies = 65536 if sharded else N_BODIES
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,9 +173,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.bodies
-    # rank r integrates its own replica (seed + r): independent systems, no exchange
-    pos, vel, mu = plummer(n, seed=20260926 + rank)
+    # rank r integrates its own replica (seed + r): independent systems, no exchange -- or, sharded, every rank
+    # builds the SAME system and owns n/world target bodies of it
+    pos, vel, mu = plummer(n, seed=20260926 + (0 if sharded else rank))
     g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    if sharded:
+        from ephemeris_explorer_amd.parallel import shard_nbody
+        shard_nbody(g, dist, transport=args.transport, device="cuda")
     g.advance(12)                       # multistep start-up, reported separately in DESIGN.md
     g.advance(args.warmup)
     g.enable_timing(True)
@@ -186,14 +196,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     from ephemeris_explorer_amd.parallel import reduce_timing
-    units, elapsed = reduce_timing(elapsed, n * args.steps, dist, device="cuda")   # sum of units, MAX of time
+    units_local = n * args.steps / world if sharded else n * args.steps
+    units, elapsed = reduce_timing(elapsed, units_local, dist, device="cuda")       # sum of units, MAX of time
     ms_kernel, launches = g.kernel_time()
 
     if rank == 0:
         value = units / elapsed
         launch_s = ms_kernel * 1e-3 / max(launches, 1)      # HIP events on the handle's stream, timed region only
-        achieved_gbs = BYTES_PER_BODY_STEP * n / launch_s / 1e9
-        flops = (FLOP_PER_INTERACTION * (n - 1) + 231.0) * n
+        nt = n // world if sharded else n                   # target bodies one launch of this rank advances
+        achieved_gbs = BYTES_PER_BODY_STEP * nt / launch_s / 1e9
+        flops = (FLOP_PER_INTERACTION * (n - 1) + 231.0) * nt
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected and corrected
         # as MI355X_MICROARCH.md prescribes) of this same command, committed under profiles/ -- not measurable live
         traffic, traffic_src = None, None
@@ -205,15 +217,22 @@ def main():
             "metric": "body-steps/s", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"plummer_{n}_f64_qt12 (BASELINE.json configs[2]; h=1/1024, seed 20260926+rank)",
-                       "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}"},
+            "config": ({"workload": f"plummer_{n}_f64_qt12, one system partitioned by target body "
+                                    f"(BASELINE.json configs[4] in f64; h=1/1024, seed 20260926)",
+                        "bodies_per_gpu": nt, "method": "QuinlanTremaine12",
+                        "parallelism": f"target-partition x{world}, 1 all-gather of {32 * n} B per step "
+                                       f"({args.transport})"} if sharded else
+                       {"workload": f"plummer_{n}_f64_qt12 (BASELINE.json configs[2]; h=1/1024, seed 20260926+rank)",
+                        "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}"}),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_lm_step_wg<12>", "launch_us": launch_s * 1e6, "launches": launches,
-                         "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * n,
-                         "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see fp64"},
+                         "kernel": "k_lm_step_wg<12>" if 2048 < nt < 8192 else "k_lm_step<BPW,12>",
+                         "launch_us": launch_s * 1e6, "launches": launches,
+                         "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * nt,
+                         "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see fp64"
+                                 + ("; launch_us includes the per-step all-gather" if sharded else "")},
             "fp64": {"bound": "fp64_valu", "achieved": flops / launch_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "flop_per_launch": flops},

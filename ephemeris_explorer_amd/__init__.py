@@ -27,12 +27,14 @@ STEP_SIZE_UNDERFLOW, MAX_ITERATIONS_REACHED, BOUND_REACHED, EVAL_FAILED, SOLOUT_
 ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = -1, -2, -3, -4, -5
 
 # every symbol include/ephemeris_amd.h declares (tests check the .so exports exactly these)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
+
 ABI_SYMBOLS = [
     "eph_abi_version", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
     "eph_device_name", "eph_srkn_coeffs", "eph_elm2_coeffs", "eph_accel_eval",
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
-    "eph_nbody_enable_timing", "eph_nbody_sync",
+    "eph_nbody_enable_timing", "eph_nbody_sync", "eph_rccl_unique_id", "eph_nbody_shard", "eph_nbody_shard_info",
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
@@ -115,6 +117,9 @@ def _lib():
     L.eph_nbody_destroy.restype = None
     L.eph_nbody_eval_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.eph_nbody_set_path.argtypes = [vp, i32]
+    L.eph_rccl_unique_id.argtypes = [vp]
+    L.eph_nbody_shard.argtypes = [vp, i32, i32, vp, EXCHANGE_FN, vp]
+    L.eph_nbody_shard_info.argtypes = [vp, _i32p, _i32p, C.POINTER(C.c_uint64)]
     L.eph_nbody_kernel_time.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.eph_nbody_enable_timing.argtypes = [vp, i32]
     L.eph_nbody_sync.argtypes = [vp]
@@ -237,6 +242,13 @@ def debug_inv_r3(n2):
     return fast, ieee
 
 
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls it and distributes the 128 bytes)."""
+    out = (C.c_char * 128)()
+    _check(_lib().eph_rccl_unique_id(out), "eph_rccl_unique_id")
+    return bytes(out.raw)
+
+
 class NBodyIntegration:
     """Integration<NBodyProblem<DVec3>, M> (no solout). method: "QuinlanTremaine12", "Stormer13" or an SRKN name."""
 
@@ -297,6 +309,35 @@ class NBodyIntegration:
         h_ = C.c_void_p()
         _check(self._L.eph_nbody_clone(self._h, C.byref(h_)), "eph_nbody_clone")
         return NBodyIntegration(None, None, None, 0, 0, _handle=(h_, self.n))
+
+    def shard(self, rank, world, unique_id=None, exchange=None):
+        """Partition the system by target body over `world` ranks (eph_nbody_shard). unique_id: the 128 bytes of
+        rccl_unique_id() from rank 0 (RCCL transport), or exchange: callable(device_ptr, slice_bytes, rank, world,
+        hip_stream) -> 0 performing the in-place all-gather (see parallel.host_staged_exchange)."""
+        cb = None
+        if exchange is not None:
+            def _tramp(ctx, buf, nbytes, r, w, stream):
+                try:
+                    return int(exchange(buf, nbytes, r, w, stream) or 0)
+                except Exception:                      # never unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = EXCHANGE_FN(_tramp)
+        self._exchange_cb = cb                          # keep the trampoline alive as long as the handle
+        uid = None
+        if unique_id is not None:
+            if len(unique_id) != 128:
+                raise ValueError("unique_id must be 128 bytes")
+            uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _check(self._L.eph_nbody_shard(self._h, int(rank), int(world), uid, cb if cb else EXCHANGE_FN(0), None),
+               "eph_nbody_shard")
+        return self
+
+    def shard_info(self):
+        lo, hi, g = C.c_int32(), C.c_int32(), C.c_uint64()
+        _check(self._L.eph_nbody_shard_info(self._h, C.byref(lo), C.byref(hi), C.byref(g)), "eph_nbody_shard_info")
+        return lo.value, hi.value, g.value
 
     def __del__(self):
         if getattr(self, "_owned", False) and getattr(self, "_h", None):

@@ -68,6 +68,7 @@ const char *eph_status_string(int32_t st) {
         case EPH_ERR_HIP: return "HIP runtime error";
         case EPH_ERR_UNSUPPORTED: return "unsupported configuration";
         case EPH_ERR_OUT_OF_MEMORY: return "out of memory";
+        case EPH_ERR_COMM: return "exchange (RCCL / callback) failed";
         default: return "unknown status";
     }
 }
@@ -205,6 +206,34 @@ int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on) {
 int32_t eph_nbody_sync(eph_nbody *h) {
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
     return h->p->sync();
+}
+
+// ---- target-partitioned multi-GPU run (shard.cpp) -----------------------------------------------------
+int32_t eph_rccl_unique_id(void *out128) {
+    EPH_GUARD_BEGIN
+    if (!out128) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    return rccl_unique_id(out128);
+    EPH_GUARD_END
+}
+int32_t eph_nbody_shard(eph_nbody *h, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
+                        void *ctx) {
+    EPH_GUARD_BEGIN
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (hipSetDevice(h->p->device()) != hipSuccess) return EPH_ERR_HIP;
+    std::shared_ptr<Exchange> x;
+    int st = Exchange::create(rank, world, rccl_unique_id, fn, ctx, &x);
+    if (st) return st;
+    return h->p->set_shard(std::move(x));
+    EPH_GUARD_END
+}
+int32_t eph_nbody_shard_info(eph_nbody *h, int32_t *lo, int32_t *hi, uint64_t *gathers) {
+    if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (lo) *lo = h->p->shard_lo();
+    if (hi) *hi = h->p->shard_hi();
+    if (gathers) *gathers = h->p->gathers();
+    return EPH_OK;
 }
 
 // ---- eph_prop ---------------------------------------------------------------------------------------

@@ -72,6 +72,7 @@ struct SampleArgs {            // solout sampling schedule for one batch (device
 
 struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm_step / k_lm_persistent)
     int n, npad, L, cur;       // cur = ring slot of the level whose acceleration is evaluated
+    int lo, hi;                // target bodies [lo, hi) of this launch (0, n unless the system is sharded over ranks)
     const Body4 *pos_cur;      // packed positions of that level
     Body4 *pos_next;           // packed positions of the next level (written when do_predict)
     double *Y, *A, *V;
@@ -86,8 +87,9 @@ struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm
 // ---- launchers (kernels.hip) --------------------------------------------------------------------
 // a[b] = acc_init[b] (or 0) + sum over the other bodies in the reference order; SoA [3][npad] output
 // kind: 0 = auto by n, 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
+// lo, hi: target bodies [lo, hi) (hi < 0: n); lo must be a multiple of 16
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out,
-                 int kind = 0);
+                 int kind = 0, int lo = 0, int hi = -1);
 int launch_pack(hipStream_t s, int n, int npad, const double *Yslot, const double *mu, Body4 *pos);
 int launch_copy3(hipStream_t s, int n, int npad, const double *src, double *dst);
 // SRKN stage update: v += a*hb ; y += v*ha ; also publishes packed positions   (symplectic.rs:90-97)

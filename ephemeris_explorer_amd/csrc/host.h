@@ -43,6 +43,27 @@ struct DevBuf {   // owning device allocation
     }
 };
 
+// The exchange step of a target-partitioned run (shard.cpp): in-place all-gather of equal slices over the ranks.
+class Exchange {
+public:
+    ~Exchange();
+    static int create(int rank, int world, const void *unique_id, eph_exchange_fn fn, void *ctx,
+                      std::shared_ptr<Exchange> *out);
+    int all_gather_inplace(void *buf, size_t slice_bytes, hipStream_t s);
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    uint64_t gathers() const { return gathers_; }
+
+private:
+    Exchange() = default;
+    int rank_ = 0, world_ = 1;
+    void *comm_ = nullptr;          // ncclComm_t
+    eph_exchange_fn fn_ = nullptr;
+    void *ctx_ = nullptr;
+    uint64_t gathers_ = 0;
+};
+int rccl_unique_id(void *out128);
+
 // Integration<NBodyProblem<DVec3>, M>: problem + integrator   (integration/src/lib.rs:394-503,
 // ephemeris/src/propagators/nbody.rs:41,93-121)
 class NBodyIntegration {
@@ -74,6 +95,12 @@ public:
     // path 1 -> per-step launches with the one-wave-per-block force, 3 -> with the workgroup-specialised force
     int force_kind() const { return path_ == 1 ? 1 : (path_ == 3 ? 2 : 0); }
     void set_sampling(const SampleArgs &s) { samp_ = s; }   // consumed by the next advance() batch
+    // target-partition the system over the ranks of `x`: this rank keeps bodies [lo, hi) current
+    int set_shard(std::shared_ptr<Exchange> x);
+    bool sharded() const { return (bool)xch_; }
+    int shard_lo() const { return lo_; }
+    int shard_hi() const { return hi_; }
+    uint64_t gathers() const { return xch_ ? xch_->gathers() : 0; }
     void enable_timing(bool on) { timing_ = on; }
     double kernel_ms() const { return kernel_ms_; }
     uint64_t kernel_launches() const { return kernel_launches_; }
@@ -89,10 +116,15 @@ private:
     double *Yslot(int s) { return Y_.p + (size_t)s * 3 * npad_; }
     double *Aslot(int s) { return A_.p + (size_t)s * 3 * npad_; }
 
+    int gather_packed(Body4 *buf);            // all-gather the ranks' slices of a packed position buffer
+    int gather_stage();                       // same for the AoS staging buffer (get_state / get_acc)
+
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     int n_ = 0, npad_ = 0, L_ = 1;
+    int lo_ = 0, hi_ = 0, slice_ = 0;         // owned targets [lo_, hi_); slice_ = npad_ / world when sharded
+    std::shared_ptr<Exchange> xch_;
     bool is_multistep_ = false;
     Elm2Coeffs lm_{};
     SrknCoeffs rk_{};

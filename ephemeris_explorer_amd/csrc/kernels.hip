@@ -415,13 +415,14 @@ __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double i
 // ------------------------------------------------------------------------------------------------------
 template <int BPW>
 __global__ void __launch_bounds__(64) k_accel(int n, int npad, const Body4 *__restrict__ pos,
-                                              const double *__restrict__ acc_init, double *__restrict__ acc_out) {
+                                              const double *__restrict__ acc_init, double *__restrict__ acc_out,
+                                              int lo, int hi) {
     __shared__ __attribute__((aligned(16))) double C[2 * 3 * BPW * kRow];   // double buffered contribution tile
     const int lane = threadIdx.x;
-    const int i0 = blockIdx.x * BPW;
+    const int i0 = lo + blockIdx.x * BPW;          // targets [lo, hi): the whole system, or this rank's shard
     const int cb = lane / 3, cc = lane % 3;
     const int my_i = i0 + cb;
-    const bool owner = lane < 3 * BPW && my_i < n;
+    const bool owner = lane < 3 * BPW && my_i < hi;
     const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
     const double a = wave_force<BPW>(pos, n, i0, init, C, lane);
     if (owner) acc_out[cc * npad + my_i] = a;
@@ -478,10 +479,10 @@ template <int BPW, int L>
 __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
     __shared__ __attribute__((aligned(16))) double C[2 * 3 * BPW * kRow];   // double buffered contribution tile
     const int lane = threadIdx.x;
-    const int i0 = blockIdx.x * BPW;
+    const int i0 = a.lo + blockIdx.x * BPW;
     const int cb = lane / 3, cc = lane % 3;
     const int my_i = i0 + cb;
-    const bool owner = lane < 3 * BPW && my_i < a.n;
+    const bool owner = lane < 3 * BPW && my_i < a.hi;
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + (owner ? my_i : 0);
 
@@ -670,12 +671,12 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
 
 __global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
                                                          const double *__restrict__ acc_init,
-                                                         double *__restrict__ acc_out, int dbg) {
+                                                         double *__restrict__ acc_out, int dbg, int lo, int hi) {
     __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i0 = blockIdx.x * kWgBodies;
+    const int i0 = lo + blockIdx.x * kWgBodies;
     const int my_i = i0 + lane / 3, cc = lane % 3;
-    const bool owner = (tid >> 6) == kWgPairWaves && lane < kWgRows && my_i < n;
+    const bool owner = (tid >> 6) == kWgPairWaves && lane < kWgRows && my_i < hi;
     const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
     const double a = wg_force(pos, n, i0, init, C, tid, dbg);
     if (owner) acc_out[cc * npad + my_i] = a;
@@ -687,10 +688,10 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
     __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool chain_wave = (tid >> 6) == kWgPairWaves;
-    const int i0 = blockIdx.x * kWgBodies;
+    const int i0 = a.lo + blockIdx.x * kWgBodies;
     const int cb = lane / 3, cc = lane % 3;
     const int my_i = i0 + cb;
-    const bool owner = chain_wave && lane < kWgRows && my_i < a.n;
+    const bool owner = chain_wave && lane < kWgRows && my_i < a.hi;
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + (owner ? my_i : 0);
 
@@ -728,8 +729,8 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
 template <int L>
 __global__ void __launch_bounds__(256) k_lm_predict(const LmArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 3 * a.n) return;
-    const int my_i = t / 3, cc = t % 3;
+    if (t >= 3 * (a.hi - a.lo)) return;
+    const int my_i = a.lo + t / 3, cc = t % 3;
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + my_i;
     double yv[L], av[L];
@@ -1202,29 +1203,33 @@ int force_kernel_kind(int n, int requested) {
     return (n > 2048 && n < 8192) ? 2 : 1;
 }
 
-int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind) {
-    if (n <= 0) return EPH_OK;
-    if (force_kernel_kind(n, kind) == 2) {
+int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind,
+                 int lo, int hi) {
+    if (hi < 0) hi = n;
+    const int nt = hi - lo;                            // targets of this launch; the kernel choice follows them
+    if (n <= 0 || nt <= 0) return EPH_OK;
+    if (force_kernel_kind(nt, kind) == 2) {
         static const int dbg = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
-        hipLaunchKernelGGL(k_accel_wg, dim3((n + kWgBodies - 1) / kWgBodies), dim3(kWgThreads), 0, s, n, npad, pos,
-                           acc_init, acc_out, dbg);
+        hipLaunchKernelGGL(k_accel_wg, dim3((nt + kWgBodies - 1) / kWgBodies), dim3(kWgThreads), 0, s, n, npad, pos,
+                           acc_init, acc_out, dbg, lo, hi);
         return done("k_accel_wg");
     }
-    const int bpw = lm_bodies_per_wave(n);
-    const dim3 grid((n + bpw - 1) / bpw), block(64);
+    const int bpw = lm_bodies_per_wave(nt);
+    const dim3 grid((nt + bpw - 1) / bpw), block(64);
     switch (bpw) {
-        case 1: hipLaunchKernelGGL(k_accel<1>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
-        case 2: hipLaunchKernelGGL(k_accel<2>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
-        case 4: hipLaunchKernelGGL(k_accel<4>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
-        default: hipLaunchKernelGGL(k_accel<8>, grid, block, 0, s, n, npad, pos, acc_init, acc_out); break;
+        case 1: hipLaunchKernelGGL(k_accel<1>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
+        case 2: hipLaunchKernelGGL(k_accel<2>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
+        case 4: hipLaunchKernelGGL(k_accel<4>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
+        default: hipLaunchKernelGGL(k_accel<8>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
     }
     return done("k_accel");
 }
 
 template <int L>
 static int launch_lm_step_L(hipStream_t s, const LmArgs &a) {
-    const int bpw = lm_bodies_per_wave(a.n);
-    const dim3 grid((a.n + bpw - 1) / bpw), block(64);
+    const int nt = a.hi - a.lo;
+    const int bpw = lm_bodies_per_wave(nt);
+    const dim3 grid((nt + bpw - 1) / bpw), block(64);
     switch (bpw) {
         case 1: hipLaunchKernelGGL((k_lm_step<1, L>), grid, block, 0, s, a); break;
         case 2: hipLaunchKernelGGL((k_lm_step<2, L>), grid, block, 0, s, a); break;
@@ -1234,9 +1239,9 @@ static int launch_lm_step_L(hipStream_t s, const LmArgs &a) {
     return done("k_lm_step");
 }
 int launch_lm_step(hipStream_t s, const LmArgs &a) {
-    if (a.n <= 0) return EPH_OK;
-    if (force_kernel_kind(a.n, a.kind) == 2) {
-        const dim3 grid((a.n + kWgBodies - 1) / kWgBodies), block(kWgThreads);
+    if (a.n <= 0 || a.hi <= a.lo) return EPH_OK;
+    if (force_kernel_kind(a.hi - a.lo, a.kind) == 2) {
+        const dim3 grid((a.hi - a.lo + kWgBodies - 1) / kWgBodies), block(kWgThreads);
         if (a.L == 12) hipLaunchKernelGGL(k_lm_step_wg<12>, grid, block, 0, s, a);
         else if (a.L == 13) hipLaunchKernelGGL(k_lm_step_wg<13>, grid, block, 0, s, a);
         else return EPH_ERR_UNSUPPORTED;
@@ -1247,8 +1252,8 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
     return EPH_ERR_UNSUPPORTED;
 }
 int launch_lm_predict(hipStream_t s, const LmArgs &a) {
-    if (a.n <= 0) return EPH_OK;
-    const dim3 grid((3 * a.n + 255) / 256), block(256);
+    if (a.n <= 0 || a.hi <= a.lo) return EPH_OK;
+    const dim3 grid((3 * (a.hi - a.lo) + 255) / 256), block(256);
     if (a.L == 12) hipLaunchKernelGGL(k_lm_predict<12>, grid, block, 0, s, a);
     else if (a.L == 13) hipLaunchKernelGGL(k_lm_predict<13>, grid, block, 0, s, a);
     else return EPH_ERR_UNSUPPORTED;

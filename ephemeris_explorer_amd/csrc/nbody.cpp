@@ -76,6 +76,8 @@ int NBodyIntegration::create(int n, const double *pos, const double *vel, const 
     EPH_HIP(hipEventCreate(&o->ev0_));
     EPH_HIP(hipEventCreate(&o->ev1_));
     if ((st = o->alloc_buffers())) return st;
+    o->lo_ = 0;
+    o->hi_ = n;
     if (n > 0) {
         hipStream_t s = o->stream_;
         EPH_HIP(hipMemcpyAsync(o->mu_.p, mu, sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -102,6 +104,7 @@ int NBodyIntegration::clone(std::unique_ptr<NBodyIntegration> *out) {
     o->h_ = h_; o->h_sub_ = h_sub_; o->time_ = time_; o->bound_ = bound_;
     o->starter_i_ = starter_i_; o->lm_i_ = lm_i_; o->evals_ = evals_;
     o->cur_ = cur_; o->pp_ = pp_; o->path_ = path_;
+    o->lo_ = lo_; o->hi_ = hi_; o->slice_ = slice_; o->xch_ = xch_;   // a clone of a sharded handle shares the ranks
     EPH_HIP(hipStreamCreateWithFlags(&o->stream_, hipStreamNonBlocking));
     EPH_HIP(hipEventCreate(&o->ev0_));
     EPH_HIP(hipEventCreate(&o->ev1_));
@@ -120,6 +123,30 @@ int NBodyIntegration::clone(std::unique_ptr<NBodyIntegration> *out) {
     return EPH_OK;
 }
 
+// Target partition: rank r owns bodies [r*slice, (r+1)*slice) with slice = npad/world. From here on
+// only the owned bodies' history, velocities and accelerations are kept current on this rank; the packed
+// positions of ALL bodies are, through one all-gather after every kernel that publishes positions.
+int NBodyIntegration::set_shard(std::shared_ptr<Exchange> x) {
+    if (!x || xch_) return EPH_ERR_BAD_ARGUMENT;          // a handle is sharded once, while every body is current
+    if (n_ <= kSmallN) return EPH_ERR_UNSUPPORTED;        // one-workgroup systems: replicas only
+    if (npad_ % (x->world() * kTile) != 0) {
+        set_last_error_text("sharding needs the padded body count to be a multiple of 64 * world");
+        return EPH_ERR_BAD_ARGUMENT;
+    }
+    slice_ = npad_ / x->world();
+    lo_ = x->rank() * slice_;
+    hi_ = lo_ + slice_ < n_ ? lo_ + slice_ : n_;
+    if (hi_ < lo_) hi_ = lo_;
+    xch_ = std::move(x);
+    return EPH_OK;
+}
+int NBodyIntegration::gather_packed(Body4 *buf) {
+    return xch_ ? xch_->all_gather_inplace(buf, sizeof(Body4) * (size_t)slice_, stream_) : EPH_OK;
+}
+int NBodyIntegration::gather_stage() {
+    return xch_ ? xch_->all_gather_inplace(stage_.p, sizeof(double) * 3 * (size_t)slice_, stream_) : EPH_OK;
+}
+
 int NBodyIntegration::sync() {
     EPH_HIP(hipSetDevice(device_));
     EPH_HIP(hipStreamSynchronize(stream_));
@@ -134,13 +161,14 @@ int NBodyIntegration::srkn_step(double h, double *y_slot) {
     for (int s = 0; s < rk_.stages; ++s) {
         if (!rk_.fsal || s > 0 || starter_i_ == 0) {
             // problem.ode.eval(t_stage, &problem.state.y, self.ddy.zero())
-            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind()))) return st;
+            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind(), lo_, hi_))) return st;
             evals_++;
         }
         // *dy = *dy + *ddy * (h * C::B[s]);  *y = *y + *dy * (h * C::A[s])
         if ((st = launch_kick_drift(stream_, n_, npad_, ASR_.p, V_.p, y_slot, h * rk_.B[s], h * rk_.A[s], mu_.p,
                                     P_[pp_ ^ 1].p)))
             return st;
+        if ((st = gather_packed(P_[pp_ ^ 1].p))) return st;
         pp_ ^= 1;
     }
     time_ = time_ + h;
@@ -159,7 +187,7 @@ int NBodyIntegration::startup_macro_step() {
     if (time_ + h_ == time_) return EPH_STEP_SIZE_UNDERFLOW;
     int st;
     if (starter_i_ / (uint32_t)substeps_ == 0) {
-        if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_), force_kind()))) return st;
+        if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_), force_kind(), lo_, hi_))) return st;
         evals_++;
     }
     const int nslot = (cur_ + L_ - 1) % L_;
@@ -167,7 +195,7 @@ int NBodyIntegration::startup_macro_step() {
     cur_ = nslot;   // from here on the working state is the new front, as in the reference after the clone_from
     for (int s = 0; s < substeps_; ++s)
         if ((st = srkn_step(h_sub_, Yslot(nslot)))) return st;
-    if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot), force_kind()))) return st;
+    if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot), force_kind(), lo_, hi_))) return st;
     evals_++;
     return EPH_OK;
 }
@@ -188,6 +216,7 @@ int64_t NBodyIntegration::steps_available(int64_t k, int *status_after) const {
 int NBodyIntegration::lm_batch(int64_t k) {
     LmArgs a{};
     a.n = n_; a.npad = npad_; a.L = L_;
+    a.lo = lo_; a.hi = hi_;
     a.Y = Y_.p; a.A = A_.p; a.V = V_.p;
     for (int j = 0; j < L_; ++j) { a.wa[j] = lm_.wa[j]; a.wb[j] = lm_.wb[j]; a.cw[j] = lm_.cw[j]; }
     a.h = h_;
@@ -211,6 +240,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
         a.pos_cur = P_[pp_].p;
         a.pos_next = P_[pp_ ^ 1].p;
         if ((st = launch_lm_predict(stream_, a))) return st;
+        if ((st = gather_packed(a.pos_next))) return st;
         for (int64_t s = 1; s <= k; ++s) {
             pp_ ^= 1;
             cur_ = (cur_ + L_ - 1) % L_;
@@ -220,6 +250,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.do_predict = s < k;
             a.step = (uint32_t)s;
             if ((st = launch_lm_step(stream_, a))) return st;
+            if (a.do_predict && (st = gather_packed(a.pos_next))) return st;
         }
         if (timing_) kernel_launches_ += (uint64_t)k;
     }
@@ -290,11 +321,13 @@ int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *s
     int st;
     if (pos && n_ > 0) {
         if ((st = launch_soa_to_aos(stream_, n_, npad_, Yslot(is_multistep_ ? cur_ : 0), stage_.p))) return st;
+        if ((st = gather_stage())) return st;               // sharded: every rank contributes its bodies
         EPH_HIP(hipMemcpyAsync(pos, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
         EPH_HIP(hipStreamSynchronize(stream_));
     }
     if (vel && n_ > 0) {
         if ((st = launch_soa_to_aos(stream_, n_, npad_, V_.p, stage_.p))) return st;
+        if ((st = gather_stage())) return st;
         EPH_HIP(hipMemcpyAsync(vel, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
         EPH_HIP(hipStreamSynchronize(stream_));
     }
@@ -309,6 +342,7 @@ int NBodyIntegration::get_acc(double *acc) {
     if (n_ == 0) return EPH_OK;
     int st;
     if ((st = launch_soa_to_aos(stream_, n_, npad_, is_multistep_ ? Aslot(cur_) : ASR_.p, stage_.p))) return st;
+    if ((st = gather_stage())) return st;
     EPH_HIP(hipMemcpyAsync(acc, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
     EPH_HIP(hipStreamSynchronize(stream_));
     return EPH_OK;

@@ -1,9 +1,15 @@
 """One process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" on CPU for the tests).
 
-The massive-body path does not shard: ranks integrate independent replicas and only the timing is
-reduced (max over ranks) -- no data-path collective. The massless sweep (next round) shards spacecraft with
-`shard_range` and broadcasts the ephemeris table once.
+Three ways the path uses more than one GPU:
+  * replicas of a massive-body system (ensembles, forward/backward): no data-path collective, only the timing is
+    reduced (max over ranks);
+  * the massless sweep: spacecraft are independent given the ephemeris -> `shard_range` over craft;
+  * ONE massive-body system partitioned by target body (`shard_nbody`): one all-gather of the packed positions per
+    force evaluation, RCCL over xGMI inside the library (`eph_nbody_shard`), or a caller-supplied exchange
+    (`host_staged_exchange`: through host memory and any torch.distributed backend -- what the tests use to run
+    two ranks on one GPU).
 """
+import ctypes as C
 import os
 
 
@@ -35,3 +41,65 @@ def reduce_timing(elapsed_s, units_local, dist=None, device="cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()), float(t.item())
+
+
+def _hip():
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return lib
+
+
+def host_staged_exchange(dist, group=None):
+    """An eph_exchange_fn body: in-place all-gather of equal slices through host memory and torch.distributed
+    (any backend, CPU tensors). Slow by construction (two PCIe copies and a host sync per force evaluation): it is
+    the portable fallback and the test transport; production runs pass an RCCL unique id instead."""
+    import numpy as np
+    import torch
+    hip = _hip()
+    D2H, H2D = 2, 1
+
+    def exchange(dev_ptr, slice_bytes, rank, world, stream):
+        if hip.hipStreamSynchronize(stream):
+            return 2
+        mine = np.empty(slice_bytes, dtype=np.uint8)
+        if hip.hipMemcpy(mine.ctypes.data, dev_ptr + rank * slice_bytes, slice_bytes, D2H):
+            return 3
+        parts = [torch.empty(slice_bytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(mine), group=group)
+        for r, part in enumerate(parts):
+            if r == rank:
+                continue
+            a = part.numpy()
+            if hip.hipMemcpy(dev_ptr + r * slice_bytes, a.ctypes.data, slice_bytes, H2D):
+                return 4
+        return 0
+
+    return exchange
+
+
+def broadcast_unique_id(dist, make_id, device="cpu", group=None):
+    """Rank 0 makes the 128-byte RCCL id (make_id()), every rank returns it."""
+    import torch
+    buf = torch.zeros(128, dtype=torch.uint8, device=device)
+    if dist.get_rank() == 0:
+        buf = torch.tensor(list(make_id()), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=0, group=group)
+    return bytes(buf.cpu().tolist())
+
+
+def shard_nbody(integration, dist=None, transport="rccl", device="cpu"):
+    """Partition `integration` (an NBodyIntegration every rank created identically) over the ranks of the
+    initialised process group. transport "rccl": RCCL inside the library; "host": host_staged_exchange."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return integration
+    from . import rccl_unique_id
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if transport == "rccl":
+        uid = broadcast_unique_id(dist, rccl_unique_id, device=device)
+        integration.shard(rank, world, unique_id=uid)
+    elif transport == "host":
+        integration.shard(rank, world, exchange=host_staged_exchange(dist))
+    else:
+        raise ValueError(transport)
+    return integration

@@ -41,7 +41,8 @@ typedef enum eph_status {
     EPH_ERR_NO_DEVICE = -2,   /* no usable gfx950 device / HIP runtime: the library never falls back to CPU */
     EPH_ERR_HIP = -3,
     EPH_ERR_UNSUPPORTED = -4,
-    EPH_ERR_OUT_OF_MEMORY = -5
+    EPH_ERR_OUT_OF_MEMORY = -5,
+    EPH_ERR_COMM = -6         /* RCCL / exchange callback failure (eph_last_error has the text) */
 } eph_status;
 
 /* PropagationDirection: Forward / Backward (ephemeris/src/propagators/mod.rs:23-93) */
@@ -101,6 +102,29 @@ int32_t eph_nbody_kernel_time(eph_nbody *h, double *total_ms, uint64_t *launches
 int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on);
 /* block until every launch queued on the handle's stream has finished */
 int32_t eph_nbody_sync(eph_nbody *h);
+
+/* ---- multi-GPU: the massive-body system partitioned by TARGET body over the ranks of one node -----------------
+ * (the reference runs one propagator per task, ephemeris_explorer/src/prediction.rs:422-443, and has
+ * no counterpart.) One process per GPU, each creating the SAME eph_nbody (same bodies, same order) and then calling
+ * eph_nbody_shard with its rank. Rank r owns bodies [r*S, (r+1)*S), S = padded_n / world (padded_n = n rounded up
+ * to 64; it must be a multiple of 64*world): it keeps their history and evaluates their all-pairs sums against ALL
+ * sources in the order of NewtonianGravity::eval (nbody.rs:22-38), so every rank's results are bit-identical to
+ * the single-device run. The only exchange is an in-place all-gather of the packed positions (32 B/body) after
+ * each kernel that publishes positions -- one per force evaluation -- and of the AoS staging buffer in
+ * eph_nbody_get_state / get_acc (which therefore are collective calls, as are advance and clone).
+ * Transport: rccl_unique_id != NULL -> ncclAllGather (RCCL over xGMI) on the handle's stream, the 128-byte id
+ * coming from eph_rccl_unique_id on rank 0 and distributed by the caller; else `fn`, called as
+ * fn(ctx, device_buffer, slice_bytes, rank, world, hipStream_t): it must gather world slices of slice_bytes in
+ * place (own slice at rank*slice_bytes), ordered after the work already enqueued on the stream, and either
+ * enqueue itself on that stream or complete before returning; non-zero return = failure (EPH_ERR_COMM).
+ * Systems of <= 64 bodies are not sharded (EPH_ERR_UNSUPPORTED): run replicas. */
+typedef int32_t (*eph_exchange_fn)(void *ctx, void *device_buffer, uint64_t slice_bytes, int32_t rank,
+                                   int32_t world, void *hip_stream);
+int32_t eph_rccl_unique_id(void *out128);
+int32_t eph_nbody_shard(eph_nbody *h, int32_t rank, int32_t world, const void *rccl_unique_id,
+                        eph_exchange_fn fn, void *ctx);
+/* owned bodies [lo, hi) and the number of all-gathers issued so far (any output may be NULL) */
+int32_t eph_nbody_shard_info(eph_nbody *h, int32_t *lo, int32_t *hi, uint64_t *gathers);
 
 /* ---- seam 3: Propagator / IncrementalPropagator / DirectionalPropagator / BoundedPropagator -----------
  * ephemeris::NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>>

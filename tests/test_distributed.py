@@ -35,6 +35,8 @@ def _worker(rank, world, port, out):
     assert nb.advance(12 + steps) == 0
     elapsed = 0.5 + rank                      # deterministic stand-in for the measured time
     total, tmax = parallel.reduce_timing(elapsed, 64 * steps, dist)
+    uid = parallel.broadcast_unique_id(dist, lambda: bytes(range(128)))     # rank 0's id reaches every rank
+    assert uid == bytes(range(128))
     lo, hi = parallel.shard_range(1001, rank, world)
     out[rank] = (total, tmax, lo, hi, float(nb.state()[0].sum()))
     dist.barrier()

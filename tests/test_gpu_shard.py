@@ -1,0 +1,127 @@
+"""One massive-body system partitioned by target body over ranks (eph_nbody_shard): every rank's
+results must be bit-identical to the single-device run, because each target's all-pairs sum keeps the order of
+NewtonianGravity::eval (ephemeris/src/propagators/nbody.rs:22-38) whatever rank evaluates it.
+
+Only one GPU is available to the tests, so the two-rank cases run two processes on that GPU with the host-staged
+exchange (gloo); the RCCL transport is exercised on a one-rank communicator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+H = 1.0 / 1024.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _single(n, method, steps):
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(n)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H, method)
+    nb.advance(steps)
+    return nb.state(), nb.acc()
+
+
+def test_rccl_one_rank_communicator(gpu):
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(1024)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H).shard(0, 1, unique_id=ea.rccl_unique_id())
+    nb.advance(12 + 30)
+    (p, v, t, sc), a = nb.state(), nb.acc()
+    lo, hi, gathers = nb.shard_info()
+    assert (lo, hi) == (0, 1024)
+    assert gathers >= 12 * 4 * 7 + 30                # one per published position set
+    (p0, v0, t0, sc0), a0 = _single(1024, "QuinlanTremaine12", 12 + 30)
+    assert t == t0 and sc == sc0
+    assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(a, a0)
+
+
+def test_shard_argument_errors(gpu):
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(32)
+    with pytest.raises(ea.EphemerisError):           # one-workgroup systems: replicas only
+        ea.NBodyIntegration(pos, vel, mu, 0.0, H).shard(0, 2, exchange=lambda *a: 0)
+    pos, vel, mu = plummer(192)                      # padded to 192: not a multiple of 64 * 2
+    with pytest.raises(ea.EphemerisError):
+        ea.NBodyIntegration(pos, vel, mu, 0.0, H).shard(0, 2, exchange=lambda *a: 0)
+    pos, vel, mu = plummer(128)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    with pytest.raises(ea.EphemerisError):           # world > 1 needs a transport
+        nb.shard(0, 2)
+    with pytest.raises(ea.EphemerisError):
+        nb.shard(2, 2, exchange=lambda *a: 0)
+    nb.shard(1, 2, exchange=lambda *a: 0)
+    assert nb.shard_info()[:2] == (64, 128)
+    with pytest.raises(ea.EphemerisError):           # a handle is sharded once
+        nb.shard(1, 2, exchange=lambda *a: 0)
+
+
+def test_failing_exchange_is_reported(gpu):
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(128)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H).shard(0, 2, exchange=lambda *a: 7)
+    with pytest.raises(ea.EphemerisError) as e:
+        nb.advance(1)
+    assert e.value.status == -6 and "7" in str(e.value)
+
+
+def _worker(rank, world, port, n, method, steps, out):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel, mu = plummer(n)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H, method)
+    parallel.shard_nbody(nb, dist, transport="host")
+    half = steps // 2
+    nb.advance(half)
+    twin = nb.clone()                                 # collective: every rank clones, the clones share the ranks
+    nb.advance(steps - half)
+    twin.advance(steps - half)
+    p, v, t, sc = nb.state()
+    a = nb.acc()
+    tp = twin.state()[0]
+    lo, hi, gathers = nb.shard_info()
+    out[rank] = (p, v, a, t, sc, lo, hi, gathers, np.array_equal(tp, p))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,method,steps", [
+    (1024, 2, "QuinlanTremaine12", 12 + 40),          # wave kernel, start-up and steady state sharded
+    (1000, 2, "QuinlanTremaine12", 12 + 9),           # ragged: the last rank owns 488 bodies
+    (512, 4, "BlanesMoan6B", 5),                      # SRKN only
+    (8192, 2, "QuinlanTremaine12", 12 + 4),           # 4096 targets per rank: the workgroup kernel at an offset
+])
+def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, method, steps, out), nprocs=world, join=True)
+    (p0, v0, t0, sc0), a0 = _single(n, method, steps)
+    assert set(out.keys()) == set(range(world))
+    npad = (n + 63) // 64 * 64
+    for r in range(world):
+        p, v, a, t, sc, lo, hi, gathers, twin_ok = out[r]
+        assert (lo, hi) == (r * npad // world, min(n, (r + 1) * npad // world))
+        assert t == t0 and sc == sc0 and gathers > 0 and twin_ok
+        assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(a, a0), (r, n, method)
