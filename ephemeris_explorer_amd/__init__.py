@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
+    "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
 ]
 
@@ -157,6 +158,9 @@ def _lib():
     L.eph_craft_batch_state.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
+    L.eph_craft_batch_enable_events.argtypes = [vp, _dp, i32, i32]
+    L.eph_craft_batch_event_counts.argtypes = [vp, _i32p, _i32p, _i32p]
+    L.eph_craft_batch_events.argtypes = [vp, i64, _dp, _i32p, _dp, _dp, _i32p, _i32p]
     L.eph_craft_batch_destroy.argtypes = [vp]
     L.eph_craft_batch_destroy.restype = None
     L.eph_hermite_eval.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _u8p]
@@ -542,6 +546,30 @@ class SpacecraftBatch:
         t, p, v = np.zeros(nk), np.zeros((nk, 3)), np.zeros((nk, 3))
         _check(self._L.eph_craft_batch_knots(self._h, int(craft), _p(t), _p(p), _p(v)), "eph_craft_batch_knots")
         return t, p, v
+
+    def enable_events(self, soi_radius, max_transitions=64, max_apsides=1024):
+        """Switch to the app's SpacecraftSolout: SOI transitions + apsides per accepted step (call before propagate)."""
+        r = _f64(soi_radius)
+        _check(self._L.eph_craft_batch_enable_events(self._h, _p(r), int(max_transitions), int(max_apsides)),
+               "eph_craft_batch_enable_events")
+        return self
+
+    def event_counts(self):
+        ntr, nap, st = (np.zeros(self.n, dtype=np.int32) for _ in range(3))
+        _check(self._L.eph_craft_batch_event_counts(self._h, _p(ntr, _i32p), _p(nap, _i32p), _p(st, _i32p)),
+               "eph_craft_batch_event_counts")
+        return ntr, nap, st
+
+    def events(self, craft, counts=None):
+        """(transitions: time[], body[]), (apsides: time[], distance[], body[], kind[]) of one craft."""
+        ntr, nap, _ = counts if counts is not None else self.event_counts()
+        a, b = max(int(ntr[craft]), 1), max(int(nap[craft]), 1)
+        tt, tb = np.zeros(a), np.zeros(a, dtype=np.int32)
+        at, ad, ab, ak = np.zeros(b), np.zeros(b), np.zeros(b, dtype=np.int32), np.zeros(b, dtype=np.int32)
+        _check(self._L.eph_craft_batch_events(self._h, int(craft), _p(tt), _p(tb, _i32p), _p(at), _p(ad),
+                                              _p(ab, _i32p), _p(ak, _i32p)), "eph_craft_batch_events")
+        k, m = int(ntr[craft]), int(nap[craft])
+        return (tt[:k], tb[:k]), (at[:m], ad[:m], ab[:m], ak[:m])
 
     def kernel_ms(self):
         ms = C.c_double()

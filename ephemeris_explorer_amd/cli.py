@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 
 from . import BACKWARD, FORWARD, AdaptiveParams, Ephemeris, NBodyPropagator, SpacecraftBatch
-from .systems import format_epoch, load_ship, load_system
+from .systems import format_epoch, load_ship, load_system, soi_radii
 
 SEC_PER_YEAR = 365.0 * 86400.0      # Duration::from_days(365.0 * 2.0) for two years (load/mod.rs:674)
 
@@ -56,6 +56,7 @@ def main(argv=None):
 
     ships = sorted((args.system / "ships").glob("*.json")) if (args.system / "ships").is_dir() else []
     eph = Ephemeris(sol_f, system.mu) if ships else None
+    soi = soi_radii(system)
     out["ships"] = []
     for path in ships:
         ship = load_ship(path)
@@ -73,11 +74,18 @@ def main(argv=None):
             continue
         batch = SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator,
                                 AdaptiveParams.default(ship.tolerance), [burns], max_knots=1 << 18)
+        batch.enable_events(soi, max_transitions=256, max_apsides=1 << 16)      # the app's SpacecraftSolout
         batch.propagate(ship.end)
         st = batch.status()
         fin = batch.state()
         entry.update({"status": int(st["status"][0]), "knots": int(st["nknots"][0]), "steps": int(st["steps"][0]),
                       "final_epoch": format_epoch(fin["t"][0]), "final_position_km": [float(x) for x in fin["pos"][0]]})
+        (tt, tb), (at, ad, ab, ak) = batch.events(0)
+        entry["soi_transitions"] = [{"epoch": format_epoch(t), "body": system.names[b]} for t, b in zip(tt, tb)]
+        entry["apsides"] = {"count": int(len(at)),
+                            "first": [{"epoch": format_epoch(t), "body": system.names[b], "distance_km": float(d),
+                                       "kind": "periapsis" if k == 0 else "apoapsis"}
+                                      for t, d, b, k in list(zip(at, ad, ab, ak))[:4]]}
         out["ships"].append(entry)
     if args.export_state:
         from .systems import parse_epoch

@@ -405,6 +405,252 @@ __global__ void __launch_bounds__(64) k_craft_propagate(const CraftArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// SpacecraftSolout events (the app's solout: ephemeris_explorer/src/dynamics/spacecraft.rs:77-221,296-451,539-586):
+// after every accepted step, sphere-of-influence crossings of every body and the apsides relative to the current
+// sphere's body are searched on the step's CubicHermite by sign test + bisection (<= 100 halvings, 1e-3 s).
+// One thread per craft walks its new segments in order (the transition list is sequential state). Bodies are
+// visited in body order (the reference iterates an EntityHashMap, whose order is unspecified).
+// ------------------------------------------------------------------------------------------------------
+struct EventArgs {
+    long long n_craft;
+    int n_bodies;
+    const BodyEntry *bodies;
+    const double *coeffs;
+    const int *ncoef;
+    const double *soi;            // [n_bodies] sphere radii (inf for the root)
+    const int *nknots;
+    const double *knot_t, *knot_y;
+    int *ev_seg;                  // next segment (knot pair k, k+1) to examine; -1 = new_solution not yet run
+    int *ntr, *nap, *ev_status;
+    double *tr_time; int *tr_body;                              // [max_tr][n]
+    double *ap_time, *ap_dist; int *ap_body, *ap_kind;          // [max_ap][n]
+    int max_tr, max_ap;
+};
+struct Hermite { double b0; V3 a0, a1, a2, a3; };
+__device__ __forceinline__ V3 hermite_pos(const Hermite &h, double t) {      // CubicHermite::eval  trajectory.rs:681-688
+    const double dt = t - h.b0;
+    return add(scale(add(scale(add(scale(h.a3, dt), h.a2), dt), h.a1), dt), h.a0);
+}
+__device__ __forceinline__ V3 hermite_vel(const Hermite &h, double t) {      // eval_derivative :690-697
+    const double dt = t - h.b0;
+    return add(scale(add(scale(scale(h.a3, dt), 3.0), scale(h.a2, 2.0)), dt), h.a1);
+}
+__device__ __forceinline__ bool ev_body_pos(const EventArgs &a, int b, double t, V3 &out) {
+    const BodyEntry be = a.bodies[b];
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) return false;
+    const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+    const int nc = a.ncoef[be.coeff_off + idx];
+    V3 bp = {0.0, 0.0, 0.0};
+    for (int k = nc - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + co[k * 3 + 0];
+        bp.y = bp.y * tau + co[k * 3 + 1];
+        bp.z = bp.z * tau + co[k * 3 + 2];
+    }
+    out = bp;
+    return true;
+}
+__device__ __forceinline__ bool ev_body_sv(const EventArgs &a, int b, double t, V3 &pos, V3 &vel) {
+    const BodyEntry be = a.bodies[b];
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) return false;
+    const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+    const int nc = a.ncoef[be.coeff_off + idx];
+    double rp[3], rv[3];
+    for (int c = 0; c < 3; ++c) {                     // Polynomial::eval_and_deriv
+        const double first = nc ? co[c] : 0.0;
+        const double last = nc ? co[(nc - 1) * 3 + c] : 0.0;
+        double e = last, d = last;
+        for (int k = nc - 2; k >= 1; --k) {
+            e = e * tau + co[k * 3 + c];
+            d = d * tau + e;
+        }
+        e = e * tau + first;
+        rp[c] = e;
+        rv[c] = d / be.interval;
+    }
+    pos = {rp[0], rp[1], rp[2]};
+    vel = {rv[0], rv[1], rv[2]};
+    return true;
+}
+// soi_distance_squared_at :77-83 (RADIAL = false) / radial_velocity_at :85-89 (RADIAL = true)
+template <bool RADIAL>
+__device__ __forceinline__ bool event_f(const EventArgs &a, const Hermite &h, int body, double t, double &out) {
+    if (!RADIAL) {
+        V3 bp;
+        if (!ev_body_pos(a, body, t, bp)) return false;
+        const V3 d = sub(hermite_pos(h, t), bp);
+        const double r = a.soi[body];
+        out = dot(d, d) - r * r;
+        return true;
+    }
+    V3 bp, bv;
+    if (!ev_body_sv(a, body, t, bp, bv)) return false;
+    const V3 rp = sub(hermite_pos(h, t), bp), rv = sub(hermite_vel(h, t), bv);
+    out = dot(rp, rv);
+    return true;
+}
+__device__ __forceinline__ double f64_signum(double x) { return x != x ? x : copysign(1.0, x); }
+// find_zero_crossing + find_root_bisection :112-162
+template <bool RADIAL>
+__device__ bool find_zero_crossing(const EventArgs &a, const Hermite &h, int body, double t0, double t1, double &time,
+                                   bool &ascending) {
+    double f0, f1;
+    if (!event_f<RADIAL>(a, h, body, t0, f0) || !event_f<RADIAL>(a, h, body, t1, f1)) return false;
+    if (f64_signum(f0) == f64_signum(f1)) return false;
+    double x0 = t0, x1 = t1, g0 = f0;
+    for (int it = 0; it < 100; ++it) {
+        const double mid = x0 + (x1 - x0) / 2.0;
+        double f_mid = 0.0;
+        event_f<RADIAL>(a, h, body, mid, f_mid);
+        if (f64_signum(g0) != f64_signum(f_mid)) x1 = mid;
+        else { x0 = mid; g0 = f_mid; }
+        if (fabs(x1 - x0) < 1e-3) {
+            time = x0;
+            ascending = __builtin_signbit(f0);
+            return true;
+        }
+    }
+    return false;
+}
+// find_soi :172-185,208-221: inside iff d2 < r*r; the closest wins, the first on ties
+__device__ int soi_at_except(const EventArgs &a, double t, V3 position, int except) {
+    int best = -1;
+    double best_d2 = 0.0;
+    for (int b = 0; b < a.n_bodies; ++b) {
+        if (b == except) continue;
+        V3 bp;
+        if (!ev_body_pos(a, b, t, bp)) continue;
+        const V3 d = sub(position, bp);
+        const double d2 = dot(d, d), r = a.soi[b];
+        if (!(d2 < r * r)) continue;
+        if (best < 0 || d2 < best_d2) { best = b; best_d2 = d2; }
+    }
+    return best;
+}
+// SoiTransitions::insert :332-339 on the craft's column of the slab; false = slab full
+__device__ bool tr_insert(const EventArgs &a, long long i, int &ntr, double time, int body) {
+    const long long n = a.n_craft;
+    int lo = 0, hi = ntr;
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        const double tm = a.tr_time[(long long)mid * n + i];
+        if (tm == time) { a.tr_body[(long long)mid * n + i] = body; return true; }
+        if (tm < time) lo = mid + 1; else hi = mid;
+    }
+    if (lo > 0 && a.tr_body[(long long)(lo - 1) * n + i] == body) return true;
+    if (ntr >= a.max_tr) return false;
+    for (int k = ntr; k > lo; --k) {
+        a.tr_time[(long long)k * n + i] = a.tr_time[(long long)(k - 1) * n + i];
+        a.tr_body[(long long)k * n + i] = a.tr_body[(long long)(k - 1) * n + i];
+    }
+    a.tr_time[(long long)lo * n + i] = time;
+    a.tr_body[(long long)lo * n + i] = body;
+    ntr += 1;
+    return true;
+}
+__device__ bool ap_insert(const EventArgs &a, long long i, int &nap, double time, double dist, int body, int kind) {
+    const long long n = a.n_craft;
+    int lo = 0, hi = nap;
+    bool found = false;
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        const double tm = a.ap_time[(long long)mid * n + i];
+        if (tm == time) { lo = mid; found = true; break; }
+        if (tm < time) lo = mid + 1; else hi = mid;
+    }
+    if (!found) {
+        if (nap >= a.max_ap) return false;
+        for (int k = nap; k > lo; --k) {
+            a.ap_time[(long long)k * n + i] = a.ap_time[(long long)(k - 1) * n + i];
+            a.ap_dist[(long long)k * n + i] = a.ap_dist[(long long)(k - 1) * n + i];
+            a.ap_body[(long long)k * n + i] = a.ap_body[(long long)(k - 1) * n + i];
+            a.ap_kind[(long long)k * n + i] = a.ap_kind[(long long)(k - 1) * n + i];
+        }
+        nap += 1;
+    }
+    a.ap_time[(long long)lo * n + i] = time;
+    a.ap_dist[(long long)lo * n + i] = dist;
+    a.ap_body[(long long)lo * n + i] = body;
+    a.ap_kind[(long long)lo * n + i] = kind;
+    return true;
+}
+__global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_craft) return;
+    const long long n = a.n_craft;
+    if (a.ev_status[i] != EPH_OK) return;
+    int seg = a.ev_seg[i], ntr = a.ntr[i], nap = a.nap[i];
+    const int nk = a.nknots[i];
+    bool full = false;
+    auto knot = [&](int k, int d) { return a.knot_y[((long long)k * 6 + d) * n + i]; };
+    if (seg < 0) {                                    // new_solution :525-537: the sphere the craft starts in
+        const int cur = soi_at_except(a, a.knot_t[i], V3{knot(0, 0), knot(0, 1), knot(0, 2)}, -1);
+        if (cur >= 0) full = !tr_insert(a, i, ntr, a.knot_t[i], cur);
+        seg = 0;
+    }
+    for (; !full && seg + 1 < nk; ++seg) {            // solout :539-586 for the step that produced knot seg + 1
+        const double t0 = a.knot_t[(long long)seg * n + i], t1 = a.knot_t[(long long)(seg + 1) * n + i];
+        const V3 p0 = {knot(seg, 0), knot(seg, 1), knot(seg, 2)}, d0 = {knot(seg, 3), knot(seg, 4), knot(seg, 5)};
+        const V3 p1 = {knot(seg + 1, 0), knot(seg + 1, 1), knot(seg + 1, 2)};
+        const V3 d1 = {knot(seg + 1, 3), knot(seg + 1, 4), knot(seg + 1, 5)};
+        Hermite h;                                    // CubicHermite::new  trajectory.rs:645-679
+        h.b0 = t0; h.a0 = p0; h.a1 = d0;
+        const double dt = t1 - t0;
+        if (dt == 0.0 && p0.x == p1.x && p0.y == p1.y && p0.z == p1.z && d0.x == d1.x && d0.y == d1.y && d0.z == d1.z) {
+            h.a2 = {0.0, 0.0, 0.0};
+            h.a3 = {0.0, 0.0, 0.0};
+        } else {
+            const double dt_recip = 1.0 / dt;
+            const double dt_recip_2 = dt_recip * dt_recip;
+            const double dt_recip_3 = dt_recip * dt_recip_2;
+            const V3 dt_val = sub(p1, p0);
+            h.a2 = sub(scale(scale(dt_val, dt_recip_2), 3.0), scale(add(scale(d0, 2.0), d1), dt_recip));
+            h.a3 = add(scale(scale(dt_val, dt_recip_3), -2.0), scale(add(d0, d1), dt_recip_2));
+        }
+        for (int b = 0; b < a.n_bodies && !full; ++b) {
+            double time;
+            bool asc;
+            if (!find_zero_crossing<false>(a, h, b, t0, t1, time, asc)) continue;
+            if (!asc) full = !tr_insert(a, i, ntr, time, b);      // Descending: entered b's sphere
+            else {
+                const int entered = soi_at_except(a, time, hermite_pos(h, time), b);
+                if (entered >= 0) full = !tr_insert(a, i, ntr, time, entered);
+            }
+        }
+        if (full) break;
+        int lo = 0, hi = ntr, i0 = -1;                // transitions.starting_at(t0) :326-329
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            const double tm = a.tr_time[(long long)mid * n + i];
+            if (tm == t0) { i0 = mid; break; }
+            if (tm < t0) lo = mid + 1; else hi = mid;
+        }
+        if (i0 < 0) i0 = lo == 0 ? 0 : lo - 1;
+        for (int q = i0; q < ntr && !full; ++q) {
+            const double t = a.tr_time[(long long)q * n + i];
+            const int soi = a.tr_body[(long long)q * n + i];
+            const double ta = t0 > t ? t0 : t;
+            const double tb = q + 1 < ntr ? a.tr_time[(long long)(q + 1) * n + i] : t1;
+            double time;
+            bool asc;
+            if (!find_zero_crossing<true>(a, h, soi, ta, tb, time, asc)) continue;
+            V3 bp;
+            if (!ev_body_pos(a, soi, time, bp)) continue;
+            const V3 d = sub(bp, hermite_pos(h, time));          // distance_at  dynamics/mod.rs:141-146
+            full = !ap_insert(a, i, nap, time, sqrt(dot(d, d)), soi, asc ? 0 : 1);
+        }
+        if (full) break;
+    }
+    a.ev_seg[i] = seg;
+    a.ntr[i] = ntr;
+    a.nap[i] = nap;
+    if (full) a.ev_status[i] = EPH_EVENTS_FULL;
+}
+
 // CubicHermiteSpline::state_vector  trajectory.rs:766-797, CubicHermite::{new, eval, eval_derivative} :645-696
 __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double *__restrict__ t,
                                                       const double *__restrict__ pos, const double *__restrict__ vel,
@@ -497,6 +743,11 @@ struct eph_craft_batch {
     DevBuf<int> cur_seg, status, nknots;
     DevBuf<long long> seg_off;
     DevBuf<SegmentDev> segs;
+    // SpacecraftSolout events (optional)
+    bool events = false;
+    int max_tr = 0, max_ap = 0;
+    DevBuf<double> soi, tr_time, ap_time, ap_dist;
+    DevBuf<int> ev_seg, ntr, nap, ev_status, tr_body, ap_body, ap_kind;
     double kernel_ms = 0;
     ~eph_craft_batch() {
         if (stream) {
@@ -652,6 +903,19 @@ int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) {
     EPH_HIP(hipEventRecord(b->ev0, b->stream));
     int st = craft_launch(b->stream, a);
     if (st) return st;
+    if (b->events) {                                  // the app's SpacecraftSolout on the steps just taken
+        EventArgs e{};
+        e.n_craft = b->n; e.n_bodies = b->eph->n_bodies;
+        e.bodies = b->eph->bodies.p; e.coeffs = b->eph->coeffs.p; e.ncoef = b->eph->ncoef.p;
+        e.soi = b->soi.p; e.nknots = b->nknots.p; e.knot_t = b->knot_t.p; e.knot_y = b->knot_y.p;
+        e.ev_seg = b->ev_seg.p; e.ntr = b->ntr.p; e.nap = b->nap.p; e.ev_status = b->ev_status.p;
+        e.tr_time = b->tr_time.p; e.tr_body = b->tr_body.p;
+        e.ap_time = b->ap_time.p; e.ap_dist = b->ap_dist.p; e.ap_body = b->ap_body.p; e.ap_kind = b->ap_kind.p;
+        e.max_tr = b->max_tr; e.max_ap = b->max_ap;
+        hipLaunchKernelGGL(k_craft_events, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, b->stream, e);
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) { set_last_error("k_craft_events", he); return EPH_ERR_HIP; }
+    }
     EPH_HIP(hipEventRecord(b->ev1, b->stream));
     EPH_HIP(hipEventSynchronize(b->ev1));
     float ms = 0;
@@ -710,6 +974,65 @@ int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, doub
                 if (vel) vel[3 * k + d] = y[(size_t)k * 6 + 3 + d];
             }
     }
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_enable_events(eph_craft_batch *b, const double *soi_radius, int32_t max_transitions,
+                                      int32_t max_apsides) {
+    try {
+        if (!b || !soi_radius || max_transitions < 1 || max_apsides < 1 || b->events) return EPH_ERR_BAD_ARGUMENT;
+        EPH_HIP(hipSetDevice(b->device));
+        const size_t nn = (size_t)std::max<long long>(b->n, 1);
+        const int nb = b->eph->n_bodies;
+        int st;
+        if ((st = b->soi.alloc(std::max(nb, 1))) || (st = b->ev_seg.alloc(nn)) || (st = b->ntr.alloc(nn)) ||
+            (st = b->nap.alloc(nn)) || (st = b->ev_status.alloc(nn)) || (st = b->tr_time.alloc(nn * max_transitions)) ||
+            (st = b->tr_body.alloc(nn * max_transitions)) || (st = b->ap_time.alloc(nn * max_apsides)) ||
+            (st = b->ap_dist.alloc(nn * max_apsides)) || (st = b->ap_body.alloc(nn * max_apsides)) ||
+            (st = b->ap_kind.alloc(nn * max_apsides)))
+            return st;
+        if (nb) EPH_HIP(hipMemcpy(b->soi.p, soi_radius, sizeof(double) * nb, hipMemcpyHostToDevice));
+        EPH_HIP(hipMemset(b->ev_seg.p, 0xff, sizeof(int) * nn));       // -1: new_solution pending
+        EPH_HIP(hipMemset(b->ntr.p, 0, sizeof(int) * nn));
+        EPH_HIP(hipMemset(b->nap.p, 0, sizeof(int) * nn));
+        EPH_HIP(hipMemset(b->ev_status.p, 0, sizeof(int) * nn));
+        b->max_tr = max_transitions;
+        b->max_ap = max_apsides;
+        b->events = true;
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+
+int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions, int32_t *n_apsides,
+                                     int32_t *event_status) {
+    if (!b || !b->events) return EPH_ERR_BAD_ARGUMENT;
+    EPH_HIP(hipSetDevice(b->device));
+    const size_t n = (size_t)b->n;
+    if (n == 0) return EPH_OK;
+    if (n_transitions) EPH_HIP(hipMemcpy(n_transitions, b->ntr.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (n_apsides) EPH_HIP(hipMemcpy(n_apsides, b->nap.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (event_status) EPH_HIP(hipMemcpy(event_status, b->ev_status.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_time, int32_t *tr_body, double *ap_time,
+                               double *ap_distance, int32_t *ap_body, int32_t *ap_kind) {
+    if (!b || !b->events || craft < 0 || craft >= b->n) return EPH_ERR_BAD_ARGUMENT;
+    EPH_HIP(hipSetDevice(b->device));
+    int ntr = 0, nap = 0;
+    EPH_HIP(hipMemcpy(&ntr, b->ntr.p + craft, sizeof(int), hipMemcpyDeviceToHost));
+    EPH_HIP(hipMemcpy(&nap, b->nap.p + craft, sizeof(int), hipMemcpyDeviceToHost));
+    const long long n = b->n;
+#define EPH_COLUMN(dst, src, T, cnt)                                                                             \
+    if ((dst) && (cnt) > 0)                                                                                      \
+        EPH_HIP(hipMemcpy2D((dst), sizeof(T), (src) + craft, sizeof(T) * n, sizeof(T), (cnt), hipMemcpyDeviceToHost))
+    EPH_COLUMN(tr_time, b->tr_time.p, double, ntr);
+    EPH_COLUMN(tr_body, b->tr_body.p, int, ntr);
+    EPH_COLUMN(ap_time, b->ap_time.p, double, nap);
+    EPH_COLUMN(ap_distance, b->ap_dist.p, double, nap);
+    EPH_COLUMN(ap_body, b->ap_body.p, int, nap);
+    EPH_COLUMN(ap_kind, b->ap_kind.p, int, nap);
+#undef EPH_COLUMN
     return EPH_OK;
 }
 

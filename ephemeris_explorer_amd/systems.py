@@ -5,6 +5,7 @@ load/solar_system/mod.rs:208-226 (ships); epoch strings: ftime/src/epoch.rs:19-4
 (f64 seconds since 1958-01-01 TAI); durations: ftime/src/duration.rs:279-345.
 """
 import json
+import math
 from dataclasses import dataclass, field
 from pathlib import Path
 
@@ -143,6 +144,27 @@ def load_system(directory):
         sysm.count = np.array([e["settings"][n]["count"] for n in sysm.names], dtype=np.uint32)
         sysm.degree = np.array([e["settings"][n]["degree"] for n in sysm.names], dtype=np.uint32)
     return sysm
+
+
+def soi_radii(system):
+    """Sphere-of-influence radius per body, in body order (ephemeris_explorer/src/load/mod.rs:283-307,
+    dynamics/spacecraft.rs:33-38): bodies by decreasing mu (stable sort); a body's parent is, among the heavier bodies
+    whose sphere contains it at the epoch, the one giving the smallest r = a * (mu / mu_parent)^(2/5) with a = their
+    distance at the epoch; no such body -> infinity (the root). The power is the host libm's pow, as in the
+    reference (f64::powf)."""
+    order = sorted(range(system.n), key=lambda i: -system.mu[i])          # sorted() is stable, like sort_by
+    radius = {}
+    for k, i in enumerate(order):
+        best = math.inf
+        for j in order[:k]:
+            d = system.pos[i] - system.pos[j]
+            a = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+            if a < radius[j]:
+                r = a * math.pow(system.mu[i] / system.mu[j], 2.0 / 5.0)
+                if r < best:                                              # min_by keeps the first minimum
+                    best = r
+        radius[i] = best
+    return np.array([radius[i] for i in range(system.n)], dtype=np.float64)
 
 
 @dataclass

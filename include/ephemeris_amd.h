@@ -180,6 +180,7 @@ int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, co
 typedef struct eph_ephemeris eph_ephemeris;   /* device-resident table of the massive bodies' UniformSplines */
 typedef struct eph_craft_batch eph_craft_batch;
 #define EPH_KNOTS_FULL 6                       /* per-craft status: the knot slab is full (library limit, not a StepError) */
+#define EPH_EVENTS_FULL 7                      /* per-craft event status: a transition / apsis slab is full */
 
 /* uploads the splines of `s` (Vec<UniformSpline>) with the bodies' mu; `s` may be destroyed afterwards */
 int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out);
@@ -215,6 +216,21 @@ int32_t eph_craft_batch_status(eph_craft_batch *b, int32_t *status, int32_t *nkn
 int32_t eph_craft_batch_state(eph_craft_batch *b, double *t, double *pos_xyz, double *vel_xyz, double *next_h);
 /* the CubicHermiteSpline of one craft: nknots[craft] x (t, pos, vel) */
 int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, double *pos_xyz, double *vel_xyz);
+/* The app's solout, SpacecraftSolout (ephemeris_explorer/src/dynamics/spacecraft.rs:514-587): besides the knots,
+ * every accepted step is searched for sphere-of-influence crossings of every body and for apsides relative to the
+ * current sphere's body (find_zero_crossing :112-162: sign test + bisection, <= 100 halvings, 1e-3 s), giving the
+ * SoiTransitions (:303-375) and Apsides (:409-451) of SpacecraftSolution. soi_radius[b] per body (infinity for
+ * the root; load/mod.rs:283-307). Call once, before the first propagate; from then on eph_craft_batch_propagate also
+ * runs the event search on the steps it took. Bodies are visited in body order (the reference iterates an
+ * EntityHashMap, whose order is unspecified). apsis kind: 0 = Periapsis, 1 = Apoapsis. */
+int32_t eph_craft_batch_enable_events(eph_craft_batch *b, const double *soi_radius, int32_t max_transitions,
+                                      int32_t max_apsides);
+/* per craft: number of transitions / apsides, and EPH_OK or EPH_EVENTS_FULL. Any pointer may be NULL. */
+int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions, int32_t *n_apsides,
+                                     int32_t *event_status);
+/* one craft's sorted lists (arrays sized by eph_craft_batch_event_counts; any may be NULL) */
+int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_time, int32_t *tr_body, double *ap_time,
+                               double *ap_distance, int32_t *ap_body, int32_t *ap_kind);
 int32_t eph_craft_batch_kernel_time(eph_craft_batch *b, double *total_ms);
 void eph_craft_batch_destroy(eph_craft_batch *b);
 /* CubicHermiteSpline::state_vector (ephemeris/src/trajectory.rs:766-797) at m epochs, on the device */

@@ -1213,6 +1213,11 @@ struct orc_craft {
     /* solution: CubicHermiteSpline */
     int64_t nk, capk;
     double *kt, *kp, *kv;
+    /* SpacecraftSolout (the app's solout): SoiTransitions + Apsides  dynamics/spacecraft.rs:296-451,514-587 */
+    double *soi_radius;            /* NULL = CubicHermiteSplineSolout only */
+    int64_t ntr, captr, nap, capap;
+    struct transition { double time; int32_t body; } *tr;
+    struct apsis { double time, distance; int32_t body, kind; } *ap;   /* kind 0 = Periapsis, 1 = Apoapsis */
 };
 
 static int timeline_idx_at(const orc_craft *c, double time) {   /* partition_point(|seg| seg.end() <= time) :157-160 */
@@ -1304,6 +1309,196 @@ static int craft_reset_integrator(orc_craft *c) {               /* spacecraft.rs
                          c->fac, c->n_max);
 }
 
+/* ---- SpacecraftSolout events -------------------------------------------------------------------------------- */
+typedef struct { double b0; v3 a0, a1, a2, a3; } hermite_t;
+static hermite_t hermite_new(double t0, double t1, v3 p0, v3 p1, v3 d0, v3 d1) {   /* CubicHermite::new trajectory.rs:645-679 */
+    hermite_t h;
+    h.b0 = t0; h.a0 = p0; h.a1 = d0;
+    const double dt = t1 - t0;
+    if (dt == 0.0 && p0.x == p1.x && p0.y == p1.y && p0.z == p1.z && d0.x == d1.x && d0.y == d1.y && d0.z == d1.z) {
+        h.a2 = (v3){0, 0, 0}; h.a3 = (v3){0, 0, 0};
+        return h;
+    }
+    const double dt_recip = 1.0 / dt;
+    const double dt_recip_2 = dt_recip * dt_recip;
+    const double dt_recip_3 = dt_recip * dt_recip_2;
+    const v3 dt_val = v3_sub(p1, p0);
+    /* a2 = dt_val * dt_recip_2 * 3.0 - (d0 * 2.0 + d1) * dt_recip ; a3 = dt_val * dt_recip_3 * -2.0 + (d0 + d1) * dt_recip_2 */
+    h.a2 = v3_sub(v3_scale(v3_scale(dt_val, dt_recip_2), 3.0), v3_scale(v3_add(v3_scale(d0, 2.0), d1), dt_recip));
+    h.a3 = v3_add(v3_scale(v3_scale(dt_val, dt_recip_3), -2.0), v3_scale(v3_add(d0, d1), dt_recip_2));
+    return h;
+}
+static v3 hermite_pos(const hermite_t *h, double t) {            /* eval :681-688 */
+    const double dt = t - h->b0;
+    return v3_add(v3_scale(v3_add(v3_scale(v3_add(v3_scale(h->a3, dt), h->a2), dt), h->a1), dt), h->a0);
+}
+static v3 hermite_vel(const hermite_t *h, double t) {            /* eval_derivative :690-697 */
+    const double dt = t - h->b0;
+    return v3_add(v3_scale(v3_add(v3_scale(v3_scale(h->a3, dt), 3.0), v3_scale(h->a2, 2.0)), dt), h->a1);
+}
+static int body_position(const orc_craft *c, int b, double t, v3 *out) {
+    double tau;
+    const poly_t *p = spline_get_polynomial(&c->eph->s[b], t, &tau);
+    if (!p) return 0;
+    *out = poly_eval(p, tau);
+    return 1;
+}
+static int body_state(const orc_craft *c, int b, double t, v3 *pos, v3 *vel) {
+    double tau;
+    const spline_t *s = &c->eph->s[b];
+    const poly_t *p = spline_get_polynomial(s, t, &tau);
+    if (!p) return 0;
+    v3 d;
+    poly_eval_and_deriv(p, tau, pos, &d);
+    *vel = (v3){d.x / s->interval, d.y / s->interval, d.z / s->interval};
+    return 1;
+}
+/* soi_distance_squared_at  dynamics/spacecraft.rs:77-83 ; radial_velocity_at :85-89 */
+typedef struct { const orc_craft *c; const hermite_t *h; int body, radial; } event_fn_t;
+static int event_f(const event_fn_t *e, double t, double *out) {
+    if (!e->radial) {
+        v3 bp;
+        if (!body_position(e->c, e->body, t, &bp)) return 0;
+        const v3 d = v3_sub(hermite_pos(e->h, t), bp);          /* position.distance_squared(body) */
+        const double r = e->c->soi_radius[e->body];
+        *out = v3_dot(d, d) - r * r;
+        return 1;
+    }
+    v3 bp, bv;
+    if (!body_state(e->c, e->body, t, &bp, &bv)) return 0;
+    const v3 rp = v3_sub(hermite_pos(e->h, t), bp), rv = v3_sub(hermite_vel(e->h, t), bv);   /* sv - body sv */
+    *out = v3_dot(rp, rv);
+    return 1;
+}
+static double f64_signum(double x) { return x != x ? x : copysign(1.0, x); }
+/* find_zero_crossing + find_root_bisection  dynamics/spacecraft.rs:112-162. Returns 1 and (time, ascending). */
+static int find_zero_crossing(const event_fn_t *e, double t0, double t1, double *time, int *ascending) {
+    double f0, f1;
+    if (!event_f(e, t0, &f0) || !event_f(e, t1, &f1)) return 0;
+    if (f64_signum(f0) == f64_signum(f1)) return 0;
+    double x0 = t0, x1 = t1, g0 = f0;
+    for (int it = 0; it < 100; ++it) {
+        const double mid = x0 + (x1 - x0) / 2.0;
+        double f_mid = 0.0;
+        event_f(e, mid, &f_mid);                                 /* f(t).unwrap() */
+        if (f64_signum(g0) != f64_signum(f_mid)) x1 = mid;
+        else { x0 = mid; g0 = f_mid; }
+        if (fabs(x1 - x0) < 1e-3) {
+            *time = x0;
+            *ascending = signbit(f0) ? 1 : 0;                    /* f0.is_sign_negative() => Ascending */
+            return 1;
+        }
+    }
+    return 0;
+}
+/* find_soi over Bodies in body order (the reference iterates an EntityHashMap, whose order is unspecified)
+ * dynamics/spacecraft.rs:172-185,208-221: inside iff d2 < r*r, the closest wins (first on ties: Iterator::min_by) */
+static int soi_at_except(const orc_craft *c, double t, v3 position, int except) {
+    int best = -1;
+    double best_d2 = 0.0;
+    for (int b = 0; b < c->eph->n; ++b) {
+        if (b == except) continue;
+        v3 bp;
+        if (!body_position(c, b, t, &bp)) continue;              /* filter_map */
+        const v3 d = v3_sub(position, bp);
+        const double d2 = v3_dot(d, d), r = c->soi_radius[b];
+        if (!(d2 < r * r)) continue;
+        if (best < 0 || d2 < best_d2 /* total_cmp on finite d2 */) { best = b; best_d2 = d2; }
+    }
+    return best;
+}
+static int64_t tr_search(const orc_craft *c, double time, int *found) {   /* binary_search_by(|(t, ..)| t.cmp(&time)) */
+    int64_t lo = 0, hi = c->ntr;
+    *found = 0;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (c->tr[mid].time == time) { *found = 1; return mid; }
+        if (c->tr[mid].time < time) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+static void tr_insert(orc_craft *c, double time, int body) {     /* SoiTransitions::insert :332-339 */
+    int found;
+    const int64_t i = tr_search(c, time, &found);
+    if (found) { c->tr[i].time = time; c->tr[i].body = body; return; }
+    if (i > 0 && c->tr[i - 1].body == body) return;
+    if (c->ntr == c->captr) {
+        c->captr = c->captr ? 2 * c->captr : 16;
+        c->tr = realloc(c->tr, sizeof(*c->tr) * (size_t)c->captr);
+    }
+    memmove(c->tr + i + 1, c->tr + i, sizeof(*c->tr) * (size_t)(c->ntr - i));
+    c->tr[i].time = time; c->tr[i].body = body;
+    c->ntr++;
+}
+static void ap_insert(orc_craft *c, double time, double distance, int body, int kind) {   /* Apsides::insert :420-426 */
+    int64_t lo = 0, hi = c->nap;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (c->ap[mid].time == time) { c->ap[mid] = (struct apsis){time, distance, body, kind}; return; }
+        if (c->ap[mid].time < time) lo = mid + 1; else hi = mid;
+    }
+    if (c->nap == c->capap) {
+        c->capap = c->capap ? 2 * c->capap : 16;
+        c->ap = realloc(c->ap, sizeof(*c->ap) * (size_t)c->capap);
+    }
+    memmove(c->ap + lo + 1, c->ap + lo, sizeof(*c->ap) * (size_t)(c->nap - lo));
+    c->ap[lo] = (struct apsis){time, distance, body, kind};
+    c->nap++;
+}
+static v3 knot_v3(const double *a, int64_t i) { return (v3){a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
+/* SpacecraftSolout::solout after the push  dynamics/spacecraft.rs:539-586 */
+static void craft_events(orc_craft *c) {
+    const int64_t k = c->nk - 2;
+    const double t0 = c->kt[k], t1 = c->kt[k + 1];
+    const hermite_t h = hermite_new(t0, t1, knot_v3(c->kp, k), knot_v3(c->kp, k + 1), knot_v3(c->kv, k),
+                                    knot_v3(c->kv, k + 1));
+    for (int b = 0; b < c->eph->n; ++b) {
+        const event_fn_t e = {c, &h, b, 0};
+        double time; int asc;
+        if (!find_zero_crossing(&e, t0, t1, &time, &asc)) continue;
+        if (!asc) tr_insert(c, time, b);                         /* Descending: entered b's sphere */
+        else {
+            const int entered = soi_at_except(c, time, hermite_pos(&h, time), b);
+            if (entered >= 0) tr_insert(c, time, entered);
+        }
+    }
+    /* transitions.starting_at(t0) :326-329 */
+    int found;
+    int64_t i0 = tr_search(c, t0, &found);
+    if (!found) i0 = i0 == 0 ? 0 : i0 - 1;
+    for (int64_t i = i0; i < c->ntr; ++i) {
+        const double t = c->tr[i].time;
+        const int soi = c->tr[i].body;
+        const double ta = t0 > t ? t0 : t;                       /* t.max(t0) */
+        const double tb = i + 1 < c->ntr ? c->tr[i + 1].time : t1;
+        const event_fn_t e = {c, &h, soi, 1};
+        double time; int asc;
+        if (!find_zero_crossing(&e, ta, tb, &time, &asc)) continue;
+        v3 bp;
+        if (!body_position(c, soi, time, &bp)) continue;         /* distance_at  dynamics/mod.rs:141-146 */
+        const v3 d = v3_sub(bp, hermite_pos(&h, time));
+        ap_insert(c, time, sqrt(v3_dot(d, d)), soi, asc ? 0 : 1);
+    }
+}
+/* Enable the app's SpacecraftSolout: soi_radius[b] per body (INFINITY for the root). new_solution :525-537 */
+void orc_craft_enable_events(orc_craft *c, const double *soi_radius) {
+    c->soi_radius = malloc(sizeof(double) * (size_t)(c->eph->n > 0 ? c->eph->n : 1));
+    memcpy(c->soi_radius, soi_radius, sizeof(double) * (size_t)c->eph->n);
+    c->ntr = c->nap = 0;
+    const int cur = soi_at_except(c, c->kt[0], knot_v3(c->kp, 0), -1);
+    if (cur >= 0) tr_insert(c, c->kt[0], cur);
+}
+int64_t orc_craft_transitions(const orc_craft *c, double *time, int32_t *body) {
+    for (int64_t i = 0; time && i < c->ntr; ++i) { time[i] = c->tr[i].time; body[i] = c->tr[i].body; }
+    return c->ntr;
+}
+int64_t orc_craft_apsides(const orc_craft *c, double *time, double *distance, int32_t *body, int32_t *kind) {
+    for (int64_t i = 0; time && i < c->nap; ++i) {
+        time[i] = c->ap[i].time; distance[i] = c->ap[i].distance; body[i] = c->ap[i].body; kind[i] = c->ap[i].kind;
+    }
+    return c->nap;
+}
+
 orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, const double *pos, const double *vel,
                          const char *method, double h_init, double h_max, double tol_pos, double tol_vel,
                          double fac_min, double fac_max, double fac, uint32_t n_max, int nburns,
@@ -1350,7 +1545,8 @@ orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, c
 }
 void orc_craft_free(orc_craft *c) {
     if (!c) return;
-    free(c->mu); free(c->seg); free(c->kt); free(c->kp); free(c->kv); free(c);
+    free(c->mu); free(c->seg); free(c->kt); free(c->kp); free(c->kv); free(c->soi_radius); free(c->tr); free(c->ap);
+    free(c);
 }
 int orc_craft_step(orc_craft *c) {                               /* spacecraft.rs:598-615 */
     /* advance_timeline(self.time())  :250-256 */
@@ -1363,6 +1559,7 @@ int orc_craft_step(orc_craft *c) {                               /* spacecraft.r
     if (st) return st;
     c->steps++;
     craft_push_knot(c);                                          /* solout :663-676 */
+    if (c->soi_radius) craft_events(c);
     return ORC_OK;
 }
 int orc_craft_step_to(orc_craft *c, double t) {

@@ -124,6 +124,13 @@ void orc_craft_get_knots(const orc_craft *, double *t, double *pos, double *vel)
 void orc_craft_state(const orc_craft *, double *t, double *pos, double *vel, double *next_h, uint32_t *n_attempts,
                      uint32_t *steps);
 uint64_t orc_craft_evals(const orc_craft *);
+/* The app's SpacecraftSolout (ephemeris_explorer/src/dynamics/spacecraft.rs:91-162,296-451,514-587): SOI transitions
+ * and apsides found on every accepted step. soi_radius[b] per body (INFINITY for the root,
+ * load/mod.rs:283-307). Bodies are visited in body order (the reference iterates an EntityHashMap). Call right
+ * after orc_craft_new. apsis kind: 0 = Periapsis, 1 = Apoapsis. Getters return the count (arrays may be NULL). */
+void orc_craft_enable_events(orc_craft *, const double *soi_radius);
+int64_t orc_craft_transitions(const orc_craft *, double *time, int32_t *body);
+int64_t orc_craft_apsides(const orc_craft *, double *time, double *distance, int32_t *body, int32_t *kind);
 /* CubicHermiteSpline::state_vector (trajectory.rs:766-797): returns 0 for None */
 int orc_hermite_eval(int64_t nknots, const double *t, const double *pos, const double *vel, double at, double *p,
                      double *v);

@@ -113,6 +113,12 @@ def lib(native=False):
     L.orc_craft_state.restype = None
     L.orc_craft_evals.argtypes = [vp]
     L.orc_craft_evals.restype = C.c_uint64
+    L.orc_craft_enable_events.argtypes = [vp, _dp]
+    L.orc_craft_enable_events.restype = None
+    L.orc_craft_transitions.argtypes = [vp, _dp, C.POINTER(C.c_int32)]
+    L.orc_craft_transitions.restype = C.c_int64
+    L.orc_craft_apsides.argtypes = [vp, _dp, _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.orc_craft_apsides.restype = C.c_int64
     L.orc_hermite_eval.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_double, _dp, _dp]
     L.orc_doc_test_decay.restype = C.c_double
     L.orc_doc_test_decay.argtypes = [C.c_char_p, C.c_int] + [C.c_double] * 5 + [_u32p]
@@ -338,7 +344,7 @@ class Craft:
 
     def __init__(self, eph, mu, t0, pos, vel, method="Verner87", h_init=60.0, h_max=1.7976931348623157e308,
                  tol_pos=1e-3, tol_vel=1e-3, fac_min=1.0 / 5.0, fac_max=5.0 / 1.0, fac=9.0 / 10.0, n_max=1_000_000,
-                 burns=()):
+                 burns=(), soi_radius=None):
         self.L = eph.L
         self.eph = eph          # keep the splines alive
         mu, pos, vel = _f64(mu), _f64(pos), _f64(vel)
@@ -352,6 +358,21 @@ class Craft:
                                       _ptr(br, _i32p))
         if not self.h:
             raise ValueError(method)
+        if soi_radius is not None:      # the app's SpacecraftSolout: SOI transitions + apsides
+            self.L.orc_craft_enable_events(self.h, _ptr(_f64(soi_radius)))
+
+    def transitions(self):
+        n = self.L.orc_craft_transitions(self.h, None, None)
+        t, b = np.zeros(max(n, 1)), np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_craft_transitions(self.h, _ptr(t), _ptr(b, _i32p))
+        return t[:n], b[:n]
+
+    def apsides(self):
+        n = self.L.orc_craft_apsides(self.h, None, None, None, None)
+        t, d = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+        b, k = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_craft_apsides(self.h, _ptr(t), _ptr(d), _ptr(b, _i32p), _ptr(k, _i32p))
+        return t[:n], d[:n], b[:n], k[:n]
 
     def step(self):
         return self.L.orc_craft_step(self.h)

@@ -423,8 +423,9 @@ class Craft:
 
     EMIN, EMAX = -1.7976931348623157e308, 1.7976931348623157e308
 
-    def __init__(self, eph, mu, t0, pos, vel, method, tol, burns, h_init=60.0, n_max=1_000_000):
+    def __init__(self, eph, mu, t0, pos, vel, method, tol, burns, h_init=60.0, n_max=1_000_000, soi=None):
         self.eph, self.mu, self.method, self.tol = eph, list(mu), method, tol
+        self.soi = soi                      # SpacecraftSolout: sphere-of-influence radii, or None
         self.h_init, self.n_max = h_init, n_max
         self.fac_min, self.fac_max, self.fac, self.h_max = 1.0 / 5.0, 5.0 / 1.0, 9.0 / 10.0, self.EMAX
         segs, cursor = [], self.EMIN
@@ -442,6 +443,134 @@ class Craft:
         self.bound = segs[self.cur][1]
         self.reset()
         self.knots = [(self.t, tuple(self.y))]
+        self.transitions, self.apsides = [], []      # [(time, body)], [(time, distance, body, kind)]
+        if soi is not None:                 # new_solution  dynamics/spacecraft.rs:525-537
+            cur = self._soi_at_except(self.t, Vec(*self.y[:3]), -1)
+            if cur is not None:
+                self.transitions.append((self.t, cur))
+
+    # ---- SpacecraftSolout (ephemeris_explorer/src/dynamics/spacecraft.rs:77-221,296-451,539-586) ----
+    def _body_pos(self, b, t):
+        e = self.eph[b]
+        return spline_position(e["start"], e["interval"], e["polys"], t)
+
+    def _soi_at_except(self, t, position, except_):
+        best = None
+        for b in range(len(self.eph)):
+            if b == except_:
+                continue
+            bp = self._body_pos(b, t)
+            if bp is None:
+                continue
+            d = position - bp
+            d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+            if d2 < self.soi[b] * self.soi[b] and (best is None or d2 < best[0]):
+                best = (d2, b)
+        return None if best is None else best[1]
+
+    @staticmethod
+    def _signum(x):
+        return x if x != x else math.copysign(1.0, x)
+
+    def _zero_crossing(self, f, t0, t1):
+        f0, f1 = f(t0), f(t1)
+        if f0 is None or f1 is None or self._signum(f0) == self._signum(f1):
+            return None
+        x0, x1, g0 = t0, t1, f0
+        for _ in range(100):
+            mid = x0 + (x1 - x0) / 2.0
+            fm = f(mid)
+            if self._signum(g0) != self._signum(fm):
+                x1 = mid
+            else:
+                x0, g0 = mid, fm
+            if abs(x1 - x0) < 1e-3:
+                return x0, math.copysign(1.0, f0) < 0.0           # (time, ascending)
+        return None
+
+    def _tr_insert(self, time, body):
+        ts = [t for t, _ in self.transitions]
+        import bisect
+        i = bisect.bisect_left(ts, time)
+        if i < len(ts) and ts[i] == time:
+            self.transitions[i] = (time, body)
+        elif i > 0 and self.transitions[i - 1][1] == body:
+            pass
+        else:
+            self.transitions.insert(i, (time, body))
+
+    def _events(self):
+        (t0, y0), (t1, y1) = self.knots[-2], self.knots[-1]
+        p0, p1, d0, d1 = Vec(*y0[:3]), Vec(*y1[:3]), Vec(*y0[3:]), Vec(*y1[3:])
+        dt = t1 - t0
+        r1 = 1.0 / dt
+        r2 = r1 * r1
+        r3 = r1 * r2
+        dv = p1 - p0
+        a2 = dv * r2 * 3.0 - (d0 * 2.0 + d1) * r1
+        a3 = dv * r3 * -2.0 + (d0 + d1) * r2
+
+        def pos(t):
+            s = t - t0
+            return (((a3 * s + a2) * s) + d0) * s + p0
+
+        def vel(t):
+            s = t - t0
+            return ((a3 * s * 3.0 + a2 * 2.0) * s) + d0
+
+        def f_soi(b):
+            def f(t):
+                bp = self._body_pos(b, t)
+                if bp is None:
+                    return None
+                d = pos(t) - bp
+                return (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) - self.soi[b] * self.soi[b]
+            return f
+
+        def f_radial(b):
+            def f(t):
+                e = self.eph[b]
+                sv = spline_eval(e["start"], e["interval"], e["polys"], t)
+                if sv is None:
+                    return None
+                rp, rv = pos(t) - sv[0], vel(t) - sv[1]
+                return rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]
+            return f
+
+        for b in range(len(self.eph)):
+            ev = self._zero_crossing(f_soi(b), t0, t1)
+            if ev is None:
+                continue
+            time, ascending = ev
+            if not ascending:
+                self._tr_insert(time, b)
+            else:
+                entered = self._soi_at_except(time, pos(time), b)
+                if entered is not None:
+                    self._tr_insert(time, entered)
+        ts = [t for t, _ in self.transitions]
+        import bisect
+        i = bisect.bisect_left(ts, t0)
+        i0 = i if (i < len(ts) and ts[i] == t0) else max(i - 1, 0)
+        for i in range(i0, len(self.transitions)):
+            t, soi = self.transitions[i]
+            ta = max(t, t0)
+            tb = self.transitions[i + 1][0] if i + 1 < len(self.transitions) else t1
+            ev = self._zero_crossing(f_radial(soi), ta, tb)
+            if ev is None:
+                continue
+            time, ascending = ev
+            bp = self._body_pos(soi, time)
+            if bp is None:
+                continue
+            d = bp - pos(time)
+            rec = (time, math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), soi, 0 if ascending else 1)
+            at = [a[0] for a in self.apsides]
+            j = bisect.bisect_left(at, time)
+            if j < len(at) and at[j] == time:
+                self.apsides[j] = rec
+            else:
+                self.apsides.insert(j, rec)
 
     def reset(self):
         self.rk = (Erkng if "AP" in tables()["methods"][self.method] else Erk)(self.method, self.y)
@@ -521,4 +650,6 @@ class Craft:
             if self.rk.fsal:
                 self.rk.k[-1] = list(prev[3])
         self.knots.append((self.t, tuple(self.y)))
+        if self.soi is not None:
+            self._events()
         return 0

@@ -186,3 +186,48 @@ def test_headless_cli_on_a_reference_system(gpu, tmp_path, capsys):
     back = ls(tmp_path)
     assert back.n == 3 and back.epoch == parse_epoch("1950-02-01 00:00:00")
     assert np.linalg.norm(back.pos[1] - back.pos[0]) > 1.4e8        # Earth is 1 au from the Sun
+
+
+def test_spacecraft_solout_events(gpu, simple_system):
+    """The app's SpacecraftSolout (dynamics/spacecraft.rs:514-587): SOI transitions and apsides of the whole Mars
+    transfer, bit-identical to the oracle (times, distances, bodies, kinds); the event search runs on the steps of
+    each propagate call, so a propagation in two legs gives the same lists."""
+    from ephemeris_explorer_amd.systems import soi_radii
+    s, sol, eph, osol = simple_system
+    soi = soi_radii(s)
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    burns = ship_burns(ship, s.names)
+    end = parse_epoch("1951-01-01 00:00:00")
+    params = gpu.AdaptiveParams.default(ship.tolerance)
+    c = orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, ship.integrator, tol_pos=ship.tolerance,
+                  tol_vel=ship.tolerance, burns=burns, soi_radius=soi)
+    assert c.step_to(end) == 0
+    ott, otb = c.transitions()
+    oat, oad, oab, oak = c.apsides()
+    names = [s.names[b] for b in otb]
+    assert names == ["Earth", "Sun", "Mars"] and len(oat) > 1000     # parking orbit, cruise, Mars orbit
+    for legs in ([end], [ship.start + 40 * 86400.0, parse_epoch("1950-07-27 00:00:00"), end]):
+        batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator, params, [burns],
+                                    max_knots=20000).enable_events(soi, max_transitions=16, max_apsides=4096)
+        for leg in legs:
+            batch.propagate(leg)
+        assert batch.status()["status"][0] == 0
+        ntr, nap, est = batch.event_counts()
+        assert est[0] == 0 and ntr[0] == len(ott) and nap[0] == len(oat)
+        (tt, tb), (at, ad, ab, ak) = batch.events(0)
+        assert np.array_equal(bits(tt), bits(ott)) and np.array_equal(tb, otb)
+        assert np.array_equal(bits(at), bits(oat)) and np.array_equal(bits(ad), bits(oad))
+        assert np.array_equal(ab, oab) and np.array_equal(ak, oak)
+
+
+def test_event_slab_overflow_is_reported(gpu, simple_system):
+    from ephemeris_explorer_amd.systems import soi_radii
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    params = gpu.AdaptiveParams.default(ship.tolerance)
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos] * 3, [ship.vel] * 3, ship.integrator, params, None,
+                                max_knots=4096).enable_events(soi_radii(s), max_transitions=4, max_apsides=5)
+    batch.propagate(ship.start + 86400.0)                            # ~15 revolutions of the parking orbit
+    ntr, nap, est = batch.event_counts()
+    assert list(est) == [7, 7, 7] and list(nap) == [5, 5, 5] and list(ntr) == [1, 1, 1]
+    assert list(batch.status()["status"]) == [0, 0, 0]               # the trajectories themselves are complete
