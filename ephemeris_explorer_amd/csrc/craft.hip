@@ -19,6 +19,7 @@
 #include <memory>
 #include <vector>
 
+#include "device_math.h"
 #include "host.h"
 
 namespace eph {
@@ -162,21 +163,34 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     const V3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
     V3 acc = {0.0, 0.0, 0.0};
     for (int b = 0; b < a.n_bodies; ++b) {            // Bodies::acceleration: index order
-        const BodyEntry be = a.bodies[b];
+        // the body's table entry is the same for every lane: scalar loads through the constant address space
+        const int bu = __builtin_amdgcn_readfirstlane(b);
+        const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
+        BodyEntry be;
+        be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
+        be.coeff_off = bc->coeff_off;
         long long idx;
         double tau;
         if (!spline_locate(be, t, idx, tau)) return false;
-        const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
-        const int nc = a.ncoef[be.coeff_off + idx];
-        V3 bp = {0.0, 0.0, 0.0};                      // eval_slice_horner
-        for (int k = nc - 1; k >= 0; --k) {
-            bp.x = bp.x * tau + co[k * 3 + 0];
-            bp.y = bp.y * tau + co[k * 3 + 1];
-            bp.z = bp.z * tau + co[k * 3 + 2];
+        // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so
+        // the leading steps give 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no
+        // ncoef load, no loop, and twelve 16-byte loads in flight at once
+        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (be.coeff_off + idx) * kDiv * 3);
+        double c[kDiv * 3];
+#pragma unroll
+        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
+        V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = kDiv - 1; k >= 0; --k) {
+            bp.x = bp.x * tau + c[k * 3 + 0];
+            bp.y = bp.y * tau + c[k * 3 + 1];
+            bp.z = bp.z * tau + c[k * 3 + 2];
         }
         const V3 d = sub(bp, pos);                    // acceleration_at::<false>: dir = body - at
         const double n2 = dot(d, d);
-        const double inv = 1.0 / (n2 * sqrt(n2));
+        double inv;                                   // 1 / (n2 * sqrt(n2)), IEEE sqrt and divide (device_math.h)
+        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
+        else inv = 1.0 / (n2 * sqrt(n2));
         acc = add(acc, scale(d, be.mu * inv));
     }
     V3 man = {0.0, 0.0, 0.0};
@@ -227,8 +241,17 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
 
 // NYS = false: ERK pair on the 6-vector (explicit.rs).  NYS = true: ERKNG pair on SecondOrderState<[DVec3; 1]>
 // (nystrom/explicit_generalized.rs:97-170, the app's Fine45): k[s][0..2] hold dk[s].
-template <int S, bool FSAL, bool NYS = false>
-__global__ void __launch_bounds__(64) k_craft_propagate(const CraftArgs a) {
+// Register budget (OCC = waves per SIMD the allocation is held to): the 13- and 16-stage pairs need > 256 registers
+// for the stage derivatives, which leaves ONE wave per SIMD and every L1 hit of the coefficient loads exposed
+// (measured, rocprofv3: 48 % of wave time parked on s_waitcnt, 46 % issuing). With more than one wave of craft per
+// SIMD, two resident waves with the surplus k[][] spilled to scratch are faster (262144 craft: 1.96e8 vs 1.2e8
+// craft-steps/s); with fewer, the unconstrained allocation is (65536 craft: 1.14e8 vs 1.01e8). craft_launch picks
+// by batch size. (Also measured: a runtime stage loop around ONE copy of the right-hand side, stage combinations
+// selected by a uniform switch -- 4x less code than this unrolled form, which exceeds the instruction cache -- is
+// slower, 1.03e8 / 1.12e8: every k[][] element then stays live across the loop and the allocator spills more.)
+template <int S, bool FSAL, bool NYS = false, int OCC = 1>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+k_craft_propagate(const CraftArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_craft) return;
     const long long n = a.n_craft;
@@ -697,11 +720,18 @@ __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double
 
 static int craft_launch(hipStream_t s, const CraftArgs &a) {
     const dim3 grid((unsigned)((a.n_craft + 63) / 64)), block(64);
-#define EPH_CRAFT_CASE(S_, F_) hipLaunchKernelGGL((k_craft_propagate<S_, F_>), grid, block, 0, s, a)
+    // more waves of craft than SIMDs (256 CUs x 4): hold the kernel to two waves per SIMD (EPH_CRAFT_OCC overrides)
+    static const int forced = [] { const char *e = getenv("EPH_CRAFT_OCC"); return e ? atoi(e) : 0; }();
+    const bool occ2 = forced ? forced == 2 : (a.n_craft + 63) / 64 > 1024;
+#define EPH_CRAFT_CASE(S_, F_)                                                                     \
+    do {                                                                                           \
+        if (occ2) hipLaunchKernelGGL((k_craft_propagate<S_, F_, false, 2>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((k_craft_propagate<S_, F_, false, 1>), grid, block, 0, s, a);      \
+    } while (0)
     const int S = a.rk.stages;
     const bool F = a.rk.fsal != 0;
     if (a.rk.nystrom) {
-        if (S == 7 && F) hipLaunchKernelGGL((k_craft_propagate<7, true, true>), grid, block, 0, s, a);
+        if (S == 7 && F) hipLaunchKernelGGL((k_craft_propagate<7, true, true, 2>), grid, block, 0, s, a);
         else return EPH_ERR_UNSUPPORTED;
     } else if (S == 6 && !F) EPH_CRAFT_CASE(6, false);
     else if (S == 7 && F) EPH_CRAFT_CASE(7, true);
@@ -784,7 +814,8 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
         for (int b = 0; b < nb; ++b)
             for (const Polynomial &p : s->s.splines[b].polynomials) {
                 nc[q] = p.ncoef;
-                std::memcpy(&co[q * kDiv * 3], &p.c[0][0], sizeof(double) * kDiv * 3);
+                // rows >= ncoef stay +0.0: craft_rhs runs Horner over all kDiv rows
+                std::memcpy(&co[q * kDiv * 3], &p.c[0][0], sizeof(double) * 3 * (size_t)std::min(std::max(p.ncoef, 0), kDiv));
                 ++q;
             }
         if ((st = e->bodies.alloc(std::max(nb, 1))) || (st = e->coeffs.alloc(co.size())) || (st = e->ncoef.alloc(nc.size())))

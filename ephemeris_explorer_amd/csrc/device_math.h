@@ -1,0 +1,40 @@
+// device_math.h -- IEEE-exact f64 sqrt / reciprocal sequences without the range-scaling wrappers (device only).
+//
+// sqrt and the reciprocal on the path must be the IEEE correctly rounded results (the CPU's sqrtsd / divsd). The
+// compiler's f64 expansions are: v_rsq_f64 / v_rcp_f64 seed + fma refinement, wrapped in range scaling (v_ldexp,
+// v_div_scale, v_div_fmas, v_div_fixup) that only acts for operands near the ends of the exponent range.
+// `*_inrange` are exactly those refinement sequences without the wrappers: bit-identical whenever the scaling
+// would have been a no-op, which in_range() guarantees (x in [2^-300, 2^300), so x*sqrt(x) in [2^-450, 2^450)).
+// tests/test_gpu_parity.py::test_inrange_sqrt_and_reciprocal_sequences_are_ieee checks them against the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace eph {
+
+__device__ __forceinline__ bool in_range(double n2) {
+    // biased exponent in [723, 1323)  <=>  2^-300 <= n2 < 2^300  (n2 >= 0; NaN/inf/0/denormals are out)
+    return (unsigned)(__double2hiint(n2) - 0x2D300000) < 0x25800000u;
+}
+__device__ __forceinline__ double sqrt_inrange(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double rcp_inrange(double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-p, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+
+}  // namespace eph

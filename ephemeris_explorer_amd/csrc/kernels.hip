@@ -8,6 +8,7 @@
 #include <utility>
 
 #include "eph_internal.h"
+#include "device_math.h"
 
 namespace eph {
 
@@ -36,31 +37,6 @@ __device__ __forceinline__ PairPre pair_pre(double xi, double yi, double zi, con
     p.dz = pj.z - zi;
     p.n2 = p.dx * p.dx + p.dy * p.dy + p.dz * p.dz;   // glam DVec3::length_squared, left to right
     return p;
-}
-__device__ __forceinline__ bool in_range(double n2) {
-    // biased exponent in [723, 1323)  <=>  2^-300 <= n2 < 2^300  (n2 >= 0; NaN/inf/0/denormals are out)
-    return (unsigned)(__double2hiint(n2) - 0x2D300000) < 0x25800000u;
-}
-__device__ __forceinline__ double sqrt_inrange(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = y * 0.5;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
-}
-__device__ __forceinline__ double rcp_inrange(double p) {
-    double r = __builtin_amdgcn_rcp(p);
-    double e = __builtin_fma(-p, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-p, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-p, r, 1.0);
-    return __builtin_fma(e, r, r);
 }
 template <bool FAST>
 __device__ __forceinline__ void pair_finish(const PairPre &p, double mu, double &cx, double &cy, double &cz) {
