@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
-    "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
+    "eph_craft_batch_reset_knots", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
 ]
 
@@ -158,6 +158,7 @@ def _lib():
     L.eph_craft_batch_state.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
+    L.eph_craft_batch_reset_knots.argtypes = [vp]
     L.eph_craft_batch_enable_events.argtypes = [vp, _dp, i32, i32]
     L.eph_craft_batch_event_counts.argtypes = [vp, _i32p, _i32p, _i32p]
     L.eph_craft_batch_events.argtypes = [vp, i64, _dp, _i32p, _dp, _dp, _i32p, _i32p]
@@ -546,6 +547,10 @@ class SpacecraftBatch:
         t, p, v = np.zeros(nk), np.zeros((nk, 3)), np.zeros((nk, 3))
         _check(self._L.eph_craft_batch_knots(self._h, int(craft), _p(t), _p(p), _p(v)), "eph_craft_batch_knots")
         return t, p, v
+
+    def reset_knots(self):
+        """Keep only the newest knot of every craft (as knot 0) and clear KNOTS_FULL: the drain point of a long run."""
+        _check(self._L.eph_craft_batch_reset_knots(self._h), "eph_craft_batch_reset_knots")
 
     def enable_events(self, soi_radius, max_transitions=64, max_apsides=1024):
         """Switch to the app's SpacecraftSolout: SOI transitions + apsides per accepted step (call before propagate)."""

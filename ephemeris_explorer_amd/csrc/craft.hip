@@ -674,6 +674,24 @@ __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
     if (full) a.ev_status[i] = EPH_EVENTS_FULL;
 }
 
+// eph_craft_batch_reset_knots: the newest knot of every craft becomes knot 0 of an otherwise empty slab (the next
+// CubicHermiteSpline piece starts where the drained one ended), a KNOTS_FULL status is cleared, and the event
+// search's segment cursor moves with the knots.
+__global__ void __launch_bounds__(256) k_craft_reset_knots(long long n, int *nknots, int *status, double *knot_t,
+                                                           double *knot_y, int *ev_seg) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nk = nknots[i];
+    if (nk > 1) {
+        knot_t[i] = knot_t[(long long)(nk - 1) * n + i];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) knot_y[(long long)d * n + i] = knot_y[((long long)(nk - 1) * 6 + d) * n + i];
+        nknots[i] = 1;
+        if (ev_seg && ev_seg[i] >= 0) ev_seg[i] = max(ev_seg[i] - (nk - 1), 0);
+    }
+    if (status[i] == EPH_KNOTS_FULL) status[i] = EPH_OK;
+}
+
 // CubicHermiteSpline::state_vector  trajectory.rs:766-797, CubicHermite::{new, eval, eval_derivative} :645-696
 __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double *__restrict__ t,
                                                       const double *__restrict__ pos, const double *__restrict__ vel,
@@ -1064,6 +1082,18 @@ int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_tim
     EPH_COLUMN(ap_body, b->ap_body.p, int, nap);
     EPH_COLUMN(ap_kind, b->ap_kind.p, int, nap);
 #undef EPH_COLUMN
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_reset_knots(eph_craft_batch *b) {
+    if (!b) return EPH_ERR_BAD_ARGUMENT;
+    if (b->n == 0) return EPH_OK;
+    EPH_HIP(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_craft_reset_knots, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->stream, b->n,
+                       b->nknots.p, b->status.p, b->knot_t.p, b->knot_y.p, b->events ? b->ev_seg.p : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("k_craft_reset_knots", e); return EPH_ERR_HIP; }
+    EPH_HIP(hipStreamSynchronize(b->stream));
     return EPH_OK;
 }
 

@@ -231,6 +231,11 @@ int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions,
 /* one craft's sorted lists (arrays sized by eph_craft_batch_event_counts; any may be NULL) */
 int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_time, int32_t *tr_body, double *ap_time,
                                double *ap_distance, int32_t *ap_body, int32_t *ap_kind);
+/* Drain point for long propagations: after the caller has read the knots it wants, the newest knot of every craft
+ * becomes knot 0 of an otherwise empty slab (so consecutive pieces of the CubicHermiteSpline share their end point,
+ * what CubicHermiteSpline::extend, ephemeris/src/trajectory.rs:842-844, needs to stitch them, minus the duplicate), EPH_KNOTS_FULL is cleared and the next
+ * eph_craft_batch_propagate continues. Events already found are kept. */
+int32_t eph_craft_batch_reset_knots(eph_craft_batch *b);
 int32_t eph_craft_batch_kernel_time(eph_craft_batch *b, double *total_ms);
 void eph_craft_batch_destroy(eph_craft_batch *b);
 /* CubicHermiteSpline::state_vector (ephemeris/src/trajectory.rs:766-797) at m epochs, on the device */

@@ -231,3 +231,39 @@ def test_event_slab_overflow_is_reported(gpu, simple_system):
     ntr, nap, est = batch.event_counts()
     assert list(est) == [7, 7, 7] and list(nap) == [5, 5, 5] and list(ntr) == [1, 1, 1]
     assert list(batch.status()["status"]) == [0, 0, 0]               # the trajectories themselves are complete
+
+
+def test_draining_the_knot_slab(gpu, simple_system):
+    """A long propagation through a small slab: propagate -> read knots -> reset_knots, repeated. The stitched
+    pieces (each starts with the previous piece's last knot) and the events equal the oracle's single run."""
+    from ephemeris_explorer_amd.systems import soi_radii
+    s, sol, eph, osol = simple_system
+    soi = soi_radii(s)
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    end = ship.start + 2 * 86400.0                      # no burns: the parking orbit, ~210 knots per day
+    c = orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, "Verner87", soi_radius=soi)
+    assert c.step_to(end) == 0
+    ot, op, ov = c.knots()
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], "Verner87", max_knots=100).enable_events(soi, 16, 4096)
+    ts, ps, vs, rounds = [], [], [], 0
+    while True:
+        batch.propagate(end)
+        st = batch.status()["status"][0]
+        kt, kp, kv = batch.knots(0)
+        first = 0 if not ts else 1                          # knot 0 repeats the previous piece's last knot
+        if ts:
+            assert kt[0] == ts[-1][-1]
+        ts.append(kt[first:]); ps.append(kp[first:]); vs.append(kv[first:])
+        rounds += 1
+        if st == 0:
+            break
+        assert st == gpu.KNOTS_FULL and len(kt) == 100
+        batch.reset_knots()
+        assert batch.status()["nknots"][0] == 1 and batch.status()["status"][0] == 0
+    assert rounds > 3
+    assert compare_knots((np.concatenate(ts), np.concatenate(ps), np.concatenate(vs)), (ot, op, ov), "stitched")
+    (tt, tb), (at, ad, ab, ak) = batch.events(0)
+    ott, otb = c.transitions()
+    oat, oad, oab, oak = c.apsides()
+    assert np.array_equal(bits(tt), bits(ott)) and np.array_equal(tb, otb)
+    assert np.array_equal(bits(at), bits(oat)) and np.array_equal(bits(ad), bits(oad)) and np.array_equal(ak, oak)
