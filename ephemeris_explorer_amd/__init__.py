@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append",
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
-    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_craft_batch_create", "eph_craft_batch_propagate",
+    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_reset_knots", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
@@ -149,6 +149,7 @@ def _lib():
     L.eph_least_squares_fit.argtypes = [i32, i32, i64, _dp, _dp, _i32p]
     L.eph_debug_inv_r3.argtypes = [i64, _dp, _dp, _dp]
     L.eph_ephemeris_create.argtypes = [vp, _dp, C.POINTER(vp)]
+    L.eph_ephemeris_interpolation_errors.argtypes = [vp, vp, i64, _dp, C.POINTER(i64)]
     L.eph_ephemeris_destroy.argtypes = [vp]
     L.eph_ephemeris_destroy.restype = None
     L.eph_craft_batch_create.argtypes = [vp, i64, _dp, _dp, _dp, C.c_char_p, C.POINTER(AdaptiveParams), _i64p, _dp, _dp,
@@ -490,6 +491,15 @@ class Ephemeris:
         _check(self._L.eph_ephemeris_create(solution._h, _p(mu), C.byref(h_)), "eph_ephemeris_create")
         self._h = h_
         self.n_bodies = len(mu)
+
+    def interpolation_errors(self, integration, n_steps):
+        """debug.rs:182-238: advance `integration` (NBodyIntegration over the same bodies) up to n_steps steps, or to its
+        bound, and return (max |position - spline position| per body in metres, steps taken)."""
+        err = np.zeros(self.n_bodies)
+        done = C.c_int64()
+        _check(self._L.eph_ephemeris_interpolation_errors(self._h, integration._h, int(n_steps), _p(err),
+                                                          C.byref(done)), "eph_ephemeris_interpolation_errors")
+        return err, done.value
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -31,10 +31,6 @@ int check_device() {
 
 using namespace eph;
 
-struct eph_nbody {
-    std::unique_ptr<NBodyIntegration> own;
-    NBodyIntegration *p = nullptr;
-};
 struct eph_prop {
     std::unique_ptr<NBodyPropagator> p;
     eph_nbody view;

@@ -692,6 +692,34 @@ __global__ void __launch_bounds__(256) k_craft_reset_knots(long long n, int *nkn
     if (status[i] == EPH_KNOTS_FULL) status[i] = EPH_OK;
 }
 
+// The debug window's interpolation-error scan (ephemeris_explorer/src/ui/windows/debug.rs:182-238): re-integrate
+// the massive bodies and, after every step, compare each body's position with its UniformSpline at that epoch;
+// keep the maximum of `position.distance(traj_position) * 1e3` (metres) per body. Thread per body; err[b] < 0 marks
+// "no entry yet" (EntityHashMap::entry(..).or_insert).
+__global__ void __launch_bounds__(256) k_interp_error(int n, int npad, const double *__restrict__ Y, double t,
+                                                      const BodyEntry *__restrict__ bodies,
+                                                      const double *__restrict__ coeffs, const int *__restrict__ ncoef,
+                                                      double *err, int *failed) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const BodyEntry be = bodies[b];
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) { *failed = 1; return; }   // traj.position(epoch).unwrap()
+    const double *co = coeffs + (be.coeff_off + idx) * kDiv * 3;
+    const int nc = ncoef[be.coeff_off + idx];
+    V3 tp = {0.0, 0.0, 0.0};
+    for (int k = nc - 1; k >= 0; --k) {
+        tp.x = tp.x * tau + co[k * 3 + 0];
+        tp.y = tp.y * tau + co[k * 3 + 1];
+        tp.z = tp.z * tau + co[k * 3 + 2];
+    }
+    const V3 d = sub(V3{Y[b], Y[npad + b], Y[2 * npad + b]}, tp);
+    const double e = sqrt(dot(d, d)) * 1e3;
+    const double cur = err[b];
+    err[b] = cur < 0.0 ? e : fmax(cur, e);
+}
+
 // CubicHermiteSpline::state_vector  trajectory.rs:766-797, CubicHermite::{new, eval, eval_derivative} :645-696
 __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double *__restrict__ t,
                                                       const double *__restrict__ pos, const double *__restrict__ vel,
@@ -846,6 +874,43 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 void eph_ephemeris_destroy(eph_ephemeris *e) { delete e; }
+
+int32_t eph_ephemeris_interpolation_errors(const eph_ephemeris *e, eph_nbody *h, int64_t n_steps, double *max_error_m,
+                                           int64_t *steps_done) {
+    try {
+        if (!e || !h || !h->p || n_steps < 0 || !max_error_m) return EPH_ERR_BAD_ARGUMENT;
+        NBodyIntegration *g = h->p;
+        const int n = g->n();
+        if (n != e->n_bodies || g->sharded()) return EPH_ERR_BAD_ARGUMENT;
+        EPH_HIP(hipSetDevice(g->device()));
+        DevBuf<double> err;
+        DevBuf<int> failed;
+        int st;
+        if ((st = err.alloc(std::max(n, 1))) || (st = failed.alloc(1))) return st;
+        std::vector<double> init((size_t)std::max(n, 1), -1.0);
+        EPH_HIP(hipMemcpyAsync(err.p, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice, g->stream()));
+        EPH_HIP(hipMemsetAsync(failed.p, 0, sizeof(int), g->stream()));
+        EPH_HIP(hipStreamSynchronize(g->stream()));
+        int64_t done = 0;
+        int status = EPH_OK;
+        for (; done < n_steps; ++done) {                       // while integrator.advance(&mut nbody).is_ok()
+            if ((status = g->advance(1))) break;
+            if (n > 0)
+                hipLaunchKernelGGL(k_interp_error, dim3((n + 255) / 256), dim3(256), 0, g->stream(), n, g->npad(),
+                                   g->positions_soa(), g->time(), e->bodies.p, e->coeffs.p, e->ncoef.p, err.p, failed.p);
+        }
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) { set_last_error("k_interp_error", he); return EPH_ERR_HIP; }
+        int f = 0;
+        EPH_HIP(hipMemcpyAsync(max_error_m, err.p, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream()));
+        EPH_HIP(hipMemcpyAsync(&f, failed.p, sizeof(int), hipMemcpyDeviceToHost, g->stream()));
+        EPH_HIP(hipStreamSynchronize(g->stream()));
+        if (steps_done) *steps_done = done;
+        if (status < 0) return status;
+        if (f) return EPH_EVAL_FAILED;                         // an epoch outside a spline: the reference would panic
+        return EPH_OK;                                         // a StepError (bound reached) just ends the scan
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
 
 int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const double *t0, const double *pos,
                                const double *vel, const char *method, const eph_adaptive_params *params,

@@ -101,6 +101,9 @@ public:
     int shard_lo() const { return lo_; }
     int shard_hi() const { return hi_; }
     uint64_t gathers() const { return xch_ ? xch_->gathers() : 0; }
+    // device view of the current positions, SoA [3][npad] (for on-device consumers: the interpolation-error scan)
+    const double *positions_soa() { return Yslot(is_multistep_ ? cur_ : 0); }
+    int npad() const { return npad_; }
     void enable_timing(bool on) { timing_ = on; }
     double kernel_ms() const { return kernel_ms_; }
     uint64_t kernel_launches() const { return kernel_launches_; }
@@ -213,6 +216,10 @@ private:
 };
 
 }  // namespace eph
+struct eph_nbody {      // the C ABI's opaque Integration handle (a view when it belongs to a propagator)
+    std::unique_ptr<eph::NBodyIntegration> own;
+    eph::NBodyIntegration *p = nullptr;
+};
 struct eph_solution {   // the C ABI's opaque Vec<UniformSpline<DVec3>>
     eph::Solution s;
 };

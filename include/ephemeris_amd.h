@@ -185,6 +185,13 @@ typedef struct eph_craft_batch eph_craft_batch;
 /* uploads the splines of `s` (Vec<UniformSpline>) with the bodies' mu; `s` may be destroyed afterwards */
 int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out);
 void eph_ephemeris_destroy(eph_ephemeris *e);
+/* The debug window's interpolation-error scan (ephemeris_explorer/src/ui/windows/debug.rs:182-238): advance `h` (an
+ * eph_nbody over the same bodies, e.g. QuinlanTremaine12 with the ephemeris dt and a bound) step by step and, after
+ * every step, compare each body's position with its spline in `e` at that epoch; max_error_m[b] = the maximum of
+ * position.distance(traj_position) * 1e3 (-1 if no step was taken). Stops at n_steps or at the first StepError
+ * (e.g. the bound); an epoch outside a spline gives EPH_EVAL_FAILED (the reference unwraps). */
+int32_t eph_ephemeris_interpolation_errors(const eph_ephemeris *e, eph_nbody *h, int64_t n_steps, double *max_error_m,
+                                           int64_t *steps_done);
 
 /* AdaptiveMethodParams (integration/src/lib.rs:171-274); the app's values: h_init 60, h_max f64::MAX, tol 1e-3,
  * fac_min 1/5, fac_max 5, fac 9/10, n_max 1e6 (ephemeris_explorer/src/load/mod.rs:472-486) */

@@ -267,3 +267,28 @@ def test_draining_the_knot_slab(gpu, simple_system):
     oat, oad, oab, oak = c.apsides()
     assert np.array_equal(bits(tt), bits(ott)) and np.array_equal(tb, otb)
     assert np.array_equal(bits(at), bits(oat)) and np.array_equal(bits(ad), bits(oad)) and np.array_equal(ak, oak)
+
+
+def test_interpolation_error_scan(gpu, simple_system):
+    """The debug window's scan (ephemeris_explorer/src/ui/windows/debug.rs:182-238): QuinlanTremaine12 re-integration
+    with the ephemeris dt, max over steps of |position - spline position| * 1e3 per body. Device result == the same
+    loop over the oracle's integrator and splines, bit for bit; and the fit errors are the small numbers the
+    ephemeris settings are tuned for."""
+    s, sol, eph, osol = simple_system
+    steps = 400
+    g = gpu.NBodyIntegration(s.pos, s.vel, s.mu, s.epoch, s.dt, "QuinlanTremaine12")
+    g.set_bound(s.epoch + 300 * s.dt)                      # the scan ends at the bound (BoundReached), not at n_steps
+    err, done = eph.interpolation_errors(g, steps)
+    assert done == 300
+    o = orc.NBody(s.pos, s.vel, s.mu, s.epoch, s.dt)
+    want = np.full(s.n, -1.0)
+    for _ in range(done):
+        assert o.advance(1) == 0
+        pos, _, t, _ = o.state()
+        for b in range(s.n):
+            tp = osol.eval(b, t)[0]
+            d = pos[b] - tp
+            e = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) * 1e3
+            want[b] = e if want[b] < 0.0 else max(want[b], e)
+    assert np.array_equal(bits(err), bits(want))
+    assert 0.0 < err.max() < 50.0                          # metres
