@@ -292,3 +292,45 @@ def test_interpolation_error_scan(gpu, simple_system):
             want[b] = e if want[b] < 0.0 else max(want[b], e)
     assert np.array_equal(bits(err), bits(want))
     assert 0.0 < err.max() < 50.0                          # metres
+
+
+def test_config4_full_size_sweep(gpu):
+    """BASELINE.json configs[3] at its full width on one GPU: the full_solar_system ephemeris (32 bodies) and 1e6
+    spacecraft (the Mars Transfer Ship state perturbed per component by normal(0, 100 km / 0.01 km/s), seed 20260926,
+    as SURVEY 8(d) prescribes), Verner87, tol 1e-3, bounded to 0.1 day. Size-independent properties: every craft
+    finishes; a craft's trajectory does not depend on the batch it is in (batch of 1e6 == batch of 64 == the CPU
+    oracle, bit for bit, for a spread sample); the sweep is deterministic."""
+    s = load_system("full_solar_system_2433282.5")
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    days = 0.1
+    end_eph = s.epoch + 5 * 86400.0
+    sol = gpu.NBodyPropagator.from_system(s).propagate(end_eph)
+    eph = gpu.Ephemeris(sol, s.mu)
+    n = 1_000_000
+    rng = np.random.default_rng(20260926)
+    pos = ship.pos + rng.normal(0.0, 100.0, size=(n, 3))
+    vel = ship.vel + rng.normal(0.0, 0.01, size=(n, 3))
+    t_end = ship.start + days * 86400.0
+    big = gpu.SpacecraftBatch(eph, ship.start, pos, vel, "Verner87", max_knots=96)
+    big.propagate(t_end)
+    st = big.status()
+    assert (st["status"] == 0).all() and st["steps"].min() > 10 and st["nknots"].max() < 96
+    fin = big.state()
+    assert (fin["t"] >= t_end).all()
+    sample = np.concatenate([np.arange(8), rng.integers(0, n, 48), np.arange(n - 8, n)])
+    small = gpu.SpacecraftBatch(eph, ship.start, pos[sample], vel[sample], "Verner87", max_knots=96)
+    small.propagate(t_end)
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert o.step_to(end_eph) == 0
+    osol = o.take_solution()
+    for k, i in enumerate(sample):
+        a, b = big.knots(int(i)), small.knots(k)
+        assert compare_knots(a, b, f"craft {i}: batch of 1e6 vs batch of 64")
+        if k % 8 == 0:
+            c = orc.Craft(osol, s.mu, ship.start, pos[i], vel[i], "Verner87")
+            assert c.step_to(t_end) == 0
+            assert compare_knots(a, c.knots(), f"craft {i} vs oracle")
+    again = gpu.SpacecraftBatch(eph, ship.start, pos, vel, "Verner87", max_knots=96)
+    again.propagate(t_end)
+    f2 = again.state()
+    assert np.array_equal(bits(f2["pos"]), bits(fin["pos"])) and np.array_equal(bits(f2["t"]), bits(fin["t"]))
