@@ -208,11 +208,12 @@ def main():
         flops = (FLOP_PER_INTERACTION * (n - 1) + 231.0) * nt
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected and corrected
         # as MI355X_MICROARCH.md prescribes) of this same command, committed under profiles/ -- not measurable live
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_insts = None, None, None
         tj = ROOT / "profiles" / "traffic.json"
         if tj.exists() and n == N_BODIES:
             tinfo = json.loads(tj.read_text())
             traffic, traffic_src = tinfo.get("traffic_bytes_per_launch"), tinfo.get("source")
+            valu_insts = tinfo.get("valu_wave_insts_per_launch")
         out = {
             "metric": "body-steps/s", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,6 +238,13 @@ def main():
                      "unit": "TFLOP/s", "frac": flops / launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "flop_per_launch": flops},
         }
+        if valu_insts:
+            # issue-slot view of the same launch: wave64 VALU instructions (SQ_INSTS_VALU of the committed profile) x 64
+            # lanes / live launch time, against 256 CU x 4 SIMD x 16 f64 lanes per clock at 2.4 GHz
+            lane_ops = valu_insts * 64.0 / launch_s
+            out["fp64"]["valu_issue"] = {"achieved": lane_ops / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS / 2.0,
+                                         "unit": "T lane-ops/s", "frac": lane_ops / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
+                                         "valu_wave_insts_per_launch": valu_insts}
         if world == 1 and not args.no_cpu_baseline and n == N_BODIES:
             base, o = cpu_baseline(pos, vel, mu, args.cpu_steps)
             out["cpu_baseline"] = base

@@ -56,6 +56,7 @@ main = max(out["kernels"].items(), key=lambda kv: kv[1].get("calls", 0) * kv[1].
 (dst / "traffic.json").write_text(json.dumps({
     "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)",
     "kernel": main[0], "traffic_bytes_per_launch": main[1].get("traffic_bytes_per_launch"),
+    "valu_wave_insts_per_launch": main[1].get("SQ_INSTS_VALU"),
     "avg_ns_kernel_trace": main[1].get("avg_ns_kernel_trace")}, indent=1) + "\n")
 print(json.dumps(out, indent=1)[:3000])
 print("bench:", bench["value"], bench["roofline"]["launch_us"])
