@@ -43,13 +43,30 @@ def main(argv=None):
     system = load_system(args.system)
     out = {"system": system.name, "bodies": system.n, "dt_s": system.dt, "epoch": format_epoch(system.epoch)}
     t0 = time.time()
+    # forward and backward propagators run concurrently, one host thread and one HIP stream each -- the reference
+    # runs them as two async tasks (prediction.rs:422-443, load/mod.rs:673-687)
+    import threading
     fwd = NBodyPropagator.from_system(system, FORWARD)
-    sol_f = fwd.propagate(system.epoch + args.years * SEC_PER_YEAR)
+    bwd = None if args.no_backward else NBodyPropagator.from_system(system, BACKWARD)
+    sols = {}
+
+    def run(key, prop, until):
+        sols[key] = prop.propagate(until)
+
+    threads = [threading.Thread(target=run, args=("f", fwd, system.epoch + args.years * SEC_PER_YEAR))]
+    if bwd is not None:
+        threads.append(threading.Thread(target=run, args=("b", bwd, system.epoch - args.years * SEC_PER_YEAR)))
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if "f" not in sols or (bwd is not None and "b" not in sols):
+        raise SystemExit("ephemeris propagation failed")
+    sol_f = sols["f"]
     out["forward"] = {"reached": format_epoch(fwd.time()), "steps": fwd.state()[3],
                       "polynomials": int(sum(sol_f.info(b)[2] for b in range(system.n)))}
-    if not args.no_backward:
-        bwd = NBodyPropagator.from_system(system, BACKWARD)
-        sol_b = bwd.propagate(system.epoch - args.years * SEC_PER_YEAR)
+    if bwd is not None:
+        sol_b = sols["b"]
         out["backward"] = {"reached": format_epoch(bwd.time()), "steps": bwd.state()[3],
                            "polynomials": int(sum(sol_b.info(b)[2] for b in range(system.n)))}
     out["ephemeris_seconds"] = time.time() - t0
