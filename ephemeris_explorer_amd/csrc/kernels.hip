@@ -5,6 +5,8 @@
 //
 // Reference citations are relative to the reference repository root.
 #include <cstdlib>
+#include <initializer_list>
+#include <type_traits>
 #include <utility>
 
 #include "eph_internal.h"
@@ -810,6 +812,15 @@ __global__ void __launch_bounds__(512) k_lm_persistent(const LmArgs a, long long
 //     ddy[i] = (0 + c(0,i) + ... + c(i-1,i)) + (0 + c(i,i+1) + ... + c(i,n-1)).
 // Two barriers per step; history ring, velocity, predictor and Cowell formula live in the (body, component) thread.
 // ------------------------------------------------------------------------------------------------------
+// the step loop of k_lm_small unrolled over the L ring rotations: copy K runs at rotation (L - K) % L
+template <typename Step, int... Ks>
+__device__ __forceinline__ void small_steps(Step &step, long long &s, long long nsteps, int &rot, bool &more,
+                                            std::integer_sequence<int, Ks...>) {
+    constexpr int L = sizeof...(Ks);
+    (void)std::initializer_list<int>{(more ? (step(std::integral_constant<int, (L - Ks) % L>{}, s),
+                                              rot = (L - Ks + L - 1) % L, more = ++s <= nsteps, 0)
+                                           : 0)...};
+}
 constexpr int kSmallMaxN = 40;           // two zero-padded contribution arrays must fit 160 KiB of LDS
 constexpr int kSmallRow = 48 + 2;        // doubles per row (n <= 40 -> 48 walked): 16-byte aligned, conflict-free
 template <int L>
@@ -871,7 +882,10 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
         const Body4 bi = sP[i], bj = sP[j];
         const double dx = bj.x - bi.x, dy = bj.y - bi.y, dz = bj.z - bi.z;
         const double n2 = dx * dx + dy * dy + dz * dz;
-        const double inv = 1.0 / (n2 * sqrt(n2));
+        // IEEE sqrt and divide; the wrapper-free sequences when every lane's operand is in range (device_math.h)
+        double inv;
+        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
+        else inv = 1.0 / (n2 * sqrt(n2));
         const double si = bj.mu * inv, sj = bi.mu * inv;
         U[i * 3 + 0][j] = dx * si;
         U[i * 3 + 1][j] = dy * si;
@@ -881,13 +895,18 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
         Lw[j * 3 + 2][i] = -dz * sj;
     };
 
-    for (long long s = 1; s <= nsteps; ++s) {
-        // ---- predictor (ELM2::advance) in the (body, comp) threads
-        double ynew = 0.0;
-        if (owner) {
-            ynew = lm_predict<L>(yv, av, wa, wb, hh);
-            reinterpret_cast<double *>(&sP[my_i])[cc] = ynew;
-        }
+    // ---- predictor (ELM2::advance) of the first step, in the (body, comp) threads
+    double ynew = 0.0;
+    if (owner) {
+        ynew = lm_predict<L>(yv, av, wa, wb, hh);
+        reinterpret_cast<double *>(&sP[my_i])[cc] = ynew;
+    }
+    // One step with the history ring at rotation R: level (newest - j) lives in yv[(R + j) % L]. The new level
+    // overwrites the oldest in place, so the ring never moves through registers; the step loop is unrolled over
+    // the L rotations (R is a compile-time constant in each copy).
+    auto step = [&](auto rc, long long s) {
+        constexpr int R = decltype(rc)::value;
+        constexpr int Rn = (R + L - 1) % L;            // slot of the oldest level = slot of the level being built
         __syncthreads();   // positions of the new level visible
         // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
         if (pi0 >= 0) pair(pi0, pj0);
@@ -911,31 +930,51 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
         const double other = __shfl_xor(acc, 1);          // the partner half (adjacent lane, same wave)
         if (owner) {
             const double anew = acc + other;               // ddy[i] (lower sum) += output_i (upper sum)
-            v = lm_cowell<L>(anew, av, ynew, yv[0], cw, h, hc);
+            double yl[L], al[L];                           // the levels before this step, newest first
+#pragma unroll
+            for (int j = 0; j < L; ++j) { yl[j] = yv[(R + j) % L]; al[j] = av[(R + j) % L]; }
+            // Cowell velocity of this level and the predictor of the NEXT level are independent dependent-add
+            // chains over the same history: issued together so each fills the other's issue gaps; the predictor's
+            // result is what the other waves wait for at the barrier
+            double y2[L], a2[L];
+            y2[0] = ynew;
+            a2[0] = anew;
+#pragma unroll
+            for (int j = 1; j < L; ++j) { y2[j] = yl[j - 1]; a2[j] = al[j - 1]; }
+            const double ynext = lm_predict<L>(y2, a2, wa, wb, hh);
+            if (s < nsteps) reinterpret_cast<double *>(&sP[my_i])[cc] = ynext;
+            v = lm_cowell<L>(anew, al, ynew, yl[0], cw, h, hc);
             if (samp_m) {                                  // SplineInterpolators::solout_with  nbody.rs:389-397
                 const uint32_t t = samp_phase + (uint32_t)s;
                 if (t % samp_m == 0) a.samp.log[(samp_base + (uint64_t)(t / samp_m - 1)) * 3 + cc] = ynew;
             }
-#pragma unroll
-            for (int j = L - 1; j > 0; --j) { yv[j] = yv[j - 1]; av[j] = av[j - 1]; }
-            yv[0] = ynew;
-            av[0] = anew;
+            yv[Rn] = ynew;
+            av[Rn] = anew;
+            ynew = ynext;
         }
-        // no barrier needed here: the next predictor writes sP only after every pair thread of this step passed the
-        // barrier above, and U / Lw are rewritten only after the next "positions visible" barrier
+        // the predictor writes sP after every pair thread of this step passed the barrier above; U / Lw are
+        // rewritten only after the next "positions visible" barrier
+    };
+    int rot = 0;                                       // rotation after the steps taken so far
+    {
+        long long s = 1;
+        bool more = nsteps >= 1;
+        while (more) small_steps(step, s, nsteps, rot, more, std::make_integer_sequence<int, L>{});
     }
 
     if (owner) {
         const int cur = (int)(((long long)a.cur - nsteps % L + L) % L);   // slot of the newest level after nsteps
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
+        for (int p = 0; p < L; ++p) {                     // register p holds level (newest - j), j = (p - rot) mod L
+            const int j = (p - rot + L) % L;
             const int slot = (cur + j) % L;
-            a.Y[slot * lvl + off] = yv[j];
-            a.A[slot * lvl + off] = av[j];
+            a.Y[slot * lvl + off] = yv[p];
+            a.A[slot * lvl + off] = av[p];
         }
         a.V[off] = v;
-        reinterpret_cast<double *>(a.pos_next + my_i)[cc] = yv[0];
-        reinterpret_cast<double *>(const_cast<Body4 *>(a.pos_cur) + my_i)[cc] = yv[0];
+        const double ynewest = a.Y[(size_t)cur * lvl + off];
+        reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynewest;
+        reinterpret_cast<double *>(const_cast<Body4 *>(a.pos_cur) + my_i)[cc] = ynewest;
     }
 }
 
