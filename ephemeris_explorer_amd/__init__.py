@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
-    "eph_craft_batch_reset_knots", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
+    "eph_craft_batch_reset_knots", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
 ]
 
@@ -160,6 +160,7 @@ def _lib():
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
     L.eph_craft_batch_reset_knots.argtypes = [vp]
+    L.eph_timeline_divergence_time.argtypes = [i64, _dp, _dp, _dp, _i32p, i64, _dp, _dp, _dp, _i32p, f64, _dp]
     L.eph_craft_batch_enable_events.argtypes = [vp, _dp, i32, i32]
     L.eph_craft_batch_event_counts.argtypes = [vp, _i32p, _i32p, _i32p]
     L.eph_craft_batch_events.argtypes = [vp, i64, _dp, _i32p, _dp, _dp, _i32p, _i32p]
@@ -595,6 +596,27 @@ class SpacecraftBatch:
         if getattr(self, "_h", None):
             self._L.eph_craft_batch_destroy(self._h)
             self._h = None
+
+
+def _burn_arrays(burns):
+    n = len(burns)
+    bs = _f64([b[0] for b in burns] or [0.0])
+    be = _f64([b[1] for b in burns] or [0.0])
+    ba = _f64([b[2] for b in burns] or [[0.0, 0.0, 0.0]])
+    br = np.ascontiguousarray([b[3] for b in burns] or [0], dtype=np.int32)
+    return n, bs, be, ba, br
+
+
+def timeline_divergence_time(old_burns, new_burns, before):
+    """Timeline::divergence_time_before (spacecraft.rs:179-213) of new_burns against old_burns; burns are
+    (start, end, acc[3], ref_body or -1). The epoch a flight plan restarts from (flight_plan.rs:263-303)."""
+    no, os_, oe, oa, or_ = _burn_arrays(list(old_burns))
+    nn, ns, ne, na, nr = _burn_arrays(list(new_burns))
+    out = C.c_double()
+    _check(_lib().eph_timeline_divergence_time(no, _p(os_), _p(oe), _p(oa), _p(or_, _i32p), nn, _p(ns), _p(ne), _p(na),
+                                               _p(nr, _i32p), float(before), C.byref(out)),
+           "eph_timeline_divergence_time")
+    return out.value
 
 
 def hermite_eval(t, pos, vel, at, with_velocity=True):

@@ -836,6 +836,24 @@ struct eph_craft_batch {
     }
 };
 
+// Timeline::new  ephemeris/src/propagators/spacecraft.rs:129-152: stable sort by start, coast segments in the gaps,
+// from Epoch::MIN to Epoch::MAX; appended to `segs`
+static void timeline_new(long long nburns, const double *burn_start, const double *burn_end, const double *burn_acc,
+                         const int32_t *burn_ref, std::vector<SegmentDev> &segs) {
+    const double EMIN = -1.7976931348623157e308, EMAX = 1.7976931348623157e308;   // Epoch::MIN / MAX
+    std::vector<long long> order;
+    for (long long q = 0; q < nburns; ++q) order.push_back(q);
+    std::stable_sort(order.begin(), order.end(), [&](long long x, long long y) { return burn_start[x] < burn_start[y]; });
+    double cursor = EMIN;
+    for (long long q : order) {
+        if (burn_start[q] > cursor) segs.push_back(SegmentDev{cursor, burn_start[q], 0, 0, 0, 0, -1});
+        cursor = burn_end[q];
+        segs.push_back(SegmentDev{burn_start[q], burn_end[q], burn_acc[3 * q], burn_acc[3 * q + 1], burn_acc[3 * q + 2],
+                                  1, burn_ref[q]});
+    }
+    if (cursor < EMAX) segs.push_back(SegmentDev{cursor, EMAX, 0, 0, 0, 0, -1});
+}
+
 extern "C" {
 
 int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out) {
@@ -942,18 +960,9 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
         for (long long i = 0; i < n; ++i) {
             seg_off[i] = (long long)segs.size();
             const long long b0 = burn_offset ? burn_offset[i] : 0, b1 = burn_offset ? burn_offset[i + 1] : 0;
-            std::vector<long long> order;
-            for (long long q = b0; q < b1; ++q) order.push_back(q);
-            std::stable_sort(order.begin(), order.end(), [&](long long x, long long y) { return burn_start[x] < burn_start[y]; });
-            double cursor = EMIN;
-            for (long long q : order) {
+            for (long long q = b0; q < b1; ++q)
                 if (burn_ref[q] >= e->n_bodies) return EPH_ERR_BAD_ARGUMENT;
-                if (burn_start[q] > cursor) segs.push_back(SegmentDev{cursor, burn_start[q], 0, 0, 0, 0, -1});
-                cursor = burn_end[q];
-                segs.push_back(SegmentDev{burn_start[q], burn_end[q], burn_acc[3 * q], burn_acc[3 * q + 1],
-                                          burn_acc[3 * q + 2], 1, burn_ref[q]});
-            }
-            if (cursor < EMAX) segs.push_back(SegmentDev{cursor, EMAX, 0, 0, 0, 0, -1});
+            timeline_new(b1 - b0, burn_start + b0, burn_end + b0, burn_acc + 3 * b0, burn_ref + b0, segs);
             // segment_idx_at(t0): partition_point(seg.end() <= time)
             int idx = 0;
             const long long ns = (long long)segs.size() - seg_off[i];
@@ -1148,6 +1157,39 @@ int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_tim
     EPH_COLUMN(ap_kind, b->ap_kind.p, int, nap);
 #undef EPH_COLUMN
     return EPH_OK;
+}
+
+// Timeline::divergence_time_before  spacecraft.rs:179-213 (common_times: segments zipped while their starts agree,
+// stopping after the first pair whose thrust differs; the last such start that is < before)
+int32_t eph_timeline_divergence_time(int64_t n_old, const double *old_start, const double *old_end, const double *old_acc,
+                                     const int32_t *old_ref, int64_t n_new, const double *new_start,
+                                     const double *new_end, const double *new_acc, const int32_t *new_ref,
+                                     double before, double *restart_epoch) {
+    try {
+        if (n_old < 0 || n_new < 0 || !restart_epoch || (n_old > 0 && (!old_start || !old_end || !old_acc || !old_ref)) ||
+            (n_new > 0 && (!new_start || !new_end || !new_acc || !new_ref)))
+            return EPH_ERR_BAD_ARGUMENT;
+        std::vector<SegmentDev> a, b;
+        timeline_new(n_new, new_start, new_end, new_acc, new_ref, a);     // self = the new timeline
+        timeline_new(n_old, old_start, old_end, old_acc, old_ref, b);
+        bool done = false, any = false;
+        double last = 0.0;
+        for (size_t k = 0; k < a.size() && k < b.size(); ++k) {
+            if (done || a[k].start != b[k].start) break;
+            const double t = a[k].start;
+            // s1.thrust() != s2.thrust(): Option<ConstantThrust { acceleration, frame }>
+            const bool same = a[k].is_burn == b[k].is_burn &&
+                              (!a[k].is_burn || (a[k].ax == b[k].ax && a[k].ay == b[k].ay && a[k].az == b[k].az &&
+                                                 a[k].ref == b[k].ref));
+            if (!same) done = true;
+            if (!(t < before)) break;                                    // take_while(|&t| t < before)
+            last = t;
+            any = true;
+        }
+        if (!any) return EPH_ERR_BAD_ARGUMENT;                           // the reference unwraps (before <= Epoch::MIN)
+        *restart_epoch = last;
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 
 int32_t eph_craft_batch_reset_knots(eph_craft_batch *b) {

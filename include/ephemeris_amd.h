@@ -238,6 +238,15 @@ int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions,
 /* one craft's sorted lists (arrays sized by eph_craft_batch_event_counts; any may be NULL) */
 int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_time, int32_t *tr_body, double *ap_time,
                                double *ap_distance, int32_t *ap_body, int32_t *ap_kind);
+/* Flight-plan restart (ephemeris_explorer/src/flight_plan.rs:263-303): Timeline::divergence_time_before
+ * (ephemeris/src/propagators/spacecraft.rs:179-213) of the NEW burn list against the OLD one -- the start of the last
+ * segment, earlier than `before`, up to which both timelines agree; the caller restarts a craft from the knot at
+ * that epoch (max'ed with the trajectory start). Host-only logic (no device needed). Burns as in
+ * eph_craft_batch_create. The reference panics if no common start precedes `before`: EPH_ERR_BAD_ARGUMENT. */
+int32_t eph_timeline_divergence_time(int64_t n_old, const double *old_start, const double *old_end, const double *old_acc,
+                                     const int32_t *old_ref, int64_t n_new, const double *new_start,
+                                     const double *new_end, const double *new_acc, const int32_t *new_ref,
+                                     double before, double *restart_epoch);
 /* Drain point for long propagations: after the caller has read the knots it wants, the newest knot of every craft
  * becomes knot 0 of an otherwise empty slab (so consecutive pieces of the CubicHermiteSpline share their end point,
  * what CubicHermiteSpline::extend, ephemeris/src/trajectory.rs:842-844, needs to stitch them, minus the duplicate), EPH_KNOTS_FULL is cleared and the next

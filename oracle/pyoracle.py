@@ -653,3 +653,41 @@ class Craft:
         if self.soi is not None:
             self._events()
         return 0
+
+
+# ---- Timeline::{new, common_times, divergence_time_before}  ephemeris/src/propagators/spacecraft.rs:129-213 ----
+EPOCH_MIN, EPOCH_MAX = -1.7976931348623157e308, 1.7976931348623157e308
+
+
+def timeline_new(burns):
+    """burns: (start, end, acc[3], ref) -> segments (start, end, thrust) with thrust = None for a coast."""
+    segs, cursor = [], EPOCH_MIN
+    for s, e, acc, ref in sorted(burns, key=lambda b: b[0]):        # sort_by is stable, like sorted()
+        if s > cursor:
+            segs.append((cursor, s, None))
+        cursor = e
+        segs.append((s, e, (tuple(float(x) for x in acc), int(ref))))
+    if cursor < EPOCH_MAX:
+        segs.append((cursor, EPOCH_MAX, None))
+    return segs
+
+
+def timeline_common_times(a, b):
+    out, done = [], False
+    for s1, s2 in zip(a, b):
+        if done or s1[0] != s2[0]:
+            break
+        out.append(s1[0])
+        if s1[2] != s2[2]:
+            done = True
+    return out
+
+
+def timeline_divergence_time_before(new_burns, old_burns, before):
+    """self = the new timeline (flight_plan.rs:289-291). None where the reference would panic (unwrap on empty)."""
+    times = []
+    for t in timeline_common_times(timeline_new(new_burns), timeline_new(old_burns)):
+        if not t < before:
+            break
+        times.append(t)
+    return times[-1] if times else None
