@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
-    "eph_craft_batch_reset_knots", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
+    "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
 ]
 
@@ -160,6 +160,7 @@ def _lib():
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
     L.eph_craft_batch_reset_knots.argtypes = [vp]
+    L.eph_craft_batch_reset_events.argtypes = [vp]
     L.eph_timeline_divergence_time.argtypes = [i64, _dp, _dp, _dp, _i32p, i64, _dp, _dp, _dp, _i32p, f64, _dp]
     L.eph_craft_batch_enable_events.argtypes = [vp, _dp, i32, i32]
     L.eph_craft_batch_event_counts.argtypes = [vp, _i32p, _i32p, _i32p]
@@ -562,6 +563,10 @@ class SpacecraftBatch:
     def reset_knots(self):
         """Keep only the newest knot of every craft (as knot 0) and clear KNOTS_FULL: the drain point of a long run."""
         _check(self._L.eph_craft_batch_reset_knots(self._h), "eph_craft_batch_reset_knots")
+
+    def reset_events(self):
+        """Keep only the newest SOI transition of every craft, drop the apsides, clear EVENTS_FULL (after reading)."""
+        _check(self._L.eph_craft_batch_reset_events(self._h), "eph_craft_batch_reset_events")
 
     def enable_events(self, soi_radius, max_transitions=64, max_apsides=1024):
         """Switch to the app's SpacecraftSolout: SOI transitions + apsides per accepted step (call before propagate)."""

@@ -616,6 +616,10 @@ __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
         seg = 0;
     }
     for (; !full && seg + 1 < nk; ++seg) {            // solout :539-586 for the step that produced knot seg + 1
+        // a slab counts as full while fewer than two entries are free at a step boundary, so that draining
+        // (eph_craft_batch_reset_events) resumes exactly at a step; a step needing more than that (several
+        // crossings at once into a nearly full slab) still reports EVENTS_FULL, from inside the step
+        if (ntr + 2 > a.max_tr || nap + 2 > a.max_ap) { full = true; break; }
         const double t0 = a.knot_t[(long long)seg * n + i], t1 = a.knot_t[(long long)(seg + 1) * n + i];
         const V3 p0 = {knot(seg, 0), knot(seg, 1), knot(seg, 2)}, d0 = {knot(seg, 3), knot(seg, 4), knot(seg, 5)};
         const V3 p1 = {knot(seg + 1, 0), knot(seg + 1, 1), knot(seg + 1, 2)};
@@ -672,6 +676,22 @@ __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
     a.ntr[i] = ntr;
     a.nap[i] = nap;
     if (full) a.ev_status[i] = EPH_EVENTS_FULL;
+}
+
+// eph_craft_batch_reset_events: keeps the newest transition (the sphere the craft is in -- what
+// SoiTransitions::starting_at needs for the next step), drops the older ones and all apsides, clears EVENTS_FULL
+__global__ void __launch_bounds__(256) k_craft_reset_events(long long n, int *ntr, int *nap, int *ev_status,
+                                                            double *tr_time, int *tr_body) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = ntr[i];
+    if (k > 1) {
+        tr_time[i] = tr_time[(long long)(k - 1) * n + i];
+        tr_body[i] = tr_body[(long long)(k - 1) * n + i];
+        ntr[i] = 1;
+    }
+    nap[i] = 0;
+    if (ev_status[i] == EPH_EVENTS_FULL) ev_status[i] = EPH_OK;
 }
 
 // eph_craft_batch_reset_knots: the newest knot of every craft becomes knot 0 of an otherwise empty slab (the next
@@ -1200,6 +1220,18 @@ int32_t eph_craft_batch_reset_knots(eph_craft_batch *b) {
                        b->nknots.p, b->status.p, b->knot_t.p, b->knot_y.p, b->events ? b->ev_seg.p : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("k_craft_reset_knots", e); return EPH_ERR_HIP; }
+    EPH_HIP(hipStreamSynchronize(b->stream));
+    return EPH_OK;
+}
+
+int32_t eph_craft_batch_reset_events(eph_craft_batch *b) {
+    if (!b || !b->events) return EPH_ERR_BAD_ARGUMENT;
+    if (b->n == 0) return EPH_OK;
+    EPH_HIP(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_craft_reset_events, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->stream, b->n,
+                       b->ntr.p, b->nap.p, b->ev_status.p, b->tr_time.p, b->tr_body.p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("k_craft_reset_events", e); return EPH_ERR_HIP; }
     EPH_HIP(hipStreamSynchronize(b->stream));
     return EPH_OK;
 }

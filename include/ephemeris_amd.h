@@ -232,7 +232,9 @@ int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, doub
  * EntityHashMap, whose order is unspecified). apsis kind: 0 = Periapsis, 1 = Apoapsis. */
 int32_t eph_craft_batch_enable_events(eph_craft_batch *b, const double *soi_radius, int32_t max_transitions,
                                       int32_t max_apsides);
-/* per craft: number of transitions / apsides, and EPH_OK or EPH_EVENTS_FULL. Any pointer may be NULL. */
+/* per craft: number of transitions / apsides, and EPH_OK or EPH_EVENTS_FULL (raised at a step boundary as soon as
+ * fewer than two entries are free in either slab, so max_transitions and max_apsides must be >= 3). Any pointer may
+ * be NULL. */
 int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions, int32_t *n_apsides,
                                      int32_t *event_status);
 /* one craft's sorted lists (arrays sized by eph_craft_batch_event_counts; any may be NULL) */
@@ -252,6 +254,10 @@ int32_t eph_timeline_divergence_time(int64_t n_old, const double *old_start, con
  * what CubicHermiteSpline::extend, ephemeris/src/trajectory.rs:842-844, needs to stitch them, minus the duplicate), EPH_KNOTS_FULL is cleared and the next
  * eph_craft_batch_propagate continues. Events already found are kept. */
 int32_t eph_craft_batch_reset_knots(eph_craft_batch *b);
+/* Drain point for the event slabs: after the caller has read them, only the newest transition of every craft (the
+ * sphere it is in) is kept, apsides are emptied and EPH_EVENTS_FULL is cleared. A craft whose slab filled up in the
+ * middle of a propagate call resumes its event search from the step where it stopped at the next propagate. */
+int32_t eph_craft_batch_reset_events(eph_craft_batch *b);
 int32_t eph_craft_batch_kernel_time(eph_craft_batch *b, double *total_ms);
 void eph_craft_batch_destroy(eph_craft_batch *b);
 /* CubicHermiteSpline::state_vector (ephemeris/src/trajectory.rs:766-797) at m epochs, on the device */
