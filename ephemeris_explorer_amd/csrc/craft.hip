@@ -51,6 +51,7 @@ struct CraftArgs {
     int max_knots;
     // method + controller
     ErkCoeffs rk;
+    const ErkCoeffs *rkd;     // the same table in device memory (k_craft_wave indexes it by stage at run time)
     double h_init, h_max, tol_pos, tol_vel, fac_min, fac_max, fac;
     unsigned n_max;
     double t_end;
@@ -157,41 +158,99 @@ __device__ __forceinline__ bool spline_locate(const BodyEntry &b, double at, lon
     return true;
 }
 
+// One body's term of Bodies::acceleration (dynamics/spacecraft.rs:70-74,222-228): segment lookup, Horner, point mass.
+__device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &be, double t, const V3 &pos, V3 &term) {
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) return false;
+    // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so
+    // the leading steps give 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no
+    // ncoef load, no loop, and twelve 16-byte loads in flight at once
+    const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (be.coeff_off + idx) * kDiv * 3);
+    double c[kDiv * 3];
+#pragma unroll
+    for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
+    V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + c[k * 3 + 0];
+        bp.y = bp.y * tau + c[k * 3 + 1];
+        bp.z = bp.z * tau + c[k * 3 + 2];
+    }
+    const V3 d = sub(bp, pos);                        // acceleration_at::<false>: dir = body - at
+    const double n2 = dot(d, d);
+    double inv;                                       // 1 / (n2 * sqrt(n2)), IEEE sqrt and divide (device_math.h)
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
+    else inv = 1.0 / (n2 * sqrt(n2));
+    term = scale(d, be.mu * inv);
+    return true;
+}
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kCraftWaveMax = 4096;                  // batches up to this size run one wave per spacecraft
+constexpr int kRedRow = kTile + 2;                    // LDS row of the wave variant's contribution tile
+
 // FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.
+// WAVE = false: one thread per spacecraft, the bodies in a loop. WAVE = true: one WAVE per spacecraft (every lane
+// carries the same craft state): lane b evaluates body b, the terms go through LDS and lanes 0..2 add them in body
+// order -- the same chain of f64 additions -- then the sum is broadcast. `red` = 3 x kRedRow doubles of LDS.
+template <bool WAVE>
 __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &sg, double t, const double (&y)[6],
-                                          double (&dy)[6]) {
+                                          double (&dy)[6], double *red) {
     const V3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
     V3 acc = {0.0, 0.0, 0.0};
-    for (int b = 0; b < a.n_bodies; ++b) {            // Bodies::acceleration: index order
-        // the body's table entry is the same for every lane: scalar loads through the constant address space
-        const int bu = __builtin_amdgcn_readfirstlane(b);
-        const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
-        BodyEntry be;
-        be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
-        be.coeff_off = bc->coeff_off;
-        long long idx;
-        double tau;
-        if (!spline_locate(be, t, idx, tau)) return false;
-        // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so
-        // the leading steps give 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no
-        // ncoef load, no loop, and twelve 16-byte loads in flight at once
-        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (be.coeff_off + idx) * kDiv * 3);
-        double c[kDiv * 3];
+    if (WAVE) {
+        const int lane = threadIdx.x;
+        for (int b0 = 0; b0 < a.n_bodies; b0 += kTile) {
+            const int b = b0 + lane;
+            V3 term = {0.0, 0.0, 0.0};
+            bool located = true;
+            if (b < a.n_bodies) {
+                const BodyEntry be = a.bodies[b];
+                located = body_term(a, be, t, pos, term);
+            }
+            if (__builtin_amdgcn_ballot_w64(!located)) return false;
+            red[lane] = term.x;                       // lanes past the last body contribute +0.0 (exact to add)
+            red[kRedRow + lane] = term.y;
+            red[2 * kRedRow + lane] = term.z;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int left = a.n_bodies - b0;
+            const int cnt = ((left < kTile ? left : kTile) + 15) & ~15;
+            double sum = lane == 0 ? acc.x : (lane == 1 ? acc.y : acc.z);
+            if (lane < 3) {
+                const double *row = red + lane * kRedRow;
+                for (int c = 0; c < cnt; c += 16) {
+                    double2 r[8];
 #pragma unroll
-        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
-        V3 bp = {0.0, 0.0, 0.0};
+                    for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const double2 *>(row + c + 2 * k);
 #pragma unroll
-        for (int k = kDiv - 1; k >= 0; --k) {
-            bp.x = bp.x * tau + c[k * 3 + 0];
-            bp.y = bp.y * tau + c[k * 3 + 1];
-            bp.z = bp.z * tau + c[k * 3 + 2];
+                    for (int k = 0; k < 8; ++k) {
+                        sum = sum + r[k].x;
+                        sum = sum + r[k].y;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            acc.x = lane_bcast(sum, 0);
+            acc.y = lane_bcast(sum, 1);
+            acc.z = lane_bcast(sum, 2);
         }
-        const V3 d = sub(bp, pos);                    // acceleration_at::<false>: dir = body - at
-        const double n2 = dot(d, d);
-        double inv;                                   // 1 / (n2 * sqrt(n2)), IEEE sqrt and divide (device_math.h)
-        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
-        else inv = 1.0 / (n2 * sqrt(n2));
-        acc = add(acc, scale(d, be.mu * inv));
+    } else {
+        for (int b = 0; b < a.n_bodies; ++b) {        // Bodies::acceleration: index order
+            // the body's table entry is the same for every lane: scalar loads through the constant address space
+            const int bu = __builtin_amdgcn_readfirstlane(b);
+            const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
+            BodyEntry be;
+            be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
+            be.coeff_off = bc->coeff_off;
+            V3 term;
+            if (!body_term(a, be, t, pos, term)) return false;
+            acc = add(acc, term);
+        }
     }
     V3 man = {0.0, 0.0, 0.0};
     if (sg.is_burn) {
@@ -326,7 +385,7 @@ k_craft_propagate(const CraftArgs a) {
                         }
                     }
                     double out[6];
-                    ok = craft_rhs(a, sg, ti, yi, out);
+                    ok = craft_rhs<false>(a, sg, ti, yi, out, nullptr);
 #pragma unroll
                     for (int d = 0; d < 3; ++d) k[s][d] = out[3 + d];
                     continue;
@@ -339,7 +398,7 @@ k_craft_propagate(const CraftArgs a) {
 #pragma unroll
                     for (int d = 0; d < 6; ++d) yi[d] = yi[d] + k[j][d] * ha;
                 }
-                ok = craft_rhs(a, sg, ti, yi, k[s]);
+                ok = craft_rhs<false>(a, sg, ti, yi, k[s], nullptr);
             }
             if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
             double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -425,6 +484,216 @@ k_craft_propagate(const CraftArgs a) {
     if (FSAL) {
 #pragma unroll
         for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_craft_wave: ONE WAVE per spacecraft -- the form for few spacecraft (the app's handful of ships), where the
+// thread form leaves the chip empty and needs ~0.27 ms per step of a craft (13 stages x 32 body terms in sequence).
+// Every lane carries the same craft state; in the right-hand side lane b evaluates body b and lanes 0..2 add the
+// terms in body order (craft_rhs<true>). The stage derivatives live in LDS (uniform, read back as broadcasts), so
+// the stage loop is a run-time loop around one copy of the right-hand side: the code fits the instruction cache
+// (with stages unrolled a single wave spends its time fetching ~100 KB of instructions per attempt: measured
+// 50 us per step) and one kernel serves every method. Same operations in the same order as k_craft_propagate.
+// ------------------------------------------------------------------------------------------------------
+template <bool NYS>
+__global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
+    __shared__ __attribute__((aligned(16))) double K[16 * 6];          // k[s][d] (ERK) / dk[s][0..2] (ERKNG)
+    __shared__ __attribute__((aligned(16))) double red[3 * kRedRow];
+    const long long i = blockIdx.x, n = a.n_craft;
+    const int lane = threadIdx.x;
+    int status = a.status[i];
+    if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
+    status = EPH_OK;
+    const auto *rc = (const __attribute__((address_space(4))) ErkCoeffs *)(unsigned long long)a.rkd;
+    const int S = a.rk.stages;
+    const bool FSAL = a.rk.fsal != 0;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto put_k = [&](int s, const double (&v)[6]) {                // lane 0 writes row s
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) K[s * 6 + d] = v[d];
+        }
+        wave_sync();
+    };
+
+    double time = a.time[i], y[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) y[d] = a.y[d * n + i];
+    double next_h = a.next_h[i];
+    unsigned n_att = a.n_attempts[i], rk_i = a.rk_i[i], steps = a.steps[i];
+    int cur = a.cur_seg[i], nk = a.nknots[i];
+    double last_knot = a.last_knot_t[i];
+    const SegmentDev *segs = a.segs + a.seg_off[i];
+    SegmentDev sg = segs[cur];
+    double bound = sg.end;
+    if (FSAL) {
+        double kl[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) kl[d] = a.klast[d * n + i];
+        put_k(S - 1, kl);
+    }
+    const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+
+    while (!(last_knot >= a.t_end)) {                 // has_reached: solution.end() >= time
+        if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
+        if (time >= sg.end) {                         // advance_timeline + reset_integrator  spacecraft.rs:606-609
+            cur += 1;
+            sg = segs[cur];
+            bound = sg.end;
+            next_h = a.h_init;
+            n_att = 0;
+            rk_i = 0;
+        }
+        // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439
+        const double prev_t = time;
+        double prev_y[6], prev_klast[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? K[(S - 1) * 6 + d] : 0.0; }
+        const unsigned prev_i = rk_i;
+        bool failed = false;
+        for (;;) {
+            if (n_att > a.n_max) { status = EPH_MAX_ITERATIONS_REACHED; failed = true; break; }
+            if (time + next_h > bound) next_h = bound - time;
+            const double h = next_h;
+            if (time >= bound) { status = EPH_BOUND_REACHED; failed = true; break; }
+            if (time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; break; }
+            bool ok = true;
+            for (int sv = 0; sv < S; ++sv) {          // ERK::advance explicit.rs:72-106 / ERKNG::advance :97-143
+                const int s = __builtin_amdgcn_readfirstlane(sv);
+                if (FSAL && s == 0 && rk_i > 0) {     // self.k.swap(0, STAGES - 1); continue
+                    double k0[6], kl[6];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) { k0[d] = K[d]; kl[d] = K[(S - 1) * 6 + d]; }
+                    wave_sync();
+                    put_k(0, kl);
+                    put_k(S - 1, k0);
+                    continue;
+                }
+                if (!ok) continue;
+                const double ti = time + h * rc->C[s];
+                double yi[6], out[6];
+                if (NYS) {
+                    const double hc = h * rc->C[s];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { yi[d] = y[d] + y[3 + d] * hc; yi[3 + d] = y[3 + d]; }
+                    for (int jv = 0; jv < s; ++jv) {
+                        const int j = __builtin_amdgcn_readfirstlane(jv);
+                        const double hhap = h * h * rc->A[s][j], hav = h * rc->A2[s & 7][j & 7];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const double kj = K[j * 6 + d];
+                            yi[d] = yi[d] + kj * hhap;
+                            yi[3 + d] = yi[3 + d] + kj * hav;
+                        }
+                    }
+                    ok = craft_rhs<true>(a, sg, ti, yi, out, red);
+                    const double dk[6] = {out[3], out[4], out[5], 0.0, 0.0, 0.0};
+                    put_k(s, dk);
+                    continue;
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) yi[d] = y[d];
+                for (int jv = 0; jv < s; ++jv) {
+                    const int j = __builtin_amdgcn_readfirstlane(jv);
+                    const double ha = h * rc->A[s][j];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) yi[d] = yi[d] + K[j * 6 + d] * ha;
+                }
+                ok = craft_rhs<true>(a, sg, ti, yi, out, red);
+                put_k(s, out);
+            }
+            if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
+            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (NYS) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) y[d] = y[d] + y[3 + d] * h;
+                for (int sv = 0; sv < S; ++sv) {
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double hhbp = h * h * rc->B[s], hbv = h * rc->B2[s & 7];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const double ks = K[s * 6 + d];
+                        y[d] = y[d] + ks * hhbp;
+                        y[3 + d] = y[3 + d] + ks * hbv;
+                    }
+                }
+                for (int sv = 0; sv < S; ++sv) {
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double hhep = h * h * rc->E[s], hev = h * rc->E2[s & 7];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const double ks = K[s * 6 + d];
+                        e[d] = e[d] + ks * hhep;
+                        e[3 + d] = e[3 + d] + ks * hev;
+                    }
+                }
+            } else {
+                for (int sv = 0; sv < S; ++sv) {
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double hb = h * rc->B[s];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) y[d] = y[d] + K[s * 6 + d] * hb;
+                }
+                for (int sv = 0; sv < S; ++sv) {      // RKEmbedded::error
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double he = h * rc->E[s];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) e[d] = e[d] + K[s * 6 + d] * he;
+                }
+            }
+            time = time + h;
+            rk_i += 1;
+            n_att += 1;
+            // AbsTol::err_over_tol
+            const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
+            const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
+            const double err = fmax(pm, vm);
+            // IController::step  mod.rs:225-243
+            const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
+            const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
+            const double nh = next_h * c;
+            next_h = nh > a.h_max ? a.h_max : nh;
+            if (err <= 1.0) break;
+            time = prev_t;                            // PreviousStep::restore
+#pragma unroll
+            for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+            rk_i = prev_i;
+            if (FSAL) {
+                wave_sync();
+                put_k(S - 1, prev_klast);
+            }
+        }
+        if (failed) break;
+        steps += 1;
+        if (lane == 0) {                              // CubicHermiteSplineSolout::solout: push (t, r, v)
+            a.knot_t[(long long)nk * n + i] = time;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + i] = y[d];
+        }
+        nk += 1;
+        last_knot = time;
+    }
+
+    if (lane == 0) {
+        a.time[i] = time;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.y[d * n + i] = y[d];
+        a.next_h[i] = next_h;
+        a.n_attempts[i] = n_att;
+        a.rk_i[i] = rk_i;
+        a.steps[i] = steps;
+        a.cur_seg[i] = cur;
+        a.nknots[i] = nk;
+        a.last_knot_t[i] = last_knot;
+        a.status[i] = status;
+        if (FSAL) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) a.klast[d * n + i] = K[(S - 1) * 6 + d];
+        }
     }
 }
 
@@ -785,6 +1054,21 @@ __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double
 }
 
 static int craft_launch(hipStream_t s, const CraftArgs &a) {
+    // few spacecraft: one wave each (k_craft_wave); many: one thread each (k_craft_propagate). Measured crossover on
+    // MI355X, Verner87, 32 bodies: see scripts/bench_craft_small.py and profiles/README.md
+    static const int form = [] {
+        const char *e = getenv("EPH_CRAFT_FORM");      // "wave" | "thread" (tuning / tests)
+        return !e ? 0 : (e[0] == 'w' ? 1 : 2);
+    }();
+    const bool wave = form ? form == 1 : a.n_craft <= kCraftWaveMax;
+    if (wave) {
+        const dim3 grid((unsigned)a.n_craft), block(64);
+        if (a.rk.nystrom) hipLaunchKernelGGL(k_craft_wave<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(k_craft_wave<false>, grid, block, 0, s, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error("k_craft_wave", e); return EPH_ERR_HIP; }
+        return EPH_OK;
+    }
     const dim3 grid((unsigned)((a.n_craft + 63) / 64)), block(64);
     // more waves of craft than SIMDs (256 CUs x 4): hold the kernel to two waves per SIMD (EPH_CRAFT_OCC overrides)
     static const int forced = [] { const char *e = getenv("EPH_CRAFT_OCC"); return e ? atoi(e) : 0; }();
@@ -839,6 +1123,7 @@ struct eph_craft_batch {
     DevBuf<int> cur_seg, status, nknots;
     DevBuf<long long> seg_off;
     DevBuf<SegmentDev> segs;
+    DevBuf<ErkCoeffs> rk_dev;
     // SpacecraftSolout events (optional)
     bool events = false;
     int max_tr = 0, max_ap = 0;
@@ -996,8 +1281,9 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             (st = b->rk_i.alloc(nn)) || (st = b->steps.alloc(nn)) || (st = b->cur_seg.alloc(nn)) ||
             (st = b->status.alloc(nn)) || (st = b->nknots.alloc(nn)) || (st = b->seg_off.alloc(n + 1)) ||
             (st = b->segs.alloc(std::max<size_t>(segs.size(), 1))) || (st = b->knot_t.alloc(nn * max_knots)) ||
-            (st = b->knot_y.alloc(6 * nn * max_knots)))
+            (st = b->knot_y.alloc(6 * nn * max_knots)) || (st = b->rk_dev.alloc(1)))
             return st;
+        EPH_HIP(hipMemcpy(b->rk_dev.p, &b->rk, sizeof(ErkCoeffs), hipMemcpyHostToDevice));
         if (n > 0) {
             std::vector<double> ysoa(6 * n), hs(n, params->h_init);
             for (long long i = 0; i < n; ++i)
@@ -1039,6 +1325,7 @@ int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) {
     a.seg_off = b->seg_off.p; a.segs = b->segs.p;
     a.knot_t = b->knot_t.p; a.knot_y = b->knot_y.p; a.max_knots = b->max_knots;
     a.rk = b->rk;
+    a.rkd = b->rk_dev.p;
     a.h_init = b->params.h_init; a.h_max = b->params.h_max; a.tol_pos = b->params.tol_position;
     a.tol_vel = b->params.tol_velocity; a.fac_min = b->params.fac_min; a.fac_max = b->params.fac_max;
     a.fac = b->params.fac; a.n_max = b->params.n_max;
