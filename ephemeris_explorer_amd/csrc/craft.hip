@@ -78,6 +78,9 @@ __device__ __forceinline__ bool try_normalize(V3 a, V3 &out) {
 // operation on the path whose bits depend on the platform. Evaluated here correctly rounded in double-double
 // arithmetic (log: atanh series, exp: Taylor series, ~100 bits), the same operation sequence the oracle pins.
 struct DD { double hi, lo; };
+#define EPH_POW_CONST __device__ const
+typedef DD EPH_POW_DD;
+#include "cr_pow_tables.inc"
 __device__ __forceinline__ DD dd_two_sum(double a, double b) {
     const double s = a + b, bb = s - a;
     return {s, (a - (s - bb)) + (b - bb)};
@@ -123,8 +126,9 @@ __device__ __noinline__ double cr_pow(double x, double y) {
     if (m < 0x1.6a09e667f3bcdp-1) { m *= 2.0; e -= 1; }
     const DD s = dd_div(DD{m - 1.0, 0.0}, dd_two_sum(m, 1.0));
     const DD s2 = dd_mul(s, s);
-    DD sum = dd_div(DD{1.0, 0.0}, DD{61.0, 0.0});
-    for (int k = 29; k >= 0; --k) sum = dd_add(dd_mul(sum, s2), dd_div(DD{1.0, 0.0}, DD{(double)(2 * k + 1), 0.0}));
+    // atanh(s)/s = sum_k s2^k / (2k+1), Horner over the double-double table (remainder < 2^-120)
+    DD sum = {eph_pow_atanh[EPH_POW_TERMS - 1].hi, eph_pow_atanh[EPH_POW_TERMS - 1].lo};
+    for (int k = EPH_POW_TERMS - 2; k >= 0; --k) sum = dd_add(dd_mul(sum, s2), DD{eph_pow_atanh[k].hi, eph_pow_atanh[k].lo});
     DD lg = dd_mul(dd_mul_d(s, 2.0), sum);
     lg = dd_add(dd_mul_d(ln2, (double)e), lg);
     const DD z = dd_mul_d(lg, y);
@@ -132,11 +136,9 @@ __device__ __noinline__ double cr_pow(double x, double y) {
     if (z.hi < -745.0) return 0.0;
     const double kf = nearbyint(z.hi / ln2.hi);
     const DD r = dd_add(z, dd_neg(dd_mul_d(ln2, kf)));
-    DD term = {1.0, 0.0}, ex = {1.0, 0.0};
-    for (int n = 1; n <= 30; ++n) {
-        term = dd_div(dd_mul(term, r), DD{(double)n, 0.0});
-        ex = dd_add(ex, term);
-    }
+    // exp(r) = sum_n r^n / n!, Horner over the double-double table, |r| <= ln2/2
+    DD ex = {eph_pow_invfact[EPH_POW_TERMS - 1].hi, eph_pow_invfact[EPH_POW_TERMS - 1].lo};
+    for (int n = EPH_POW_TERMS - 2; n >= 0; --n) ex = dd_add(dd_mul(ex, r), DD{eph_pow_invfact[n].hi, eph_pow_invfact[n].lo});
     return ldexp(ex.hi + ex.lo, (int)kf);
 }
 __global__ void k_debug_pow(long long n, const double *__restrict__ x, double y, double *__restrict__ out) {

@@ -1066,6 +1066,9 @@ static inline dd_t dd_div(dd_t a, dd_t b) {
     return dd_add(q, (dd_t){q3, 0.0});
 }
 static const dd_t DD_LN2 = {0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56};
+#define EPH_POW_CONST const
+typedef struct { double hi, lo; } EPH_POW_DD;
+#include "cr_pow_tables.inc"
 
 static double cr_pow(double x, double y) {
     if (isnan(x) || isnan(y)) return NAN;
@@ -1078,8 +1081,10 @@ static double cr_pow(double x, double y) {
     if (m < 0x1.6a09e667f3bcdp-1) { m *= 2.0; e -= 1; }
     const dd_t s = dd_div((dd_t){m - 1.0, 0.0}, dd_two_sum(m, 1.0));
     const dd_t s2 = dd_mul(s, s);
-    dd_t sum = dd_div((dd_t){1.0, 0.0}, (dd_t){61.0, 0.0});
-    for (int k = 29; k >= 0; --k) sum = dd_add(dd_mul(sum, s2), dd_div((dd_t){1.0, 0.0}, (dd_t){(double)(2 * k + 1), 0.0}));
+    /* atanh(s)/s = sum_k s2^k / (2k+1), Horner over the double-double table (remainder < 2^-120) */
+    dd_t sum = {eph_pow_atanh[EPH_POW_TERMS - 1].hi, eph_pow_atanh[EPH_POW_TERMS - 1].lo};
+    for (int k = EPH_POW_TERMS - 2; k >= 0; --k)
+        sum = dd_add(dd_mul(sum, s2), (dd_t){eph_pow_atanh[k].hi, eph_pow_atanh[k].lo});
     dd_t lg = dd_mul(dd_mul_d(s, 2.0), sum);
     lg = dd_add(dd_mul_d(DD_LN2, (double)e), lg);
     /* z = y*log(x); exp(z) = 2^k * exp(r), r = z - k*ln2 */
@@ -1088,11 +1093,10 @@ static double cr_pow(double x, double y) {
     if (z.hi < -745.0) return 0.0;
     const double kf = nearbyint(z.hi / DD_LN2.hi);
     const dd_t r = dd_add(z, (dd_t){-dd_mul_d(DD_LN2, kf).hi, -dd_mul_d(DD_LN2, kf).lo});
-    dd_t term = {1.0, 0.0}, ex = {1.0, 0.0};
-    for (int n = 1; n <= 30; ++n) {
-        term = dd_div(dd_mul(term, r), (dd_t){(double)n, 0.0});
-        ex = dd_add(ex, term);
-    }
+    /* exp(r) = sum_n r^n / n!, Horner over the double-double table, |r| <= ln2/2 */
+    dd_t ex = {eph_pow_invfact[EPH_POW_TERMS - 1].hi, eph_pow_invfact[EPH_POW_TERMS - 1].lo};
+    for (int n = EPH_POW_TERMS - 2; n >= 0; --n)
+        ex = dd_add(dd_mul(ex, r), (dd_t){eph_pow_invfact[n].hi, eph_pow_invfact[n].lo});
     return ldexp(ex.hi + ex.lo, (int)kf);
 }
 static int g_pow_mode = 0;   /* 0: correctly rounded (the pinned definition), 1: this host's libm pow */
