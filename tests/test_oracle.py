@@ -273,3 +273,26 @@ def test_least_squares_fit_reproduces_polynomials():
         assert n == deg + 1 and np.abs(co[: deg + 1] - c).max() < 1e-5
     co, n = orc.least_squares_fit(5, ts, np.zeros((9, 3)))
     assert n == 0                                               # trim() removes exact zeros
+
+
+def test_f64_recurrence_vs_exact_arithmetic():
+    """how far a correct f64 evaluation of the QuinlanTremaine12 recurrence sits from the same recurrence
+    in exact (40-digit) arithmetic -- the Python restatement run over mpmath numbers. sun_earth_moon, dt = 6 h, 3000
+    steps (2 years): ~3e-4 km = 2e-12 AU; with round-off growing like steps^1.5 that is ~4e-10 AU at 1e5 steps, so the
+    north star's 1e-9 AU bound separates "a correct f64 implementation" from "a different algorithm". (The GPU does
+    not need the margin: it reproduces the oracle's bits.)"""
+    import mpmath as mp
+    s = load_system("sun_earth_moon_2433282.5")
+    steps = 3000
+    with mp.workdps(40):
+        p = po.Problem(s.pos, s.vel, s.mu, s.epoch, num=mp.mpf, sqrt=mp.sqrt)
+        lm = po.LinearMultistep2("QuinlanTremaine12", s.dt, p, num=mp.mpf)
+        for _ in range(steps):
+            lm.advance()
+        exact = np.array([[float(c) for c in r] for r in p.y])
+    o = orc.NBody(s.pos, s.vel, s.mu, s.epoch, s.dt)
+    assert o.advance(steps) == 0
+    d = np.abs(o.state()[0] - exact).max()
+    au = 1.495978707e8
+    assert 0.0 < d / au < 2e-11
+    assert d / au * (1e5 / steps) ** 1.5 < 1e-9
