@@ -872,8 +872,12 @@ __device__ bool ap_insert(const EventArgs &a, long long i, int &nap, double time
     a.ap_kind[(long long)lo * n + i] = kind;
     return true;
 }
+// WAVE = true (few spacecraft): one wave per craft, every lane in the same state; the sign tests of the SOI search
+// -- two body evaluations per body and step, almost never followed by a crossing -- run with lane b on body b, and
+// only the bodies whose sign changes go through the (wave-uniform) bisection, in body order.
+template <bool WAVE>
 __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = WAVE ? (long long)blockIdx.x : (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_craft) return;
     const long long n = a.n_craft;
     if (a.ev_status[i] != EPH_OK) return;
@@ -909,15 +913,34 @@ __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
             h.a2 = sub(scale(scale(dt_val, dt_recip_2), 3.0), scale(add(scale(d0, 2.0), d1), dt_recip));
             h.a3 = add(scale(scale(dt_val, dt_recip_3), -2.0), scale(add(d0, d1), dt_recip_2));
         }
-        for (int b = 0; b < a.n_bodies && !full; ++b) {
+        auto crossing = [&](int b) {                   // one body's find_soi_crossing and its consequence
             double time;
             bool asc;
-            if (!find_zero_crossing<false>(a, h, b, t0, t1, time, asc)) continue;
+            if (!find_zero_crossing<false>(a, h, b, t0, t1, time, asc)) return;
             if (!asc) full = !tr_insert(a, i, ntr, time, b);      // Descending: entered b's sphere
             else {
                 const int entered = soi_at_except(a, time, hermite_pos(h, time), b);
                 if (entered >= 0) full = !tr_insert(a, i, ntr, time, entered);
             }
+        };
+        if (WAVE) {
+            for (int b0 = 0; b0 < a.n_bodies && !full; b0 += kTile) {
+                const int b = b0 + (int)threadIdx.x;
+                bool cross = false;
+                if (b < a.n_bodies) {                  // the sign test of find_zero_crossing, lane b on body b
+                    double f0, f1;
+                    cross = event_f<false>(a, h, b, t0, f0) && event_f<false>(a, h, b, t1, f1) &&
+                            f64_signum(f0) != f64_signum(f1);
+                }
+                unsigned long long mask = __builtin_amdgcn_ballot_w64(cross);
+                while (mask && !full) {                // body order
+                    const int lb = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    crossing(b0 + lb);
+                }
+            }
+        } else {
+            for (int b = 0; b < a.n_bodies && !full; ++b) crossing(b);
         }
         if (full) break;
         int lo = 0, hi = ntr, i0 = -1;                // transitions.starting_at(t0) :326-329
@@ -1055,14 +1078,17 @@ __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double
     inside[q] = 1;
 }
 
-static int craft_launch(hipStream_t s, const CraftArgs &a) {
-    // few spacecraft: one wave each (k_craft_wave); many: one thread each (k_craft_propagate). Measured crossover on
-    // MI355X, Verner87, 32 bodies: see scripts/bench_craft_small.py and profiles/README.md
+// few spacecraft: one wave each (k_craft_wave, k_craft_events<true>); many: one thread each. Measured crossover on
+// MI355X, Verner87, 32 bodies: see scripts/bench_craft_small.py and profiles/README.md
+static bool craft_wave_form(long long n_craft) {
     static const int form = [] {
         const char *e = getenv("EPH_CRAFT_FORM");      // "wave" | "thread" (tuning / tests)
         return !e ? 0 : (e[0] == 'w' ? 1 : 2);
     }();
-    const bool wave = form ? form == 1 : a.n_craft <= kCraftWaveMax;
+    return form ? form == 1 : n_craft <= kCraftWaveMax;
+}
+static int craft_launch(hipStream_t s, const CraftArgs &a) {
+    const bool wave = craft_wave_form(a.n_craft);
     if (wave) {
         const dim3 grid((unsigned)a.n_craft), block(64);
         if (a.rk.nystrom) hipLaunchKernelGGL(k_craft_wave<true>, grid, block, 0, s, a);
@@ -1344,7 +1370,8 @@ int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) {
         e.tr_time = b->tr_time.p; e.tr_body = b->tr_body.p;
         e.ap_time = b->ap_time.p; e.ap_dist = b->ap_dist.p; e.ap_body = b->ap_body.p; e.ap_kind = b->ap_kind.p;
         e.max_tr = b->max_tr; e.max_ap = b->max_ap;
-        hipLaunchKernelGGL(k_craft_events, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, b->stream, e);
+        if (craft_wave_form(b->n)) hipLaunchKernelGGL(k_craft_events<true>, dim3((unsigned)b->n), dim3(64), 0, b->stream, e);
+        else hipLaunchKernelGGL(k_craft_events<false>, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, b->stream, e);
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) { set_last_error("k_craft_events", he); return EPH_ERR_HIP; }
     }

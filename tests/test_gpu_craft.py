@@ -351,3 +351,19 @@ def test_config4_full_size_sweep(gpu):
     again.propagate(t_end)
     f2 = again.state()
     assert np.array_equal(bits(f2["pos"]), bits(fin["pos"])) and np.array_equal(bits(f2["t"]), bits(fin["t"]))
+
+
+def test_thread_form_on_small_batches(gpu):
+    """Batches of up to 4096 spacecraft run one wave per craft (k_craft_wave, k_craft_events<true>), larger ones one
+    thread per craft. The scenario tests above are small, so they exercise the wave form; this runs the same
+    bit-parity scenarios again with the thread form forced (EPH_CRAFT_FORM is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, EPH_CRAFT_FORM="thread")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_craft.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "mars_transfer or every_embedded or solout_events or slab_overflow or draining"],
+                       env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
