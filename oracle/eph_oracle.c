@@ -173,8 +173,34 @@ static void gravity_eval(int n, const v3 *y, const double *mu, v3 *ddy) {
     }
     g_pair_counter += (uint64_t)n * (uint64_t)(n - 1) / 2;
 }
+/* "What a parallel CPU could do" (SURVEY 8(d)): the same sums partitioned by TARGET body over OpenMP threads. Each
+ * thread evaluates whole rows -- all N^2 directed interactions instead of N(N-1)/2 pairs -- in the reference's
+ * per-body order, so the result has the same bits as gravity_eval: for j < i the term is the `computed.1` half of
+ * pair (j, i), -(p_i - p_j) * (mu_j * inv). Off (0 threads) unless orc_set_gravity_threads is called. */
+static int g_gravity_threads = 0;
+void orc_set_gravity_threads(int t) { g_gravity_threads = t; }
+static void gravity_eval_rows(int n, const v3 *y, const double *mu, v3 *ddy) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(g_gravity_threads)
+    for (int i = 0; i < n; ++i) {
+        v3 acc = ddy[i];
+        for (int j = 0; j < i; ++j) {
+            v3 aj_, ai_;
+            acceleration_paired(y[j], mu[j], y[i], mu[i], &aj_, &ai_);   /* pair (j, i): second half acts on i */
+            acc.x += ai_.x; acc.y += ai_.y; acc.z += ai_.z;
+        }
+        v3 out = {0.0, 0.0, 0.0};
+        for (int j = i + 1; j < n; ++j) {
+            v3 ai, aj;
+            acceleration_paired(y[i], mu[i], y[j], mu[j], &ai, &aj);
+            out.x += ai.x; out.y += ai.y; out.z += ai.z;
+        }
+        acc.x += out.x; acc.y += out.y; acc.z += out.z;
+        ddy[i] = acc;
+    }
+}
 void orc_newtonian_gravity_eval(int n, const double *y, const double *mu, double *ddy) {
-    gravity_eval(n, (const v3 *)y, mu, (v3 *)ddy);
+    if (g_gravity_threads > 1) gravity_eval_rows(n, (const v3 *)y, mu, (v3 *)ddy);
+    else gravity_eval(n, (const v3 *)y, mu, (v3 *)ddy);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -193,7 +219,8 @@ static v3 *v3_dup(const v3 *s, int n) { v3 *d = v3_alloc(n); memcpy(d, s, sizeof
 static void v3_zero(v3 *v, int n) { for (int i = 0; i < n; ++i) v[i].x = v[i].y = v[i].z = 0.0; }
 
 static void ode_eval(problem_t *p, const v3 *y, v3 *ddy_zeroed) {
-    gravity_eval(p->n, y, p->mu, ddy_zeroed);
+    if (g_gravity_threads > 1) gravity_eval_rows(p->n, y, p->mu, ddy_zeroed);
+    else gravity_eval(p->n, y, p->mu, ddy_zeroed);
     p->evals++;
 }
 

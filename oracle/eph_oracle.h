@@ -49,6 +49,9 @@ int orc_erk_coeffs(const char *name, int *stages, int *order, int *order_embedde
 
 /* ---- NewtonianGravity::eval (ephemeris/src/propagators/nbody.rs:16-39) --------------------------- */
 /* y, ddy: AoS xyz; ddy is ACCUMULATED into (caller zeroes), exactly like the reference. */
+/* > 1: gravity evaluated by that many OpenMP threads, partitioned by target body (same bits; all N^2 directed
+ * interactions). 0 / 1: the reference's serial pair loop. Process-wide. */
+void orc_set_gravity_threads(int threads);
 void orc_newtonian_gravity_eval(int n, const double *y, const double *mu, double *ddy);
 /* number of (paired) interactions evaluated since process start -- used by bench.py for ns/pair */
 uint64_t orc_pair_counter(void);

@@ -332,6 +332,11 @@ def poly_eval_and_deriv(coeffs, ncoef, tau):
     return v, d
 
 
+def set_gravity_threads(threads, native=False):
+    """> 1: OpenMP target-partitioned gravity (same bits). Applies to the library variant it is called on."""
+    lib(native).orc_set_gravity_threads(int(threads))
+
+
 def doc_test_decay(method, adaptive, h, h_max=0.0, atol=0.0, rtol=0.0, t_end=5.0):
     steps = C.c_uint32()
     y = lib().orc_doc_test_decay(method.encode(), int(adaptive), h, h_max, atol, rtol, t_end, C.byref(steps))

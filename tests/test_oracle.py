@@ -296,3 +296,21 @@ def test_f64_recurrence_vs_exact_arithmetic():
     au = 1.495978707e8
     assert 0.0 < d / au < 2e-11
     assert d / au * (1e5 / steps) ** 1.5 < 1e-9
+
+
+def test_target_partitioned_openmp_gravity_has_the_same_bits():
+    """bench.py's "all_cores" CPU line evaluates the sums partitioned by target body over OpenMP threads (all N^2
+    directed interactions); it must be the serial pair loop's result bit for bit, through a whole integration."""
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(300)
+    a = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0)
+    assert a.advance(12 + 20) == 0
+    orc.set_gravity_threads(4)
+    try:
+        b = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0)
+        assert b.advance(12 + 20) == 0
+        acc_par = orc.gravity(pos, mu)
+    finally:
+        orc.set_gravity_threads(0)
+    assert np.array_equal(a.state()[0], b.state()[0]) and np.array_equal(a.state()[1], b.state()[1])
+    assert np.array_equal(acc_par, orc.gravity(pos, mu))
