@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
-    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow", "eph_debug_div",
 ]
 
 
@@ -169,6 +169,7 @@ def _lib():
     L.eph_craft_batch_destroy.restype = None
     L.eph_hermite_eval.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _u8p]
     L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
+    L.eph_debug_div.argtypes = [i64, _dp, _dp, _dp, _dp]
     if L.eph_abi_version() != 1:
         raise ImportError("libephemeris_amd.so ABI version mismatch")
     _L = L
@@ -633,6 +634,14 @@ def hermite_eval(t, pos, vel, at, with_velocity=True):
     _check(_lib().eph_hermite_eval(len(t), _p(t), _p(pos), _p(vel), m, _p(at), _p(op), _p(ov) if with_velocity else None,
                                    _p(inside, _u8p)), "eph_hermite_eval")
     return op, (ov if with_velocity else None), inside.astype(bool)
+
+
+def debug_div(a, b):
+    """(shared-reciprocal quotient, compiler IEEE quotient) of a / b on the device."""
+    a, b = _f64(a).ravel(), _f64(b).ravel()
+    fast, ieee = np.zeros_like(a), np.zeros_like(a)
+    _check(_lib().eph_debug_div(a.size, _p(a), _p(b), _p(fast), _p(ieee)), "eph_debug_div")
+    return fast, ieee
 
 
 def debug_pow(x, y):

@@ -187,6 +187,56 @@ __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &b
     term = scale(d, be.mu * inv);
     return true;
 }
+// k_craft_wave: lane b always evaluates body b, so the body's table entry, the refined reciprocal of its spline
+// interval and the coefficients of the polynomial it is currently in stay in the lane's registers; the polynomial is
+// reloaded only when the segment index changes (every few hundred steps). Used when n_bodies <= 64.
+struct LaneBody {
+    BodyEntry be;
+    double r;                 // rcp_refined(be.interval)
+    bool b_ok;                // interval in range for the wrapper-free division
+    long long idx;            // segment whose coefficients are in c (-1: none)
+    double c[kDiv * 3];
+};
+__device__ __forceinline__ bool body_term_cached(const CraftArgs &a, LaneBody &lb, double t, const V3 &pos, V3 &term) {
+    // UniformSpline::get_polynomial, the two divisions by the interval through the shared reciprocal (same quotients)
+    const BodyEntry &b = lb.be;
+    const double local = t - b.start;
+    const double span = b.interval * (double)b.npoly;
+    if (__builtin_signbit(local) || local > span) return false;
+    const double cq = ceil(div_shared(local, b.interval, lb.r, lb.b_ok));
+    const unsigned long long ci = cq <= 0.0 ? 0ull : (cq >= 18446744073709551616.0 ? ~0ull : (unsigned long long)cq);
+    const unsigned long long i = ci == 0 ? 0 : ci - 1;
+    if (i >= (unsigned long long)b.npoly) return false;
+    const long long idx = (long long)i;
+    const double tau = div_shared(local - b.interval * (double)i, b.interval, lb.r, lb.b_ok);
+    if (idx != lb.idx) {
+        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (b.coeff_off + idx) * kDiv * 3);
+#pragma unroll
+        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; lb.c[2 * q] = v.x; lb.c[2 * q + 1] = v.y; }
+        lb.idx = idx;
+    }
+    V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + lb.c[k * 3 + 0];
+        bp.y = bp.y * tau + lb.c[k * 3 + 1];
+        bp.z = bp.z * tau + lb.c[k * 3 + 2];
+    }
+    const V3 d = sub(bp, pos);
+    const double n2 = dot(d, d);
+    double inv;
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
+    else inv = 1.0 / (n2 * sqrt(n2));
+    term = scale(d, b.mu * inv);
+    return true;
+}
+__global__ void k_debug_div(long long n, const double *__restrict__ a, const double *__restrict__ b,
+                            double *__restrict__ fast, double *__restrict__ ieee) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = div_shared(a[i], b[i], rcp_refined(b[i]), in_range_div(b[i]));
+    ieee[i] = a[i] / b[i];
+}
 __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
@@ -200,7 +250,7 @@ constexpr int kRedRow = kTile + 2;                    // LDS row of the wave var
 // order -- the same chain of f64 additions -- then the sum is broadcast. `red` = 3 x kRedRow doubles of LDS.
 template <bool WAVE>
 __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &sg, double t, const double (&y)[6],
-                                          double (&dy)[6], double *red) {
+                                          double (&dy)[6], double *red, LaneBody *lb = nullptr) {
     const V3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
     V3 acc = {0.0, 0.0, 0.0};
     if (WAVE) {
@@ -210,8 +260,11 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             V3 term = {0.0, 0.0, 0.0};
             bool located = true;
             if (b < a.n_bodies) {
-                const BodyEntry be = a.bodies[b];
-                located = body_term(a, be, t, pos, term);
+                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);
+                else {
+                    const BodyEntry be = a.bodies[b];
+                    located = body_term(a, be, t, pos, term);
+                }
             }
             if (__builtin_amdgcn_ballot_w64(!located)) return false;
             red[lane] = term.x;                       // lanes past the last body contribute +0.0 (exact to add)
@@ -539,6 +592,13 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
         put_k(S - 1, kl);
     }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+    LaneBody lb;
+    lb.be = a.bodies[lane < a.n_bodies ? lane : 0];
+    lb.r = rcp_refined(lb.be.interval);
+    lb.b_ok = in_range_div(lb.be.interval);
+    lb.idx = -1;
+#pragma unroll
+    for (int q = 0; q < kDiv * 3; ++q) lb.c[q] = 0.0;
 
     while (!(last_knot >= a.t_end)) {                 // has_reached: solution.end() >= time
         if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
@@ -592,7 +652,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
                             yi[3 + d] = yi[3 + d] + kj * hav;
                         }
                     }
-                    ok = craft_rhs<true>(a, sg, ti, yi, out, red);
+                    ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
                     const double dk[6] = {out[3], out[4], out[5], 0.0, 0.0, 0.0};
                     put_k(s, dk);
                     continue;
@@ -605,7 +665,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
 #pragma unroll
                     for (int d = 0; d < 6; ++d) yi[d] = yi[d] + K[j * 6 + d] * ha;
                 }
-                ok = craft_rhs<true>(a, sg, ti, yi, out, red);
+                ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
                 put_k(s, out);
             }
             if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
@@ -1588,6 +1648,26 @@ int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos, con
         EPH_HIP(hipMemcpy(inside, din.p, m, hipMemcpyDeviceToHost));
         return EPH_OK;
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+
+int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast, double *ieee) {
+    try {
+        if (n < 0 || (n > 0 && (!a || !b || !fast || !ieee))) return EPH_ERR_BAD_ARGUMENT;
+        int st = check_device();
+        if (st) return st;
+        if (n == 0) return EPH_OK;
+        DevBuf<double> da, db, df, di;
+        if ((st = da.alloc(n)) || (st = db.alloc(n)) || (st = df.alloc(n)) || (st = di.alloc(n))) return st;
+        EPH_HIP(hipMemcpy(da.p, a, sizeof(double) * n, hipMemcpyHostToDevice));
+        EPH_HIP(hipMemcpy(db.p, b, sizeof(double) * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_debug_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (long long)n, da.p, db.p,
+                           df.p, di.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error("k_debug_div", e); return EPH_ERR_HIP; }
+        EPH_HIP(hipMemcpy(fast, df.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+        EPH_HIP(hipMemcpy(ieee, di.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return EPH_OK;
+    } catch (...) { return EPH_ERR_HIP; }
 }
 
 int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out) {

@@ -37,4 +37,30 @@ __device__ __forceinline__ double rcp_inrange(double p) {
     return __builtin_fma(e, r, r);
 }
 
+// a / b, IEEE correctly rounded, with the reciprocal refinement shared between numerators: the compiler's f64
+// division is  r = rcp(b) + two Newton steps;  q = a*r;  e = fma(-b, q, a);  q = fma(e, r, q)  inside the scaling
+// wrappers. rcp_refined(b) is the first half, div_refined the second; bit-identical to a / b whenever div_scale /
+// div_fixup would have been no-ops: b in [2^-200, 2^200) and a either 0 or in that range too (quotient within
+// [2^-400, 2^400)). tests/test_gpu_craft.py::test_shared_reciprocal_division_is_ieee.
+__device__ __forceinline__ bool in_range_div(double x) {   // biased exponent in [823, 1223)
+    return (unsigned)(__double2hiint(x) - 0x33700000) < 0x19000000u;
+}
+__device__ __forceinline__ double rcp_refined(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double div_refined(double a, double b, double r) {
+    const double q = a * r;
+    const double e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, r, q);
+}
+// a / b with the shared reciprocal where it is exact (b_ok: b in range), the compiler's division otherwise
+__device__ __forceinline__ double div_shared(double a, double b, double r, bool b_ok) {
+    if (b_ok && (a == 0.0 || in_range_div(a))) return div_refined(a, b, r);
+    return a / b;
+}
+
 }  // namespace eph

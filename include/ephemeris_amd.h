@@ -266,6 +266,9 @@ int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos_xyz,
 
 /* Test hook: the step-size controller's correctly rounded pow(x[i], y) on the device */
 int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out);
+/* test hook: a[i] / b[i] through the shared-reciprocal division of k_craft_wave and through the compiler's IEEE
+ * division */
+int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast, double *ieee);
 /* Test hook: 1/(x*sqrt(x)) for n inputs computed by the kernel's in-range fast sequences (NaN where the range
  * guard would send the tile to the IEEE form) and by the compiler's IEEE sqrt/divide expansions. */
 int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee);

@@ -367,3 +367,30 @@ def test_thread_form_on_small_batches(gpu):
                        env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_shared_reciprocal_division_is_ieee(gpu):
+    """k_craft_wave divides by a body's spline interval through one refined reciprocal per lane (device_math.h:
+    rcp_refined / div_refined / div_shared). Quotients must equal IEEE division -- the compiler's on the device and the
+    host's -- for the intervals of the committed systems and random ones, numerators spanning the epochs and residues
+    that occur plus adversarial values (exact multiples, one ulp around them, zero, tiny and huge values that must
+    take the fallback)."""
+    rng = np.random.default_rng(7)
+    s = load_system("full_solar_system_2433282.5")
+    intervals = np.unique(np.concatenate([8.0 * s.dt * s.count.astype(np.float64), rng.uniform(1.0, 4.0e6, 64),
+                                          2.0 ** rng.integers(-20, 40, 16).astype(np.float64), [1e-70, 1e70]]))
+    a_parts, b_parts = [], []
+    for b in intervals:
+        m = rng.integers(0, 1 << 20, 20000).astype(np.float64)
+        exact = m * b
+        a = np.concatenate([rng.uniform(0.0, 1.0e10, 40000), rng.uniform(0.0, min(b, 1e300), 20000), exact,
+                            np.nextafter(exact, np.inf), np.nextafter(exact, 0.0),
+                            [0.0, b, 1.0e-7, 1.0e11, 5e-324, 1e-310, 1e-70, 1e70, 1e300]])
+        a_parts.append(a)
+        b_parts.append(np.full_like(a, b))
+    a, b = np.concatenate(a_parts), np.concatenate(b_parts)
+    fast, ieee = gpu.debug_div(a, b)
+    with np.errstate(over="ignore", under="ignore"):
+        want = a / b
+    assert np.array_equal(bits(ieee), bits(want))             # device IEEE division == host division
+    assert np.array_equal(bits(fast), bits(want)), int((bits(fast) != bits(want)).sum())
