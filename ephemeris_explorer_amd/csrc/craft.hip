@@ -28,6 +28,7 @@ struct BodyEntry {            // one massive body's UniformSpline on the device
     double start, interval, mu;
     long long npoly;
     long long coeff_off;      // index of polynomial 0 in the coefficient / ncoef arrays
+    double span;              // interval * (double)npoly, the product UniformSpline::span() forms on every lookup
 };
 struct SegmentDev {           // Segment<DVec3, ReferenceFrame>
     double start, end;
@@ -160,11 +161,36 @@ __device__ __forceinline__ bool spline_locate(const BodyEntry &b, double at, lon
     return true;
 }
 
+// UniformSpline::get_polynomial for the sweep kernels: the span product comes precomputed with the table entry and
+// the f64 <-> u64 conversions take the one-instruction 32-bit forms when every lane's segment count fits (always, in
+// practice); same values as spline_locate.
+__device__ __forceinline__ bool spline_locate_fast(const BodyEntry &b, double at, long long &idx, double &tau) {
+    const double local = at - b.start;
+    if (__builtin_signbit(local) || local > b.span) return false;
+    const double c = ceil(local / b.interval);
+    unsigned long long i;
+    double fi;
+    if (__builtin_amdgcn_ballot_w64(!(c < 2147483648.0)) == 0) {      // also false for NaN
+        const unsigned ci = c <= 0.0 ? 0u : (unsigned)c;
+        const unsigned i32 = ci == 0 ? 0u : ci - 1u;
+        i = i32;
+        fi = (double)i32;
+    } else {
+        const unsigned long long ci = c <= 0.0 ? 0ull : (c >= 18446744073709551616.0 ? ~0ull : (unsigned long long)c);
+        i = ci == 0 ? 0 : ci - 1;
+        fi = (double)i;
+    }
+    if (i >= (unsigned long long)b.npoly) return false;
+    idx = (long long)i;
+    tau = (local - b.interval * fi) / b.interval;
+    return true;
+}
+
 // One body's term of Bodies::acceleration (dynamics/spacecraft.rs:70-74,222-228): segment lookup, Horner, point mass.
 __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &be, double t, const V3 &pos, V3 &term) {
     long long idx;
     double tau;
-    if (!spline_locate(be, t, idx, tau)) return false;
+    if (!spline_locate_fast(be, t, idx, tau)) return false;
     // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so
     // the leading steps give 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no
     // ncoef load, no loop, and twelve 16-byte loads in flight at once
@@ -201,14 +227,23 @@ __device__ __forceinline__ bool body_term_cached(const CraftArgs &a, LaneBody &l
     // UniformSpline::get_polynomial, the two divisions by the interval through the shared reciprocal (same quotients)
     const BodyEntry &b = lb.be;
     const double local = t - b.start;
-    const double span = b.interval * (double)b.npoly;
-    if (__builtin_signbit(local) || local > span) return false;
+    if (__builtin_signbit(local) || local > b.span) return false;
     const double cq = ceil(div_shared(local, b.interval, lb.r, lb.b_ok));
-    const unsigned long long ci = cq <= 0.0 ? 0ull : (cq >= 18446744073709551616.0 ? ~0ull : (unsigned long long)cq);
-    const unsigned long long i = ci == 0 ? 0 : ci - 1;
+    unsigned long long i;
+    double fi;
+    if (__builtin_amdgcn_ballot_w64(!(cq < 2147483648.0)) == 0) {
+        const unsigned ci = cq <= 0.0 ? 0u : (unsigned)cq;
+        const unsigned i32 = ci == 0 ? 0u : ci - 1u;
+        i = i32;
+        fi = (double)i32;
+    } else {
+        const unsigned long long ci = cq <= 0.0 ? 0ull : (cq >= 18446744073709551616.0 ? ~0ull : (unsigned long long)cq);
+        i = ci == 0 ? 0 : ci - 1;
+        fi = (double)i;
+    }
     if (i >= (unsigned long long)b.npoly) return false;
     const long long idx = (long long)i;
-    const double tau = div_shared(local - b.interval * (double)i, b.interval, lb.r, lb.b_ok);
+    const double tau = div_shared(local - b.interval * fi, b.interval, lb.r, lb.b_ok);
     if (idx != lb.idx) {
         const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (b.coeff_off + idx) * kDiv * 3);
 #pragma unroll
@@ -301,7 +336,7 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
             BodyEntry be;
             be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
-            be.coeff_off = bc->coeff_off;
+            be.coeff_off = bc->coeff_off; be.span = bc->span;
             V3 term;
             if (!body_term(a, be, t, pos, term)) return false;
             acc = add(acc, term);
@@ -1261,7 +1296,8 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
         long long total = 0;
         for (int b = 0; b < nb; ++b) {
             const UniformSpline &u = s->s.splines[b];
-            BodyEntry be{u.start, u.interval, mu[b], (long long)u.polynomials.size(), total};
+            BodyEntry be{u.start, u.interval, mu[b], (long long)u.polynomials.size(), total,
+                         u.interval * (double)u.polynomials.size()};
             e->host_bodies.push_back(be);
             total += be.npoly;
         }
