@@ -276,7 +276,7 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-constexpr int kCraftWaveMax = 4096;                  // batches up to this size run one wave per spacecraft
+constexpr int kCraftWaveMax = 12288;                 // batches up to this size run one wave per spacecraft (measured crossover)
 constexpr int kRedRow = kTile + 2;                    // LDS row of the wave variant's contribution tile
 
 // FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.

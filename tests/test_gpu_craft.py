@@ -354,7 +354,7 @@ def test_config4_full_size_sweep(gpu):
 
 
 def test_thread_form_on_small_batches(gpu):
-    """Batches of up to 4096 spacecraft run one wave per craft (k_craft_wave, k_craft_events<true>), larger ones one
+    """Batches of up to 12288 spacecraft run one wave per craft (k_craft_wave, k_craft_events<true>), larger ones one
     thread per craft. The scenario tests above are small, so they exercise the wave form; this runs the same
     bit-parity scenarios again with the thread form forced (EPH_CRAFT_FORM is read once per process)."""
     import os
