@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
     "eph_nbody_enable_timing", "eph_nbody_sync", "eph_rccl_unique_id", "eph_nbody_shard", "eph_nbody_shard_info",
+    "eph_prop_shard",
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
@@ -121,6 +122,7 @@ def _lib():
     L.eph_rccl_unique_id.argtypes = [vp]
     L.eph_nbody_shard.argtypes = [vp, i32, i32, vp, EXCHANGE_FN, vp]
     L.eph_nbody_shard_info.argtypes = [vp, _i32p, _i32p, C.POINTER(C.c_uint64)]
+    L.eph_prop_shard.argtypes = [vp, i32, i32, vp, EXCHANGE_FN, vp]
     L.eph_nbody_kernel_time.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.eph_nbody_enable_timing.argtypes = [vp, i32]
     L.eph_nbody_sync.argtypes = [vp]
@@ -251,6 +253,26 @@ def debug_inv_r3(n2):
     return fast, ieee
 
 
+def _shard_call(fn, name, handle, rank, world, unique_id, exchange):
+    cb = None
+    if exchange is not None:
+        def _tramp(ctx, buf, nbytes, r, w, stream):
+            try:
+                return int(exchange(buf, nbytes, r, w, stream) or 0)
+            except Exception:                          # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = EXCHANGE_FN(_tramp)
+    uid = None
+    if unique_id is not None:
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+    _check(fn(handle, int(rank), int(world), uid, cb if cb else EXCHANGE_FN(0), None), name)
+    return cb                                          # the caller keeps the trampoline alive with the handle
+
+
 def rccl_unique_id():
     """ncclGetUniqueId through the library (rank 0 calls it and distributes the 128 bytes)."""
     out = (C.c_char * 128)()
@@ -323,24 +345,8 @@ class NBodyIntegration:
         """Partition the system by target body over `world` ranks (eph_nbody_shard). unique_id: the 128 bytes of
         rccl_unique_id() from rank 0 (RCCL transport), or exchange: callable(device_ptr, slice_bytes, rank, world,
         hip_stream) -> 0 performing the in-place all-gather (see parallel.host_staged_exchange)."""
-        cb = None
-        if exchange is not None:
-            def _tramp(ctx, buf, nbytes, r, w, stream):
-                try:
-                    return int(exchange(buf, nbytes, r, w, stream) or 0)
-                except Exception:                      # never unwind through the C frame
-                    import traceback
-                    traceback.print_exc()
-                    return 1
-            cb = EXCHANGE_FN(_tramp)
-        self._exchange_cb = cb                          # keep the trampoline alive as long as the handle
-        uid = None
-        if unique_id is not None:
-            if len(unique_id) != 128:
-                raise ValueError("unique_id must be 128 bytes")
-            uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
-        _check(self._L.eph_nbody_shard(self._h, int(rank), int(world), uid, cb if cb else EXCHANGE_FN(0), None),
-               "eph_nbody_shard")
+        self._exchange_cb = _shard_call(self._L.eph_nbody_shard, "eph_nbody_shard", self._h, rank, world, unique_id,
+                                        exchange)
         return self
 
     def shard_info(self):
@@ -422,6 +428,13 @@ class NBodyPropagator:
         """CelestialTrajectory::<D>::new_propagator (ephemeris_explorer/src/dynamics/celestial.rs:156-186)."""
         return cls(system.pos, system.vel, system.mu, system.epoch, system.dt, direction, system.count, system.degree,
                    method)
+
+    def shard(self, rank, world, unique_id=None, exchange=None):
+        """eph_prop_shard: partition the propagator's system by target body over the ranks (right after creation, on
+        every rank); arguments as NBodyIntegration.shard."""
+        self._exchange_cb = _shard_call(self._L.eph_prop_shard, "eph_prop_shard", self._h, rank, world, unique_id,
+                                        exchange)
+        return self
 
     def _step_status(self, st, where):
         st = _check(st, where)

@@ -224,6 +224,11 @@ int32_t eph_nbody_shard(eph_nbody *h, int32_t rank, int32_t world, const void *r
     return h->p->set_shard(std::move(x));
     EPH_GUARD_END
 }
+int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
+                       void *ctx) {
+    if (!p || !p->p) return EPH_ERR_BAD_ARGUMENT;
+    return eph_nbody_shard(&p->view, rank, world, rccl_unique_id, fn, ctx);
+}
 int32_t eph_nbody_shard_info(eph_nbody *h, int32_t *lo, int32_t *hi, uint64_t *gathers) {
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
     if (lo) *lo = h->p->shard_lo();

@@ -101,6 +101,13 @@ public:
     int shard_lo() const { return lo_; }
     int shard_hi() const { return hi_; }
     uint64_t gathers() const { return xch_ ? xch_->gathers() : 0; }
+    int shard_rank() const { return xch_ ? xch_->rank() : 0; }
+    int shard_world() const { return xch_ ? xch_->world() : 1; }
+    int shard_slice() const { return xch_ ? slice_ : n_; }          // bodies per rank (the last rank may own fewer)
+    // in-place all-gather of equal slices of a device buffer over the ranks, on this handle's stream
+    int gather_buffer(void *buf, size_t slice_bytes) {
+        return xch_ ? xch_->all_gather_inplace(buf, slice_bytes, stream_) : EPH_OK;
+    }
     // device view of the current positions, SoA [3][npad] (for on-device consumers: the interpolation-error scan)
     const double *positions_soa() { return Yslot(is_multistep_ ? cur_ : 0); }
     int npad() const { return npad_; }

@@ -180,9 +180,22 @@ int NBodyPropagator::run_batch(int64_t k) {
     }
     const int64_t W = (int64_t)first.size();
     if (W > 0) {
+        // Sharded system (eph_prop_shard): this rank samples and fits only the bodies it owns -- the windows of
+        // bodies [lo, hi) are the contiguous range [qlo, qhi) of the window list -- and the fitted polynomials
+        // are all-gathered (equal slices of world x wmax windows, 25 doubles each: 24 coefficients + ncoef) so
+        // that every rank holds the whole Vec<UniformSpline>. The window bookkeeping above is identical on
+        // every rank, so all ranks agree on the ranges.
+        const bool sharded = ig.sharded();
+        const int world = ig.shard_world(), rank = ig.shard_rank(), slice = ig.shard_slice();
+        std::vector<int64_t> qstart(n + 1, 0);
+        for (int b = 0; b < n; ++b) qstart[b + 1] = qstart[b] + nwin[b];
+        auto body_lo = [&](int r) { return std::min<int64_t>((int64_t)r * slice, n); };
+        const int64_t qlo = sharded ? qstart[body_lo(rank)] : 0, qhi = sharded ? qstart[body_lo(rank + 1)] : W;
+        int64_t wmax = 0;
+        for (int r = 0; r < world && sharded; ++r) wmax = std::max(wmax, qstart[body_lo(r + 1)] - qstart[body_lo(r)]);
         DevBuf<uint64_t> d_first;
         DevBuf<uint8_t> d_deg;
-        DevBuf<double> d_co;
+        DevBuf<double> d_co, d_all;
         DevBuf<int32_t> d_nc;
         DevBuf<uint32_t> d_src, d_cnt;
         DevBuf<uint64_t> d_region;
@@ -192,11 +205,47 @@ int NBodyPropagator::run_batch(int64_t k) {
             return st;
         EPH_HIP(hipMemcpyAsync(d_first.p, first.data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, s));
         EPH_HIP(hipMemcpyAsync(d_deg.p, deg.data(), sizeof(uint8_t) * W, hipMemcpyHostToDevice, s));
-        if ((st = launch_lsq_fit(s, W, d_first.p, d_deg.p, direction_ < 0, log_.p, d_co.p, d_nc.p))) return st;
+        if (qhi > qlo &&
+            (st = launch_lsq_fit(s, qhi - qlo, d_first.p + qlo, d_deg.p + qlo, direction_ < 0, log_.p,
+                                 d_co.p + qlo * kDiv * 3, d_nc.p + qlo)))
+            return st;
         std::vector<double> co((size_t)W * kDiv * 3);
         std::vector<int32_t> nc(W);
-        EPH_HIP(hipMemcpyAsync(co.data(), d_co.p, sizeof(double) * co.size(), hipMemcpyDeviceToHost, s));
-        EPH_HIP(hipMemcpyAsync(nc.data(), d_nc.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, s));
+        if (sharded) {
+            const size_t rec = (size_t)kDiv * 3 + 1;                  // doubles per window in the exchange buffer
+            const size_t slice_d = (size_t)std::max<int64_t>(wmax, 1) * rec;
+            if ((st = d_all.alloc(slice_d * world))) return st;
+            std::vector<double> mine(slice_d, 0.0), all(slice_d * world);
+            std::vector<double> own_co((size_t)(qhi - qlo) * kDiv * 3);
+            std::vector<int32_t> own_nc((size_t)(qhi - qlo));
+            if (qhi > qlo) {
+                EPH_HIP(hipMemcpyAsync(own_co.data(), d_co.p + qlo * kDiv * 3, sizeof(double) * own_co.size(),
+                                       hipMemcpyDeviceToHost, s));
+                EPH_HIP(hipMemcpyAsync(own_nc.data(), d_nc.p + qlo, sizeof(int32_t) * own_nc.size(),
+                                       hipMemcpyDeviceToHost, s));
+            }
+            EPH_HIP(hipStreamSynchronize(s));
+            for (int64_t q = 0; q < qhi - qlo; ++q) {
+                std::copy(own_co.begin() + q * kDiv * 3, own_co.begin() + (q + 1) * kDiv * 3, mine.begin() + q * rec);
+                mine[q * rec + kDiv * 3] = (double)own_nc[q];
+            }
+            EPH_HIP(hipMemcpyAsync(d_all.p + (size_t)rank * slice_d, mine.data(), sizeof(double) * slice_d,
+                                   hipMemcpyHostToDevice, s));
+            if ((st = ig.gather_buffer(d_all.p, sizeof(double) * slice_d))) return st;
+            EPH_HIP(hipMemcpyAsync(all.data(), d_all.p, sizeof(double) * all.size(), hipMemcpyDeviceToHost, s));
+            EPH_HIP(hipStreamSynchronize(s));
+            for (int r = 0; r < world; ++r) {
+                const int64_t a0 = qstart[body_lo(r)], a1 = qstart[body_lo(r + 1)];
+                for (int64_t q = a0; q < a1; ++q) {
+                    const double *src = all.data() + (size_t)r * slice_d + (size_t)(q - a0) * rec;
+                    std::copy(src, src + kDiv * 3, co.begin() + q * kDiv * 3);
+                    nc[q] = (int32_t)src[kDiv * 3];
+                }
+            }
+        } else {
+            EPH_HIP(hipMemcpyAsync(co.data(), d_co.p, sizeof(double) * co.size(), hipMemcpyDeviceToHost, s));
+            EPH_HIP(hipMemcpyAsync(nc.data(), d_nc.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, s));
+        }
         EPH_HIP(hipMemcpyAsync(d_src.p, carry_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
         EPH_HIP(hipMemcpyAsync(d_cnt.p, carry_cnt.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
         EPH_HIP(hipMemcpyAsync(d_region.p, log_off_.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice, s));

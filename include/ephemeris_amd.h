@@ -136,6 +136,12 @@ typedef struct eph_solution eph_solution; /* Vec<UniformSpline<DVec3>>, ephemeri
 int32_t eph_prop_create(int32_t n, const double *pos_xyz, const double *vel_xyz, const double *mu, double t0,
                         double dt, int32_t direction, const char *method, const uint32_t *count,
                         const uint32_t *degree, eph_prop **out);
+/* The same partition for a whole propagator (call right after eph_prop_create on every rank): each rank integrates,
+ * samples and fits the bodies it owns; after every batch the new polynomials are all-gathered, so eph_prop_time /
+ * has_reached / take_solution see the complete Vec<UniformSpline> on every rank, bit-identical to the single-device
+ * propagator. eph_prop_step* / step_to / propagate / clone become collective calls. */
+int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
+                       void *ctx);
 int32_t eph_prop_step(eph_prop *p);                  /* IncrementalPropagator::step  nbody.rs:200-207 */
 int32_t eph_prop_step_n(eph_prop *p, int64_t n);     /* n x step(), batched on the device */
 int32_t eph_prop_step_to(eph_prop *p, double t);     /* IncrementalPropagator::step_to  lib.rs:49-60 */

@@ -125,3 +125,49 @@ def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps):
         assert (lo, hi) == (r * npad // world, min(n, (r + 1) * npad // world))
         assert t == t0 and sc == sc0 and gathers > 0 and twin_ok
         assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(a, a0), (r, n, method)
+
+
+def _prop_worker(rank, world, port, n, out):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel, mu = plummer(n)
+    count = (np.arange(n) % 3 + 1).astype(np.uint32)       # ragged sampling periods: the ranks own unequal window counts
+    degree = (np.arange(n) % 3 + 5).astype(np.uint32)
+    p = ea.NBodyPropagator(pos, vel, mu, 0.0, H, ea.FORWARD, count, degree)
+    parallel.shard_nbody(p, dist, transport="host")
+    sol = p.propagate(100 * H)
+    rows = [(sol.info(b), sol.coeffs(b)) for b in (0, 1, n // 2 - 1, n // 2, n - 2, n - 1)]
+    out[rank] = (p.time(), rows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_propagator_builds_the_same_ephemeris(gpu):
+    """eph_prop_shard: two ranks on one GPU (host-staged exchange) each sample and fit the bodies they own, the
+    polynomials are all-gathered: every rank ends with the single-device Vec<UniformSpline>, bit for bit."""
+    import torch.multiprocessing as mp
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    n, world = 256, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_prop_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    pos, vel, mu = plummer(n)
+    count = (np.arange(n) % 3 + 1).astype(np.uint32)
+    degree = (np.arange(n) % 3 + 5).astype(np.uint32)
+    p = ea.NBodyPropagator(pos, vel, mu, 0.0, H, ea.FORWARD, count, degree)
+    sol = p.propagate(100 * H)
+    want = [(sol.info(b), sol.coeffs(b)) for b in (0, 1, n // 2 - 1, n // 2, n - 2, n - 1)]
+    for r in range(world):
+        t, rows = out[r]
+        assert t == p.time()
+        for (info, (co, nc)), (winfo, (wco, wnc)) in zip(rows, want):
+            assert info == winfo and info[2] > 0
+            assert np.array_equal(nc, wnc) and np.array_equal(co, wco)
