@@ -267,3 +267,32 @@ def test_full_size_two_kernels_agree(gpu):
     assert_same_bits(pa, pb, "positions: wave kernel vs workgroup kernel")
     assert_same_bits(va, vb, "velocities: wave kernel vs workgroup kernel")
     assert np.abs((mu[:, None] * va).sum(0)).max() < 1e-12
+
+
+def test_degenerate_sizes(gpu):
+    """Empty and tiny systems through every seam: no bodies at all (nothing to do, no error), one body (no pairs:
+    uniform motion through the same integrator arithmetic), two bodies."""
+    z3 = np.zeros((0, 3))
+    assert gpu.accel_eval(z3, np.zeros(0)).shape == (0, 3)
+    g = gpu.NBodyIntegration(z3, z3, np.zeros(0), 0.0, 60.0)
+    g.advance(30)
+    p, v, t, sc = g.state()
+    assert p.shape == (0, 3) and sc == 30 and t == 30 * 60.0
+    rng = np.random.default_rng(5)
+    for n in (1, 2):
+        pos, vel, mu = rng.normal(0, 1e5, (n, 3)), rng.normal(0, 1.0, (n, 3)), rng.uniform(1e3, 1e5, n)
+        g = gpu.NBodyIntegration(pos, vel, mu, 10.0, 60.0)
+        o = orc.NBody(pos, vel, mu, 10.0, 60.0)
+        g.advance(12 + 50)
+        assert o.advance(12 + 50) == 0
+        gp, gv, gt, gs = g.state()
+        op, ov, ot, os_ = o.state()
+        assert gt == ot and gs == os_ and np.array_equal(gp, op) and np.array_equal(gv, ov)
+        pr = gpu.NBodyPropagator(pos, vel, mu, 10.0, 60.0, gpu.FORWARD, np.full(n, 2, np.uint32), np.full(n, 5, np.uint32))
+        opr = orc.Propagator(pos, vel, mu, 10.0, 60.0, 1, np.full(n, 2, np.uint32), np.full(n, 5, np.uint32))
+        sol = pr.propagate(10.0 + 100 * 60.0)
+        assert opr.step_to(10.0 + 100 * 60.0) == 0
+        osol = opr.take_solution()
+        for b in range(n):
+            assert sol.info(b) == osol.info(b)
+            assert np.array_equal(sol.coeffs(b)[0], osol.coeffs(b)[0])
