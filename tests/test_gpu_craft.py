@@ -394,3 +394,39 @@ def test_shared_reciprocal_division_is_ieee(gpu):
         want = a / b
     assert np.array_equal(bits(ieee), bits(want))             # device IEEE division == host division
     assert np.array_equal(bits(fast), bits(want)), int((bits(fast) != bits(want)).sum())
+
+
+def test_more_than_64_bodies(gpu):
+    """An ephemeris of 96 bodies (the 32 of the full system + 64 light test bodies on displaced copies of the planets'
+    states): the wave form's lane-per-body evaluation then runs in two chunks with the ordered sum carried across
+    them. Knots bit-identical to the oracle; a 20 000-craft batch (thread form) agrees on a sample."""
+    s = load_system("full_solar_system_2433282.5")
+    rng = np.random.default_rng(96)
+    extra = 64
+    src = rng.integers(1, s.n, extra)
+    pos = np.vstack([s.pos, s.pos[src] + rng.normal(0.0, 5.0e6, (extra, 3))])
+    vel = np.vstack([s.vel, s.vel[src] + rng.normal(0.0, 0.5, (extra, 3))])
+    mu = np.concatenate([s.mu, rng.uniform(1e-3, 1.0, extra)])
+    count = np.concatenate([s.count, rng.integers(4, 40, extra).astype(np.uint32)])
+    degree = np.concatenate([s.degree, rng.integers(5, 8, extra).astype(np.uint32)])
+    end = s.epoch + 2.0 * 86400.0
+    g = gpu.NBodyPropagator(pos, vel, mu, s.epoch, s.dt, gpu.FORWARD, count, degree)
+    sol = g.propagate(end)
+    o = orc.Propagator(pos, vel, mu, s.epoch, s.dt, 1, count, degree)
+    assert o.step_to(end) == 0
+    osol = o.take_solution()
+    eph = gpu.Ephemeris(sol, mu)
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    t_end = ship.start + 0.5 * 86400.0
+    cpos = ship.pos + rng.normal(0.0, 100.0, (20000, 3))
+    cvel = ship.vel + rng.normal(0.0, 0.01, (20000, 3))
+    small = gpu.SpacecraftBatch(eph, ship.start, cpos[:3], cvel[:3], "Verner87", max_knots=512)     # wave form
+    small.propagate(t_end)
+    big = gpu.SpacecraftBatch(eph, ship.start, cpos, cvel, "Verner87", max_knots=512)               # thread form
+    big.propagate(t_end)
+    assert (small.status()["status"] == 0).all() and (big.status()["status"] == 0).all()
+    for i in range(3):
+        c = orc.Craft(osol, mu, ship.start, cpos[i], cvel[i], "Verner87")
+        assert c.step_to(t_end) == 0
+        assert compare_knots(small.knots(i), c.knots(), f"wave form, craft {i}, 96 bodies")
+        assert compare_knots(big.knots(i), c.knots(), f"thread form, craft {i}, 96 bodies")
