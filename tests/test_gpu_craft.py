@@ -430,3 +430,32 @@ def test_more_than_64_bodies(gpu):
         assert c.step_to(t_end) == 0
         assert compare_knots(small.knots(i), c.knots(), f"wave form, craft {i}, 96 bodies")
         assert compare_knots(big.knots(i), c.knots(), f"thread form, craft {i}, 96 bodies")
+
+
+@pytest.mark.parametrize("method", ["Verner87", "Fine45", "DormandPrince54"])
+def test_committed_spacecraft_knots(gpu, simple_system, method):
+    """The device against tests/golden/craft_golden.json directly (no oracle in the loop): the Mars transfer to
+    1951-01-01 with the app's event search."""
+    import json
+    from conftest import GOLDEN
+    from ephemeris_explorer_amd.systems import soi_radii
+    s, sol, eph, osol = simple_system
+    gm = json.loads((GOLDEN / "craft_golden.json").read_text())["methods"][method]
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], method, gpu.AdaptiveParams.default(ship.tolerance),
+                                [ship_burns(ship, s.names)], max_knots=40000).enable_events(soi_radii(s), 16, 8192)
+    batch.propagate(parse_epoch("1951-01-01 00:00:00"))
+    st = batch.status()
+    assert st["status"][0] == 0
+    kt, kp, kv = batch.knots(0)
+    assert (len(kt), int(st["steps"][0]), int(st["attempts"][0]), float(batch.state()["next_h"][0]).hex()) == \
+        (gm["knots"], gm["steps"], gm["attempts"], gm["next_h"])
+    for smp in gm["sample"]:
+        i = smp["i"]
+        assert float(kt[i]).hex() == smp["t"]
+        assert [float(x).hex() for x in kp[i]] == smp["pos"] and [float(x).hex() for x in kv[i]] == smp["vel"]
+    (tt, tb), (at, ad, ab, ak) = batch.events(0)
+    assert [[float(t).hex(), int(b)] for t, b in zip(tt, tb)] == gm["transitions"]
+    assert len(at) == gm["apsides"]
+    assert [[float(t).hex(), float(d).hex(), int(b), int(k)] for t, d, b, k in list(zip(at, ad, ab, ak))[:8]] == \
+        gm["first_apsides"]

@@ -146,3 +146,38 @@ def test_spacecraft_solout_events_c_vs_python(scenario):
     assert [int(b) for b in tb] == [earth, sun] and tt[0] == ship.start
     assert 2.0 * 86400.0 < tt[1] - ship.start < 3.0 * 86400.0
     assert len(at) >= 2 and all(int(b) == earth for b in ab[:2]) and ad[1] < 7000.0 and int(ak[1]) == 0
+
+
+def _golden_methods():
+    import json
+    from conftest import GOLDEN
+    return json.loads((GOLDEN / "craft_golden.json").read_text())
+
+
+@pytest.mark.parametrize("method", ["Verner87", "Fine45", "DormandPrince54"])
+def test_oracle_reproduces_the_committed_spacecraft_knots(scenario, method):
+    """tests/golden/craft_golden.json (make_golden.py): the Mars transfer to 1951-01-01, knot count, counters, sampled
+    knots, SOI transitions and first apsides -- pins the massless path (controller pow included) across changes."""
+    from ephemeris_explorer_amd.systems import soi_radii
+    s, eph, ship, burns = scenario
+    gold = _golden_methods()
+    soi = soi_radii(s)
+    assert [float(x).hex() for x in soi] == gold["soi_radius"]
+    gm = gold["methods"][method]
+    c = orc.Craft(eph, s.mu, ship.start, ship.pos, ship.vel, method, tol_pos=ship.tolerance, tol_vel=ship.tolerance,
+                  burns=burns, soi_radius=soi)
+    assert c.step_to(parse_epoch("1951-01-01 00:00:00")) == 0
+    kt, kp, kv = c.knots()
+    st = c.state()
+    assert (len(kt), st["steps"], st["attempts"], float(st["next_h"]).hex()) == \
+        (gm["knots"], gm["steps"], gm["attempts"], gm["next_h"])
+    for smp in gm["sample"]:
+        i = smp["i"]
+        assert float(kt[i]).hex() == smp["t"]
+        assert [float(x).hex() for x in kp[i]] == smp["pos"] and [float(x).hex() for x in kv[i]] == smp["vel"]
+    tt, tb = c.transitions()
+    assert [[float(t).hex(), int(b)] for t, b in zip(tt, tb)] == gm["transitions"]
+    at, ad, ab, ak = c.apsides()
+    assert len(at) == gm["apsides"]
+    assert [[float(t).hex(), float(d).hex(), int(b), int(k)] for t, d, b, k in list(zip(at, ad, ab, ak))[:8]] == \
+        gm["first_apsides"]
