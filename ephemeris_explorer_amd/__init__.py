@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
-    "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
+    "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow", "eph_debug_div",
 ]
 
@@ -161,6 +161,7 @@ def _lib():
     L.eph_craft_batch_state.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
+    L.eph_craft_batch_knot_slabs.argtypes = [vp, i32, i32, _dp, _dp]
     L.eph_craft_batch_reset_knots.argtypes = [vp]
     L.eph_craft_batch_reset_events.argtypes = [vp]
     L.eph_timeline_divergence_time.argtypes = [i64, _dp, _dp, _dp, _i32p, i64, _dp, _dp, _dp, _i32p, f64, _dp]
@@ -573,6 +574,17 @@ class SpacecraftBatch:
         t, p, v = np.zeros(nk), np.zeros((nk, 3)), np.zeros((nk, 3))
         _check(self._L.eph_craft_batch_knots(self._h, int(craft), _p(t), _p(p), _p(v)), "eph_craft_batch_knots")
         return t, p, v
+
+    def knot_slabs(self, first_knot=0, n_knots=None):
+        """All craft at once: (t[k][craft], y[k][6][craft]) for knots first_knot .. first_knot + n_knots - 1; entries
+        at or beyond a craft's nknots are unspecified (use status()["nknots"])."""
+        if n_knots is None:
+            n_knots = int(self.status()["nknots"].max()) - first_knot
+        t = np.zeros((n_knots, self.n))
+        y = np.zeros((n_knots, 6, self.n))
+        _check(self._L.eph_craft_batch_knot_slabs(self._h, int(first_knot), int(n_knots), _p(t), _p(y)),
+               "eph_craft_batch_knot_slabs")
+        return t, y
 
     def reset_knots(self):
         """Keep only the newest knot of every craft (as knot 0) and clear KNOTS_FULL: the drain point of a long run."""

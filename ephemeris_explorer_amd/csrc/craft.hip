@@ -1636,6 +1636,20 @@ int32_t eph_craft_batch_reset_knots(eph_craft_batch *b) {
     return EPH_OK;
 }
 
+int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32_t n_knots, double *knot_t,
+                                   double *knot_y) {
+    if (!b || first_knot < 0 || n_knots < 0 || first_knot + n_knots > b->max_knots) return EPH_ERR_BAD_ARGUMENT;
+    if (b->n == 0 || n_knots == 0) return EPH_OK;
+    EPH_HIP(hipSetDevice(b->device));
+    const size_t n = (size_t)b->n;
+    if (knot_t)
+        EPH_HIP(hipMemcpy(knot_t, b->knot_t.p + (size_t)first_knot * n, sizeof(double) * n * n_knots, hipMemcpyDeviceToHost));
+    if (knot_y)
+        EPH_HIP(hipMemcpy(knot_y, b->knot_y.p + (size_t)first_knot * 6 * n, sizeof(double) * 6 * n * n_knots,
+                          hipMemcpyDeviceToHost));
+    return EPH_OK;
+}
+
 int32_t eph_craft_batch_reset_events(eph_craft_batch *b) {
     if (!b || !b->events) return EPH_ERR_BAD_ARGUMENT;
     if (b->n == 0) return EPH_OK;

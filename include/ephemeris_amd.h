@@ -246,6 +246,11 @@ int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions,
 /* one craft's sorted lists (arrays sized by eph_craft_batch_event_counts; any may be NULL) */
 int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_time, int32_t *tr_body, double *ap_time,
                                double *ap_distance, int32_t *ap_body, int32_t *ap_kind);
+/* Bulk read of the knot slabs for sweeps (one copy instead of one strided gather per craft): knots first_knot ..
+ * first_knot + n_knots - 1 of EVERY craft in the device layout, knot_t[k][craft] and knot_y[k][d][craft] (d = x, y, z,
+ * vx, vy, vz); entries at or beyond a craft's nknots are unspecified. Either pointer may be NULL. */
+int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32_t n_knots, double *knot_t,
+                                   double *knot_y);
 /* Flight-plan restart (ephemeris_explorer/src/flight_plan.rs:263-303): Timeline::divergence_time_before
  * (ephemeris/src/propagators/spacecraft.rs:179-213) of the NEW burn list against the OLD one -- the start of the last
  * segment, earlier than `before`, up to which both timelines agree; the caller restarts a craft from the knot at

@@ -347,6 +347,12 @@ def test_config4_full_size_sweep(gpu):
             c = orc.Craft(osol, s.mu, ship.start, pos[i], vel[i], "Verner87")
             assert c.step_to(t_end) == 0
             assert compare_knots(a, c.knots(), f"craft {i} vs oracle")
+    slab_t, slab_y = big.knot_slabs()                       # the bulk read agrees with the per-craft gather
+    for i in sample[:6]:
+        kt, kp, kv = big.knots(int(i))
+        nk = len(kt)
+        assert np.array_equal(slab_t[:nk, i], kt) and np.array_equal(slab_y[:nk, :3, i], kp)
+        assert np.array_equal(slab_y[:nk, 3:, i], kv)
     again = gpu.SpacecraftBatch(eph, ship.start, pos, vel, "Verner87", max_knots=96)
     again.propagate(t_end)
     f2 = again.state()
