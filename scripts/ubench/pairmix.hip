@@ -76,6 +76,10 @@ __global__ void __launch_bounds__(64) k(int iters, const double *in, double *out
         }
 #pragma unroll
         for (int q2 = 0; q2 < 3 * NB; ++q2) acc += c[q2];     // (stands in for the LDS writes; 3 adds per body)
+        if (MODE == 2) {                                       // idle about as long as the arithmetic took
+#pragma unroll
+            for (int z = 0; z < 12; ++z) __builtin_amdgcn_s_sleep(1);   // 12 x 64 cycles
+        }
     }
     const long long c1 = __builtin_readcyclecounter();
     out[blockIdx.x * 64 + threadIdx.x] = acc;
@@ -111,5 +115,9 @@ int main() {
     run<5, 0>("compiler order, 2 waves/SIMD", 2048, din, dout, dcyc);
     run<5, 1>("stage-major, 2 waves/SIMD", 2048, din, dout, dcyc);
     run<5, 0>("compiler order, 1/4 chip", 256, din, dout, dcyc);
+    run<5, 2>("50% duty, 1 wave/SIMD", 1024, din, dout, dcyc);
+    run<5, 2>("50% duty, 2 waves/SIMD", 2048, din, dout, dcyc);
+    run<5, 2>("50% duty, 3 waves/SIMD", 3072, din, dout, dcyc);
+    run<5, 2>("50% duty, 4 waves/SIMD", 4096, din, dout, dcyc);
     return 0;
 }
