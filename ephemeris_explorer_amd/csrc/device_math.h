@@ -15,6 +15,10 @@ __device__ __forceinline__ bool in_range(double n2) {
     // biased exponent in [723, 1323)  <=>  2^-300 <= n2 < 2^300  (n2 >= 0; NaN/inf/0/denormals are out)
     return (unsigned)(__double2hiint(n2) - 0x2D300000) < 0x25800000u;
 }
+// the same test for several operands at once: in range iff max over the operands of range_key() < kRangeSpan
+// (one integer add and one max per operand instead of a compare and boolean plumbing)
+constexpr unsigned kRangeSpan = 0x25800000u;
+__device__ __forceinline__ unsigned range_key(double n2) { return (unsigned)(__double2hiint(n2) - 0x2D300000); }
 __device__ __forceinline__ double sqrt_inrange(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;

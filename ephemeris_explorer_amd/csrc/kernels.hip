@@ -341,10 +341,10 @@ __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double i
             constexpr int PH = decltype(ph)::value;
             const double *row_cur = row + PH * kBuf;
             double *tile_nxt = C + (PH ^ 1) * kBuf;
-            bool bad = false;
+            unsigned worst = 0u;
 #pragma unroll
-            for (int b = 0; b < BPW; ++b) bad |= !in_range(w.pre[PH][b].n2);
-            if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+            for (int b = 0; b < BPW; ++b) worst = max(worst, range_key(w.pre[PH][b].n2));
+            if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
                 tile_step_fast<BPW, PH>(w, xi, yi, zi, row_cur, tile_nxt, lane);
             } else {                                        // an operand near the end of the exponent range
 #pragma unroll
@@ -520,14 +520,14 @@ __device__ __forceinline__ void wg_pair_tile(const double (&xi)[NB], const doubl
     // (forcing a stage-major interleave of the NB interactions with scheduling anchors was measured: no gain
     // over the compiler's own schedule here, 1380 vs 1400 cycles per 5-body tile)
     PairPre pre[NB];
-    bool bad = ieee;
+    unsigned worst = ieee ? kRangeSpan : 0u;           // max of the range keys: one add + one max per body
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         pre[b] = pair_pre(xi[b], yi[b], zi[b], pj);
-        bad |= !in_range(pre[b].n2);
+        worst = max(worst, range_key(pre[b].n2));
     }
     double c[3 * NB];
-    if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+    if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) pair_finish<true>(pre[b], pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
     } else {   // the tile holding the workgroup's own bodies (n2 = 0 on the self lane) or an out-of-range operand
