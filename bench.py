@@ -105,13 +105,18 @@ def craft_main(args):
     from ephemeris_explorer_amd.systems import load_ship, load_system
 
     rank, local_rank, world = env_rank()
+    local_rank %= max(ea.device_count(), 1)            # (lets the N > 1 flow be exercised on a one-GPU box)
     torch.cuda.set_device(local_rank)
     ea.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("EPH_BENCH_BACKEND", "nccl")   # "gloo" only to test this flow with ranks sharing a GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     sysdir = ROOT / "tests/golden/systems/full_solar_system_2433282.5"
     s = load_system(sysdir)
     ship = load_ship(sysdir / "ships" / "Mars Transfer Ship.json")
@@ -201,13 +206,18 @@ def main():
 
     if not torch.cuda.is_available() or ea.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    local_rank %= max(ea.device_count(), 1)            # (lets the N > 1 flow be exercised on a one-GPU box)
     torch.cuda.set_device(local_rank)
     ea.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("EPH_BENCH_BACKEND", "nccl")   # "gloo" only to test this flow with ranks sharing a GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n = args.bodies
     # rank r integrates its own replica (seed + r): independent systems, no exchange -- or, sharded, every rank
