@@ -151,10 +151,23 @@ uint64_t orc_pair_counter(void) { return g_pair_counter; }
  * (<= 0.7): dir = p_other - p_self ; n2 = dir.length_squared() (+ softening^2 = 0) ;
  * inv = 1 / (n2 * sqrt(n2)) ; (dir * (mu_other*inv), -dir * (mu_self*inv)).
  * glam DVec3::length_squared = x*x + y*y + z*z evaluated left to right (glam 0.30.10). */
+/* Sensitivity switch (tests only): other orders a point-mass routine could plausibly use for 1/r^3. 0 = the pinned
+ * restatement; 1 = 1/(r*r*r), r = sqrt(n2); 2 = s*s*s, s = 1/sqrt(n2); 3 = (1/n2) * (1/sqrt(n2)).
+ * tests/test_oracle.py::test_pair_formula_variants_stay_within_tolerance bounds what the unpinned choice can cost. */
+static int g_pair_variant = 0;
+void orc_set_pair_variant(int v) { g_pair_variant = v; }
+static inline double inv_r3(double n2) {
+    switch (g_pair_variant) {
+        case 1: { const double r = sqrt(n2); return 1.0 / (r * r * r); }
+        case 2: { const double s = 1.0 / sqrt(n2); return s * s * s; }
+        case 3: return (1.0 / n2) * (1.0 / sqrt(n2));
+        default: return 1.0 / (n2 * sqrt(n2));
+    }
+}
 static inline void acceleration_paired(v3 pi, double mui, v3 pj, double muj, v3 *ai, v3 *aj) {
     double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
     double n2 = dx * dx + dy * dy + dz * dz;
-    double inv = 1.0 / (n2 * sqrt(n2));
+    double inv = inv_r3(n2);
     double si = muj * inv, sj = mui * inv;
     ai->x = dx * si; ai->y = dy * si; ai->z = dz * si;
     aj->x = -dx * sj; aj->y = -dy * sj; aj->z = -dz * sj;

@@ -52,6 +52,8 @@ int orc_erk_coeffs(const char *name, int *stages, int *order, int *order_embedde
 /* > 1: gravity evaluated by that many OpenMP threads, partitioned by target body (same bits; all N^2 directed
  * interactions). 0 / 1: the reference's serial pair loop. Process-wide. */
 void orc_set_gravity_threads(int threads);
+/* tests only: 0 = the pinned pair formula, 1..3 = other plausible evaluation orders of 1/r^3 (sensitivity study) */
+void orc_set_pair_variant(int variant);
 void orc_newtonian_gravity_eval(int n, const double *y, const double *mu, double *ddy);
 /* number of (paired) interactions evaluated since process start -- used by bench.py for ns/pair */
 uint64_t orc_pair_counter(void);

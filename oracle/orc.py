@@ -332,6 +332,11 @@ def poly_eval_and_deriv(coeffs, ncoef, tau):
     return v, d
 
 
+def set_pair_variant(variant, native=False):
+    """tests only: evaluation order of 1/r^3 in the pair interaction (0 = pinned restatement, 1..3 = alternatives)."""
+    lib(native).orc_set_pair_variant(int(variant))
+
+
 def set_gravity_threads(threads, native=False):
     """> 1: OpenMP target-partitioned gravity (same bits). Applies to the library variant it is called on."""
     lib(native).orc_set_gravity_threads(int(threads))
