@@ -857,12 +857,14 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
     asm volatile("" : "+v"(hh), "+v"(hc), "+v"(h));
     double v = owner ? a.V[off] : 0.0;
     // solout sampling schedule of this thread's body, read once (maybe_sample would fetch it every step)
-    uint32_t samp_m = 0, samp_phase = 0;
-    uint64_t samp_base = 0;
+    // (a countdown instead of `(phase + s) % period` every step: samples fall on the steps where phase + s is a
+    // multiple of the period, the q-th of them into slot offset + q)
+    uint32_t samp_m = 0, samp_left = 0;
+    uint64_t samp_slot = 0;
     if (owner && a.samp.period) {
         samp_m = a.samp.period[my_i];
-        samp_phase = a.samp.phase[my_i];
-        samp_base = a.samp.offset[my_i];
+        samp_left = samp_m ? samp_m - a.samp.phase[my_i] % samp_m : 0;
+        samp_slot = a.samp.offset[my_i];
     }
     // this thread's unordered pairs (i < j), row-major over the strict upper triangle, 2 per thread at most for
     // n <= 40 (780 pairs over 512 threads): decode once
@@ -944,9 +946,10 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
             const double ynext = lm_predict<L>(y2, a2, wa, wb, hh);
             if (s < nsteps) reinterpret_cast<double *>(&sP[my_i])[cc] = ynext;
             v = lm_cowell<L>(anew, al, ynew, yl[0], cw, h, hc);
-            if (samp_m) {                                  // SplineInterpolators::solout_with  nbody.rs:389-397
-                const uint32_t t = samp_phase + (uint32_t)s;
-                if (t % samp_m == 0) a.samp.log[(samp_base + (uint64_t)(t / samp_m - 1)) * 3 + cc] = ynew;
+            if (samp_m && --samp_left == 0) {              // SplineInterpolators::solout_with  nbody.rs:389-397
+                a.samp.log[samp_slot * 3 + cc] = ynew;
+                samp_slot += 1;
+                samp_left = samp_m;
             }
             yv[Rn] = ynew;
             av[Rn] = anew;
