@@ -208,8 +208,8 @@ __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &b
     const V3 d = sub(bp, pos);                        // acceleration_at::<false>: dir = body - at
     const double n2 = dot(d, d);
     double inv;                                       // 1 / (n2 * sqrt(n2)), IEEE sqrt and divide (device_math.h)
-    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
-    else inv = 1.0 / (n2 * sqrt(n2));
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = inv_r3_inrange(n2);
+    else inv = inv_r3_ieee(n2);
     term = scale(d, be.mu * inv);
     return true;
 }
@@ -260,8 +260,8 @@ __device__ __forceinline__ bool body_term_cached(const CraftArgs &a, LaneBody &l
     const V3 d = sub(bp, pos);
     const double n2 = dot(d, d);
     double inv;
-    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
-    else inv = 1.0 / (n2 * sqrt(n2));
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = inv_r3_inrange(n2);
+    else inv = inv_r3_ieee(n2);
     term = scale(d, b.mu * inv);
     return true;
 }

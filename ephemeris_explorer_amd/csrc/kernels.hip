@@ -43,8 +43,8 @@ __device__ __forceinline__ PairPre pair_pre(double xi, double yi, double zi, con
 template <bool FAST>
 __device__ __forceinline__ void pair_finish(const PairPre &p, double mu, double &cx, double &cy, double &cz) {
     double inv;
-    if (FAST) inv = rcp_inrange(p.n2 * sqrt_inrange(p.n2));
-    else inv = 1.0 / (p.n2 * sqrt(p.n2));   // IEEE correctly rounded f64 sqrt and divide
+    if (FAST) inv = inv_r3_inrange(p.n2);
+    else inv = inv_r3_ieee(p.n2);   // IEEE correctly rounded f64 sqrt and divide
     const double s = mu * inv;
     cx = p.dx * s;
     cy = p.dy * s;
@@ -55,8 +55,8 @@ __global__ void k_debug_inv_r3(long long n, const double *__restrict__ n2, doubl
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double x = n2[i];
-    fast[i] = in_range(x) ? rcp_inrange(x * sqrt_inrange(x)) : __builtin_nan("");
-    ieee[i] = 1.0 / (x * sqrt(x));
+    fast[i] = in_range(x) ? inv_r3_inrange(x) : __builtin_nan("");
+    ieee[i] = inv_r3_ieee(x);
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -886,8 +886,8 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
         const double n2 = dx * dx + dy * dy + dz * dz;
         // IEEE sqrt and divide; the wrapper-free sequences when every lane's operand is in range (device_math.h)
         double inv;
-        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = rcp_inrange(n2 * sqrt_inrange(n2));
-        else inv = 1.0 / (n2 * sqrt(n2));
+        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = inv_r3_inrange(n2);
+        else inv = inv_r3_ieee(n2);
         const double si = bj.mu * inv, sj = bi.mu * inv;
         U[i * 3 + 0][j] = dx * si;
         U[i * 3 + 1][j] = dy * si;
