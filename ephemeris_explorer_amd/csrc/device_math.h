@@ -44,8 +44,8 @@ __device__ __forceinline__ double rcp_inrange(double p) {
 // THE point-mass kernel of the path, 1 / r^3 from n2 = |d|^2, in the one place it is defined for every kernel
 // (force kernels, k_lm_small, the spacecraft sweeps). It restates `particular`'s acceleration_paired /
 // acceleration_at (source absent): inv = 1 / (n2 * sqrt(n2)), IEEE sqrt, multiply, divide. If the
-// crate's order turns out to differ, change these two functions and acceleration_paired in oracle/eph_oracle.c
-// (inv_r3 there) together.
+// crate's order turns out to differ, change these two functions and the same-named function of the CPU restatement
+// the tests check against together.
 __device__ __forceinline__ double inv_r3_inrange(double n2) { return rcp_inrange(n2 * sqrt_inrange(n2)); }
 __device__ __forceinline__ double inv_r3_ieee(double n2) { return 1.0 / (n2 * sqrt(n2)); }
 
