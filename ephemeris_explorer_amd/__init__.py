@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
-    "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
+    "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow", "eph_debug_div",
 ]
 
@@ -161,6 +161,7 @@ def _lib():
     L.eph_craft_batch_state.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
+    L.eph_craft_batch_clone.argtypes = [vp, C.POINTER(vp)]
     L.eph_craft_batch_knot_slabs.argtypes = [vp, i32, i32, _dp, _dp]
     L.eph_craft_batch_reset_knots.argtypes = [vp]
     L.eph_craft_batch_reset_events.argtypes = [vp]
@@ -551,6 +552,14 @@ class SpacecraftBatch:
                                             int(max_knots), C.byref(h_))
         _check(st, "eph_craft_batch_create")
         self._h = h_
+
+    def clone(self):
+        """SpacecraftPropagator: Clone -- a deep copy (state, knots, events) that can be resumed independently."""
+        h_ = C.c_void_p()
+        _check(self._L.eph_craft_batch_clone(self._h, C.byref(h_)), "eph_craft_batch_clone")
+        c = object.__new__(SpacecraftBatch)
+        c._L, c.ephemeris, c.n, c.params, c._h = self._L, self.ephemeris, self.n, self.params, h_
+        return c
 
     def propagate(self, t_end):
         """step_to(t_end) for every craft; per-craft outcomes in status()"""

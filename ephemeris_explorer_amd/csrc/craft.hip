@@ -1282,6 +1282,16 @@ static void timeline_new(long long nburns, const double *burn_start, const doubl
     if (cursor < EMAX) segs.push_back(SegmentDev{cursor, EMAX, 0, 0, 0, 0, -1});
 }
 
+template <typename T>
+static int clone_buf(const DevBuf<T> &src, DevBuf<T> &dst, hipStream_t s) {
+    if (!src.p) return EPH_OK;
+    int st = dst.alloc(src.count);
+    if (st) return st;
+    hipError_t e = hipMemcpyAsync(dst.p, src.p, sizeof(T) * src.count, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { set_last_error("hipMemcpyAsync (clone)", e); return EPH_ERR_HIP; }
+    return EPH_OK;
+}
+
 extern "C" {
 
 int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out) {
@@ -1634,6 +1644,42 @@ int32_t eph_craft_batch_reset_knots(eph_craft_batch *b) {
     if (e != hipSuccess) { set_last_error("k_craft_reset_knots", e); return EPH_ERR_HIP; }
     EPH_HIP(hipStreamSynchronize(b->stream));
     return EPH_OK;
+}
+
+// SpacecraftPropagator: Clone (the UI snapshots a propagator and later resumes from the snapshot,
+// ephemeris_explorer/src/prediction.rs:224-229,378): a deep copy of every per-craft buffer, knots and events included
+int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
+    try {
+        if (!b || !out) return EPH_ERR_BAD_ARGUMENT;
+        *out = nullptr;
+        EPH_HIP(hipSetDevice(b->device));
+        EPH_HIP(hipStreamSynchronize(b->stream));
+        std::unique_ptr<eph_craft_batch> c(new eph_craft_batch());
+        c->eph = b->eph; c->device = b->device; c->n = b->n; c->max_knots = b->max_knots; c->rk = b->rk;
+        c->params = b->params; c->events = b->events; c->max_tr = b->max_tr; c->max_ap = b->max_ap;
+        EPH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        EPH_HIP(hipEventCreate(&c->ev0));
+        EPH_HIP(hipEventCreate(&c->ev1));
+        hipStream_t s = c->stream;
+        int st;
+        if ((st = clone_buf(b->time, c->time, s)) || (st = clone_buf(b->y, c->y, s)) || (st = clone_buf(b->next_h, c->next_h, s)) ||
+            (st = clone_buf(b->klast, c->klast, s)) || (st = clone_buf(b->last_knot, c->last_knot, s)) ||
+            (st = clone_buf(b->knot_t, c->knot_t, s)) || (st = clone_buf(b->knot_y, c->knot_y, s)) ||
+            (st = clone_buf(b->n_attempts, c->n_attempts, s)) || (st = clone_buf(b->rk_i, c->rk_i, s)) ||
+            (st = clone_buf(b->steps, c->steps, s)) || (st = clone_buf(b->cur_seg, c->cur_seg, s)) ||
+            (st = clone_buf(b->status, c->status, s)) || (st = clone_buf(b->nknots, c->nknots, s)) ||
+            (st = clone_buf(b->seg_off, c->seg_off, s)) || (st = clone_buf(b->segs, c->segs, s)) ||
+            (st = clone_buf(b->rk_dev, c->rk_dev, s)) || (st = clone_buf(b->soi, c->soi, s)) ||
+            (st = clone_buf(b->tr_time, c->tr_time, s)) || (st = clone_buf(b->ap_time, c->ap_time, s)) ||
+            (st = clone_buf(b->ap_dist, c->ap_dist, s)) || (st = clone_buf(b->ev_seg, c->ev_seg, s)) ||
+            (st = clone_buf(b->ntr, c->ntr, s)) || (st = clone_buf(b->nap, c->nap, s)) ||
+            (st = clone_buf(b->ev_status, c->ev_status, s)) || (st = clone_buf(b->tr_body, c->tr_body, s)) ||
+            (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)))
+            return st;
+        EPH_HIP(hipStreamSynchronize(s));
+        *out = c.release();
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 
 int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32_t n_knots, double *knot_t,

@@ -246,6 +246,10 @@ int32_t eph_craft_batch_event_counts(eph_craft_batch *b, int32_t *n_transitions,
 /* one craft's sorted lists (arrays sized by eph_craft_batch_event_counts; any may be NULL) */
 int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_time, int32_t *tr_body, double *ap_time,
                                double *ap_distance, int32_t *ap_body, int32_t *ap_kind);
+/* SpacecraftPropagator: Clone -- the UI snapshots a propagator and later resumes from the snapshot
+ * (ephemeris_explorer/src/prediction.rs:224-229,378). A deep copy: state, knots and events; the clone refers to the
+ * same eph_ephemeris (which must outlive both). */
+int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out);
 /* Bulk read of the knot slabs for sweeps (one copy instead of one strided gather per craft): knots first_knot ..
  * first_knot + n_knots - 1 of EVERY craft in the device layout, knot_t[k][craft] and knot_y[k][d][craft] (d = x, y, z,
  * vx, vy, vz); entries at or beyond a craft's nknots are unspecified. Either pointer may be NULL. */

@@ -206,11 +206,25 @@ def test_spacecraft_solout_events(gpu, simple_system):
     oat, oad, oab, oak = c.apsides()
     names = [s.names[b] for b in otb]
     assert names == ["Earth", "Sun", "Mars"] and len(oat) > 1000     # parking orbit, cruise, Mars orbit
-    for legs in ([end], [ship.start + 40 * 86400.0, parse_epoch("1950-07-27 00:00:00"), end]):
+    snap = None
+    for legs in ([end], [ship.start + 40 * 86400.0, parse_epoch("1950-07-27 00:00:00"), end], "resume a clone"):
+        if legs == "resume a clone":                      # Clone + resume (prediction.rs:224-229,378)
+            batch = snap
+            legs = [parse_epoch("1950-07-27 00:00:00"), end]
+            for leg in legs:
+                batch.propagate(leg)
+            assert batch.status()["status"][0] == 0
+            ntr, nap, est = batch.event_counts()
+            (tt, tb), (at, ad, ab, ak) = batch.events(0)
+            assert np.array_equal(bits(tt), bits(ott)) and np.array_equal(bits(at), bits(oat)) and np.array_equal(ak, oak)
+            assert compare_knots(batch.knots(0), c.knots(), "resumed clone")
+            continue
         batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator, params, [burns],
                                     max_knots=20000).enable_events(soi, max_transitions=16, max_apsides=4096)
-        for leg in legs:
+        for k, leg in enumerate(legs):
             batch.propagate(leg)
+            if len(legs) == 3 and k == 0:
+                snap = batch.clone()                      # taken after the first leg, resumed later
         assert batch.status()["status"][0] == 0
         ntr, nap, est = batch.event_counts()
         assert est[0] == 0 and ntr[0] == len(ott) and nap[0] == len(oat)
