@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append",
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
-    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate",
+    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow", "eph_debug_div",
@@ -162,6 +162,7 @@ def _lib():
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
     L.eph_craft_batch_clone.argtypes = [vp, C.POINTER(vp)]
+    L.eph_craft_batch_step_n.argtypes = [vp, C.c_uint32]
     L.eph_craft_batch_knot_slabs.argtypes = [vp, i32, i32, _dp, _dp]
     L.eph_craft_batch_reset_knots.argtypes = [vp]
     L.eph_craft_batch_reset_events.argtypes = [vp]
@@ -552,6 +553,10 @@ class SpacecraftBatch:
                                             int(max_knots), C.byref(h_))
         _check(st, "eph_craft_batch_create")
         self._h = h_
+
+    def step_n(self, n_steps=1):
+        """IncrementalPropagator::step n_steps times for every craft (one knot per step)."""
+        _check(self._L.eph_craft_batch_step_n(self._h, int(n_steps)), "eph_craft_batch_step_n")
 
     def clone(self):
         """SpacecraftPropagator: Clone -- a deep copy (state, knots, events) that can be resumed independently."""

@@ -56,6 +56,7 @@ struct CraftArgs {
     double h_init, h_max, tol_pos, tol_vel, fac_min, fac_max, fac;
     unsigned n_max;
     double t_end;
+    unsigned step_limit;      // accepted steps this call may take per craft (0 = until t_end)
 };
 
 struct V3 { double x, y, z; };
@@ -425,7 +426,8 @@ k_craft_propagate(const CraftArgs a) {
     }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
 
-    while (!(last_knot >= a.t_end)) {                 // has_reached: solution.end() >= time
+    unsigned taken = 0;
+    while (!(last_knot >= a.t_end) && !(a.step_limit && taken >= a.step_limit)) {   // has_reached: solution.end() >= time
         if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
         // SpacecraftPropagator::step: advance_timeline + reset_integrator  spacecraft.rs:606-609
         if (time >= sg.end) {
@@ -552,6 +554,7 @@ k_craft_propagate(const CraftArgs a) {
         }
         if (failed) break;
         steps += 1;
+        taken += 1;
         // CubicHermiteSplineSolout::solout: push (t, r, v)
         a.knot_t[(long long)nk * n + i] = time;
 #pragma unroll
@@ -635,7 +638,8 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
 #pragma unroll
     for (int q = 0; q < kDiv * 3; ++q) lb.c[q] = 0.0;
 
-    while (!(last_knot >= a.t_end)) {                 // has_reached: solution.end() >= time
+    unsigned taken = 0;
+    while (!(last_knot >= a.t_end) && !(a.step_limit && taken >= a.step_limit)) {   // has_reached: solution.end() >= time
         if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
         if (time >= sg.end) {                         // advance_timeline + reset_integrator  spacecraft.rs:606-609
             cur += 1;
@@ -766,6 +770,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
         }
         if (failed) break;
         steps += 1;
+        taken += 1;
         if (lane == 0) {                              // CubicHermiteSplineSolout::solout: push (t, r, v)
             a.knot_t[(long long)nk * n + i] = time;
 #pragma unroll
@@ -1445,7 +1450,14 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 
-int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) {
+static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit);
+int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) { return craft_run(b, t_end, 0); }
+// IncrementalPropagator::step, n times, for every craft  (ephemeris/src/lib.rs:40-47, spacecraft.rs:598-615)
+int32_t eph_craft_batch_step_n(eph_craft_batch *b, uint32_t n_steps) {
+    if (n_steps == 0) return b ? EPH_OK : EPH_ERR_BAD_ARGUMENT;
+    return craft_run(b, 1.7976931348623157e308, n_steps);
+}
+static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) {
     if (!b) return EPH_ERR_BAD_ARGUMENT;
     if (b->n == 0) return EPH_OK;
     EPH_HIP(hipSetDevice(b->device));
@@ -1464,6 +1476,7 @@ int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end) {
     a.tol_vel = b->params.tol_velocity; a.fac_min = b->params.fac_min; a.fac_max = b->params.fac_max;
     a.fac = b->params.fac; a.n_max = b->params.n_max;
     a.t_end = t_end;
+    a.step_limit = step_limit;
     EPH_HIP(hipEventRecord(b->ev0, b->stream));
     int st = craft_launch(b->stream, a);
     if (st) return st;

@@ -221,6 +221,9 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
 /* IncrementalPropagator::step_to for every craft: step() until solution.end() >= t_end (spacecraft.rs:598-615,
  * 691-693) or an error; per-craft outcomes via eph_craft_batch_status. Returns EPH_OK if the sweep ran. */
 int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end);
+/* IncrementalPropagator::step n_steps times for every craft (ephemeris/src/lib.rs:40-47, spacecraft.rs:598-615): each
+ * craft takes exactly n_steps accepted steps (one knot each) unless it fails or its knot slab fills. */
+int32_t eph_craft_batch_step_n(eph_craft_batch *b, uint32_t n_steps);
 /* per craft: status (eph_status or EPH_KNOTS_FULL), knots in the slab, attempts of the current integrator (n),
  * accepted steps since creation. Any pointer may be NULL. */
 int32_t eph_craft_batch_status(eph_craft_batch *b, int32_t *status, int32_t *nknots, uint32_t *attempts,

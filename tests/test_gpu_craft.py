@@ -479,3 +479,27 @@ def test_committed_spacecraft_knots(gpu, simple_system, method):
     assert len(at) == gm["apsides"]
     assert [[float(t).hex(), float(d).hex(), int(b), int(k)] for t, d, b, k in list(zip(at, ad, ab, ak))[:8]] == \
         gm["first_apsides"]
+
+
+def test_single_steps(gpu, simple_system):
+    """IncrementalPropagator::step through eph_craft_batch_step_n: one accepted step (one knot) per call and craft,
+    across burn boundaries, equal to the oracle's step(); then step_n(25) == 25 x step()."""
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    burns = ship_burns(ship, s.names)
+    batch = gpu.SpacecraftBatch(eph, ship.start, [ship.pos, ship.pos + 10.0], [ship.vel, ship.vel], "Verner87",
+                                burns=[burns, []], max_knots=256)
+    cs = [orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, "Verner87", burns=burns),
+          orc.Craft(osol, s.mu, ship.start, ship.pos + 10.0, ship.vel, "Verner87")]
+    for k in range(40):
+        batch.step_n(1)
+        for c in cs:
+            assert c.step() == 0
+        assert list(batch.status()["nknots"]) == [k + 2, k + 2]
+    batch.step_n(25)
+    for c in cs:
+        for _ in range(25):
+            assert c.step() == 0
+    for i, c in enumerate(cs):
+        assert compare_knots(batch.knots(i), c.knots(), f"single steps, craft {i}")
+    assert list(batch.status()["steps"]) == [65, 65]
