@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
-    "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append",
+    "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
@@ -162,6 +162,9 @@ def _lib():
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
     L.eph_craft_batch_clone.argtypes = [vp, C.POINTER(vp)]
+    L.eph_solution_create.argtypes = [i32, _dp, _dp, _i64p, _dp, _i32p, C.POINTER(vp)]
+    L.eph_solution_clear.argtypes = [vp, i32, f64, i32]
+    L.eph_solution_between.argtypes = [vp, f64, f64, C.POINTER(vp)]
     L.eph_craft_batch_step_n.argtypes = [vp, C.c_uint32]
     L.eph_craft_batch_knot_slabs.argtypes = [vp, i32, i32, _dp, _dp]
     L.eph_craft_batch_reset_knots.argtypes = [vp]
@@ -395,6 +398,37 @@ class Solution:
         _check(self._L.eph_solution_eval(self._h, body, m, _p(at), _p(pos), _p(vel) if with_velocity else None,
                                          _p(inside, _u8p)), "eph_solution_eval")
         return pos, vel, inside.astype(bool)
+
+    @classmethod
+    def from_parts(cls, start, interval, polys):
+        """Vec<UniformSpline> from per-body (start, interval) and a list per body of (coeffs[k][3]) polynomials (host
+        only: no device needed)."""
+        n = len(start)
+        npoly = np.array([len(p) for p in polys], dtype=np.int64)
+        tot = max(int(npoly.sum()), 1)
+        co, nc, q = np.zeros((tot, 8, 3)), np.zeros(tot, dtype=np.int32), 0
+        for body in polys:
+            for poly in body:
+                poly = np.asarray(poly, dtype=np.float64).reshape(-1, 3)
+                co[q, :len(poly)] = poly
+                nc[q] = len(poly)
+                q += 1
+        h_ = C.c_void_p()
+        _check(_lib().eph_solution_create(n, _p(_f64(start)), _p(_f64(interval)), _p(npoly, _i64p), _p(co), _p(nc, _i32p),
+                                          C.byref(h_)), "eph_solution_create")
+        return cls(h_)
+
+    def clear_before(self, at, body=-1):
+        _check(self._L.eph_solution_clear(self._h, int(body), float(at), 0), "eph_solution_clear")
+
+    def clear_after(self, at, body=-1):
+        _check(self._L.eph_solution_clear(self._h, int(body), float(at), 1), "eph_solution_clear")
+
+    def between(self, start, end):
+        """UniformSpline::between for every body -> Solution, or None where the reference returns None."""
+        h_ = C.c_void_p()
+        _check(self._L.eph_solution_between(self._h, float(start), float(end), C.byref(h_)), "eph_solution_between")
+        return Solution(h_) if h_.value else None
 
     def append(self, tail, direction=FORWARD):
         st = self._L.eph_solution_append(self._h, tail._h, int(direction))

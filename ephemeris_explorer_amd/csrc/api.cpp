@@ -372,6 +372,57 @@ int32_t eph_solution_append(eph_solution *s, const eph_solution *tail, int32_t d
     return EPH_OK;
     EPH_GUARD_END
 }
+// Vec<UniformSpline> from its parts (host only): what a shim needs to hand an ephemeris built elsewhere -- or one it
+// stored -- to eph_solution_eval / eph_ephemeris_create
+int32_t eph_solution_create(int32_t n_bodies, const double *start, const double *interval, const int64_t *npoly,
+                            const double *coeffs, const int32_t *ncoef, eph_solution **out) {
+    EPH_GUARD_BEGIN
+    if (n_bodies < 0 || !out || (n_bodies > 0 && (!start || !interval || !npoly))) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<eph_solution> s(new eph_solution());
+    s->s.splines.resize((size_t)n_bodies);
+    int64_t q = 0;
+    for (int b = 0; b < n_bodies; ++b) {
+        if (npoly[b] < 0 || (npoly[b] > 0 && (!coeffs || !ncoef))) return EPH_ERR_BAD_ARGUMENT;
+        UniformSpline &u = s->s.splines[b];
+        u.start = start[b];
+        u.interval = interval[b];
+        for (int64_t k = 0; k < npoly[b]; ++k, ++q) {
+            if (ncoef[q] < 0 || ncoef[q] > kDiv) return EPH_ERR_BAD_ARGUMENT;
+            Polynomial p;
+            p.ncoef = ncoef[q];
+            std::copy(coeffs + q * kDiv * 3, coeffs + (q + 1) * kDiv * 3, &p.c[0][0]);
+            u.polynomials.push_back(p);
+        }
+    }
+    *out = s.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
+// UniformSpline::clear_before / clear_after on one body's spline, or on all of them (body < 0)
+int32_t eph_solution_clear(eph_solution *s, int32_t body, double at, int32_t after) {
+    EPH_GUARD_BEGIN
+    if (!s || body >= (int32_t)s->s.splines.size()) return EPH_ERR_BAD_ARGUMENT;
+    for (size_t b = 0; b < s->s.splines.size(); ++b) {
+        if (body >= 0 && (size_t)body != b) continue;
+        if (after) s->s.splines[b].clear_after(at); else s->s.splines[b].clear_before(at);
+    }
+    return EPH_OK;
+    EPH_GUARD_END
+}
+// UniformSpline::between for every body: *out = the sub-splines (NULL if any body's is None)
+int32_t eph_solution_between(const eph_solution *s, double from, double to, eph_solution **out) {
+    EPH_GUARD_BEGIN
+    if (!s || !out) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<eph_solution> r(new eph_solution());
+    r->s.splines.resize(s->s.splines.size());
+    for (size_t b = 0; b < s->s.splines.size(); ++b)
+        if (!s->s.splines[b].between(from, to, &r->s.splines[b])) return EPH_OK;   // None
+    *out = r.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
 void eph_solution_destroy(eph_solution *s) { delete s; }
 
 int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, const double *samples, double *coeffs,

@@ -7,6 +7,8 @@
 // All numerical state lives on the device; the host keeps the scalar bookkeeping the reference keeps
 // (time, bound, step counters, sampling counters) and replays it with the reference's f64 operations.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <deque>
 #include <memory>
@@ -169,6 +171,45 @@ struct UniformSpline {
     void push_front(const Polynomial &p) {
         polynomials.push_front(p);
         start -= interval;
+    }
+    // get_index_local / get_index_local_exclusive  trajectory.rs:591-617 (`as usize` saturates; NaN -> 0). false = None
+    static uint64_t to_usize(double x) {
+        if (!(x > 0.0)) return 0;
+        return x >= 18446744073709551616.0 ? ~0ull : (uint64_t)x;
+    }
+    bool get_index_local(double time, uint64_t *idx) const {
+        if (std::signbit(time) || time >= span()) return false;
+        *idx = to_usize(time / interval);
+        return true;
+    }
+    bool get_index_local_exclusive(double time, uint64_t *idx) const {
+        if (std::signbit(time) || time > span()) return false;
+        const uint64_t c = to_usize(std::ceil(time / interval));
+        *idx = c == 0 ? 0 : c - 1;                        // saturating_sub(1)
+        return true;
+    }
+    void clear_before(double at) {                        // trajectory.rs:536-542
+        uint64_t idx;
+        if (!get_index_local_exclusive((at + interval) - start, &idx)) return;
+        start += interval * (double)idx;
+        const uint64_t k = std::min<uint64_t>(idx, polynomials.size());   // drain(0..idx) (idx <= len here)
+        polynomials.erase(polynomials.begin(), polynomials.begin() + (std::ptrdiff_t)k);
+    }
+    void clear_after(double at) {                         // trajectory.rs:544-549
+        uint64_t idx;
+        if (!get_index_local(at - start, &idx)) return;
+        if (idx < polynomials.size()) polynomials.resize((size_t)idx);       // truncate(idx)
+    }
+    bool between(double from, double to, UniformSpline *out) const {        // trajectory.rs:484-502
+        if (polynomials.empty()) return false;
+        uint64_t a, b;
+        if (!get_index_local_exclusive(from - start, &a) || !get_index_local_exclusive(to - start, &b)) return false;
+        out->start = start + interval * (double)a;
+        out->interval = interval;
+        out->polynomials.clear();
+        for (uint64_t i = a; i < b + 1 && b + 1 != 0; ++i)                   // (start..end + 1).filter_map(get)
+            if (i < polynomials.size()) out->polynomials.push_back(polynomials[(size_t)i]);
+        return true;
     }
 };
 

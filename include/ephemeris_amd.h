@@ -170,6 +170,16 @@ int32_t eph_solution_eval(const eph_solution *s, int32_t body, int64_t m, const 
 /* UniformSpline::append (direction = EPH_FORWARD) / prepend (EPH_BACKWARD), trajectory.rs:515-539; the
  * reference's assert_eq! contiguity checks become EPH_ERR_BAD_ARGUMENT. `tail` is left unchanged. */
 int32_t eph_solution_append(eph_solution *s, const eph_solution *tail, int32_t direction);
+/* Vec<UniformSpline<DVec3>> from its parts (host only; an ephemeris built or stored elsewhere): per body start,
+ * interval and polynomial count; polynomials concatenated in body order as coeffs[poly][8][3] and ncoef[poly]. */
+int32_t eph_solution_create(int32_t n_bodies, const double *start, const double *interval, const int64_t *npoly,
+                            const double *coeffs, const int32_t *ncoef, eph_solution **out);
+/* UniformSpline::clear_before (after = 0, trajectory.rs:536-542) / clear_after (after = 1, :544-549) at epoch `at` on
+ * body's spline, or on every spline (body < 0). Host only. */
+int32_t eph_solution_clear(eph_solution *s, int32_t body, double at, int32_t after);
+/* UniformSpline::between(from, to) (trajectory.rs:484-502) for every body: *out = the sub-splines, or NULL where the
+ * reference returns None for any body. Host only. */
+int32_t eph_solution_between(const eph_solution *s, double from, double to, eph_solution **out);
 void eph_solution_destroy(eph_solution *s);
 
 /* LeastSquaresFit::interpolate (ephemeris_explorer/src/dynamics/celestial.rs:24-135) for `nwin` windows of 9

@@ -691,3 +691,51 @@ def timeline_divergence_time_before(new_burns, old_burns, before):
             break
         times.append(t)
     return times[-1] if times else None
+
+
+# ---- UniformSpline container operations  ephemeris/src/trajectory.rs:484-617 (host logic) ----
+def _usize(x):
+    """Rust `as usize` from f64: saturating, NaN -> 0"""
+    if not x > 0.0:
+        return 0
+    return (1 << 64) - 1 if x >= 18446744073709551616.0 else int(x)
+
+
+class Spline:
+    """UniformSpline<V> with opaque polynomials: start, interval, list"""
+
+    def __init__(self, start, interval, polys):
+        self.start, self.interval, self.polys = start, interval, list(polys)
+
+    def span(self):
+        return self.interval * float(len(self.polys))
+
+    def _idx(self, time):
+        if math.copysign(1.0, time) < 0.0 or time >= self.span():
+            return None
+        return _usize(time / self.interval)
+
+    def _idx_excl(self, time):
+        if math.copysign(1.0, time) < 0.0 or time > self.span():
+            return None
+        return max(_usize(math.ceil(time / self.interval)) - 1, 0)
+
+    def clear_before(self, at):
+        idx = self._idx_excl((at + self.interval) - self.start)
+        if idx is not None:
+            self.start += self.interval * float(idx)
+            del self.polys[:idx]
+
+    def clear_after(self, at):
+        idx = self._idx(at - self.start)
+        if idx is not None:
+            del self.polys[idx:]
+
+    def between(self, start, end):
+        if not self.polys:
+            return None
+        a, b = self._idx_excl(start - self.start), self._idx_excl(end - self.start)
+        if a is None or b is None:
+            return None
+        return Spline(self.start + self.interval * float(a), self.interval,
+                      [self.polys[i] for i in range(a, b + 1) if i < len(self.polys)])

@@ -1,5 +1,7 @@
 """Flight-plan restart logic (ephemeris_explorer/src/flight_plan.rs:263-303, ephemeris/src/propagators/
 spacecraft.rs:129-213): host-only code of the product library (no device call), against the Python restatement."""
+import math
+
 import numpy as np
 import pytest
 
@@ -71,3 +73,58 @@ def test_divergence_random_plans_match_restatement(ea):
                 ea.timeline_divergence_time(old, new, before)
         else:
             assert ea.timeline_divergence_time(old, new, before) == want
+
+
+def _random_solution(ea, rng, n_bodies=3):
+    starts = rng.choice([0.0, 100.0, -250.5], n_bodies)
+    intervals = rng.choice([8.0, 30.0, 600.0], n_bodies)
+    polys = [[rng.normal(size=(int(rng.integers(1, 9)), 3)) for _ in range(int(rng.integers(0, 12)))]
+             for _ in range(n_bodies)]
+    sol = ea.Solution.from_parts(starts, intervals, polys)
+    ref = [po.Spline(float(starts[b]), float(intervals[b]), [p.copy() for p in polys[b]]) for b in range(n_bodies)]
+    return sol, ref
+
+
+def _same(sol, ref):
+    for b, r in enumerate(ref):
+        st, iv, n = sol.info(b)
+        if (st, iv, n) != (r.start, r.interval, len(r.polys)):
+            return False
+        co, nc = sol.coeffs(b)
+        for q, p in enumerate(r.polys):
+            if nc[q] != len(p) or not np.array_equal(co[q, :len(p)], p):
+                return False
+    return True
+
+
+def test_spline_container_operations(ea):
+    """UniformSpline::{clear_before, clear_after, between} (ephemeris/src/trajectory.rs:484-549,591-617) of the product
+    (host logic, no device) against the Python restatement, at random and boundary epochs."""
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        sol, ref = _random_solution(ea, rng)
+        assert _same(sol, ref)
+        b0 = ref[0]
+        knots = [b0.start + b0.interval * k for k in range(len(b0.polys) + 2)]
+        at = float(rng.choice(knots + [float(rng.uniform(-400.0, 8000.0)), b0.start - 1.0, math.nextafter(b0.start, -math.inf)]))
+        op = int(rng.integers(0, 3))
+        if op == 0:
+            sol.clear_before(at)
+            for r in ref:
+                r.clear_before(at)
+            assert _same(sol, ref), ("clear_before", at)
+        elif op == 1:
+            body = int(rng.integers(-1, len(ref)))
+            sol.clear_after(at, body)
+            for b, r in enumerate(ref):
+                if body < 0 or body == b:
+                    r.clear_after(at)
+            assert _same(sol, ref), ("clear_after", at, body)
+        else:
+            end = at + float(rng.choice([0.0, 8.0, 100.0, 5000.0]))
+            got = sol.between(at, end)
+            want = [r.between(at, end) for r in ref]
+            if any(w is None for w in want):
+                assert got is None, ("between", at, end)
+            else:
+                assert got is not None and _same(got, want), ("between", at, end)
