@@ -78,10 +78,6 @@ def main(argv=None):
     for path in ships:
         ship = load_ship(path)
         entry = {"name": ship.name, "integrator": ship.integrator}
-        if ship.integrator == "Fine45":
-            entry["skipped"] = "ERKNG (Fine45) is not built yet"
-            out["ships"].append(entry)
-            continue
         try:
             burns = [(b.start, b.start + b.duration, b.acceleration,
                       system.names.index(b.reference) if b.reference else -1) for b in ship.burns]

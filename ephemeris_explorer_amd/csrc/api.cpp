@@ -352,7 +352,9 @@ int32_t eph_solution_eval(const eph_solution *s, int32_t body, int64_t m, const 
 }
 int32_t eph_solution_append(eph_solution *s, const eph_solution *tail, int32_t direction) {
     EPH_GUARD_BEGIN
-    if (!s || !tail || s->s.splines.size() != tail->s.splines.size()) return EPH_ERR_BAD_ARGUMENT;
+    // s == tail would insert a deque's own iterator range into itself (undefined behaviour); the reference's
+    // append takes `other` by value, so aliasing cannot be expressed there
+    if (!s || !tail || s == tail || s->s.splines.size() != tail->s.splines.size()) return EPH_ERR_BAD_ARGUMENT;
     // check every spline first so a failure leaves `s` untouched (the reference would have panicked)
     for (size_t b = 0; b < s->s.splines.size(); ++b) {
         const UniformSpline &x = s->s.splines[b], &y = tail->s.splines[b];
@@ -391,7 +393,8 @@ int32_t eph_solution_create(int32_t n_bodies, const double *start, const double 
             if (ncoef[q] < 0 || ncoef[q] > kDiv) return EPH_ERR_BAD_ARGUMENT;
             Polynomial p;
             p.ncoef = ncoef[q];
-            std::copy(coeffs + q * kDiv * 3, coeffs + (q + 1) * kDiv * 3, &p.c[0][0]);
+            // rows at or beyond ncoef stay +0.0 (the invariant k_lsq_fit produces and eph_solution_coeffs returns)
+            std::copy(coeffs + q * kDiv * 3, coeffs + q * kDiv * 3 + (size_t)ncoef[q] * 3, &p.c[0][0]);
             u.polynomials.push_back(p);
         }
     }

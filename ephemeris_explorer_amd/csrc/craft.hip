@@ -1382,6 +1382,17 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
     try {
         if (!e || n_craft < 0 || !method || !params || !out || max_knots < 1 || (n_craft > 0 && (!t0 || !pos || !vel)))
             return EPH_ERR_BAD_ARGUMENT;
+        // the burn tables are caller memory: validate before the first dereference (CSR offsets start at a
+        // non-negative value and never decrease; arrays present when any burn is; reference body -1 or a body index)
+        if (burn_offset) {
+            if (burn_offset[0] < 0) return EPH_ERR_BAD_ARGUMENT;
+            for (int64_t i = 0; i < n_craft; ++i)
+                if (burn_offset[i + 1] < burn_offset[i]) return EPH_ERR_BAD_ARGUMENT;
+            if (burn_offset[n_craft] > 0 && (!burn_start || !burn_end || !burn_acc || !burn_ref))
+                return EPH_ERR_BAD_ARGUMENT;
+            for (int64_t q = burn_offset[0]; q < burn_offset[n_craft]; ++q)
+                if (burn_ref[q] < -1 || burn_ref[q] >= e->n_bodies) return EPH_ERR_BAD_ARGUMENT;
+        }
         int st = check_device();
         if (st) return st;
         std::unique_ptr<eph_craft_batch> b(new eph_craft_batch());
@@ -1404,8 +1415,6 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
         for (long long i = 0; i < n; ++i) {
             seg_off[i] = (long long)segs.size();
             const long long b0 = burn_offset ? burn_offset[i] : 0, b1 = burn_offset ? burn_offset[i + 1] : 0;
-            for (long long q = b0; q < b1; ++q)
-                if (burn_ref[q] >= e->n_bodies) return EPH_ERR_BAD_ARGUMENT;
             timeline_new(b1 - b0, burn_start + b0, burn_end + b0, burn_acc + 3 * b0, burn_ref + b0, segs);
             // segment_idx_at(t0): partition_point(seg.end() <= time)
             int idx = 0;

@@ -111,6 +111,8 @@ int launch_soa_to_aos(hipStream_t s, int n, int npad, const double *soa, double 
 // LeastSquaresFit over windows of 9 samples; window w of the launch reads log[(first[w]) .. +8]
 int launch_lsq_fit(hipStream_t s, int64_t nwin, const uint64_t *first_sample, const uint8_t *degree, int backward,
                    const double *log, double *coeffs, int32_t *ncoef);
+// records of kDiv*3 + 1 doubles per window (coefficients, then ncoef) for the sharded propagator's all-gather
+int launch_pack_records(hipStream_t s, int64_t nwin, const double *coeffs, const int32_t *ncoef, double *rec);
 int launch_spline_eval(hipStream_t s, int64_t m, const double *at, double start, double interval, int64_t npoly,
                        const double *coeffs, const int32_t *ncoef, double *pos, double *vel, uint8_t *inside);
 

@@ -43,6 +43,7 @@ struct DevBuf {   // owning device allocation
         count = n;
         return EPH_OK;
     }
+    int reserve(size_t n) { return n <= count ? EPH_OK : alloc(n + n / 2); }   // grow-only scratch; contents are lost
 };
 
 // The exchange step of a target-partitioned run (shard.cpp): in-place all-gather of equal slices over the ranks.
@@ -261,6 +262,14 @@ private:
     std::vector<uint64_t> log_off_, log_cap_;
     DevBuf<uint32_t> d_period_, d_phase_;
     DevBuf<uint64_t> d_offset_;
+    // run_batch scratch (grow-only, reused by every batch) and the sticky status of a batch that failed half-way
+    DevBuf<uint64_t> d_first_, d_region_;
+    DevBuf<uint8_t> d_deg_;
+    DevBuf<double> d_co_, d_all_;
+    DevBuf<int32_t> d_nc_;
+    DevBuf<uint32_t> d_src_, d_cnt_;
+    int failed_ = EPH_OK;
+    int fit_and_push(int64_t done, hipStream_t s);
 };
 
 }  // namespace eph

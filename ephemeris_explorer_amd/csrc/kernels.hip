@@ -1033,6 +1033,16 @@ __global__ void k_carry(int n, const uint64_t *__restrict__ region, const uint32
     double *base = log + region[b] * 3;
     for (uint32_t k = 0; k < cnt[b] * 3; ++k) base[k] = base[(size_t)src[b] * 3 + k];
 }
+// sharded propagator: window q of this rank's fit -> exchange record [24 coefficients, ncoef] of its slice
+__global__ void k_pack_records(long long nwin, const double *__restrict__ co, const int32_t *__restrict__ nc,
+                               double *__restrict__ rec) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int R = kDiv * 3 + 1;
+    if (t >= nwin * R) return;
+    const long long q = t / R;
+    const int k = (int)(t % R);
+    rec[t] = k < kDiv * 3 ? co[q * kDiv * 3 + k] : (double)nc[q];
+}
 __global__ void k_aos_to_soa(int n, int npad, const double *__restrict__ aos, double *__restrict__ soa) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 3 * n) return;
@@ -1345,6 +1355,12 @@ int launch_carry(hipStream_t s, int n, const uint64_t *region, const uint32_t *s
     if (n <= 0) return EPH_OK;
     hipLaunchKernelGGL(k_carry, dim3((n + 255) / 256), dim3(256), 0, s, n, region, src, cnt, log);
     return done("k_carry");
+}
+int launch_pack_records(hipStream_t s, int64_t nwin, const double *co, const int32_t *nc, double *rec) {
+    if (nwin <= 0) return EPH_OK;
+    const long long tot = nwin * (kDiv * 3 + 1);
+    hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (long long)nwin, co, nc, rec);
+    return done("k_pack_records");
 }
 int launch_lsq_fit(hipStream_t s, int64_t nwin, const uint64_t *first_sample, const uint8_t *degree, int backward,
                    const double *log, double *coeffs, int32_t *ncoef) {

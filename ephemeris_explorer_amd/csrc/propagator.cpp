@@ -108,6 +108,7 @@ int NBodyPropagator::create(int n, const double *pos, const double *vel, const d
 }
 
 int NBodyPropagator::clone(std::unique_ptr<NBodyPropagator> *out) {
+    if (failed_) return failed_;
     std::unique_ptr<NBodyPropagator> p(new NBodyPropagator());
     int st = integ_->clone(&p->integ_);
     if (st) return st;
@@ -130,6 +131,7 @@ int NBodyPropagator::clone(std::unique_ptr<NBodyPropagator> *out) {
 
 // One device batch of k integrator steps + solout   (k x [Integration::advance -> Solout::solout], lib.rs:379-391)
 int NBodyPropagator::run_batch(int64_t k) {
+    if (failed_) return failed_;
     const int n = (int)interp_.size();
     NBodyIntegration &ig = *integ_;
     hipStream_t s = ig.stream();
@@ -149,8 +151,19 @@ int NBodyPropagator::run_batch(int64_t k) {
     ig.set_sampling(sa);
     int64_t done = 0;
     const int st_adv = ig.advance(k, &done);
+    // From here on the integrator has moved: a failure between now and the push of the fitted polynomials would
+    // leave counters, sample log and solution out of step with it, so it is made sticky -- every later step /
+    // step_to / take_solution / clone returns the same error instead of a spline with a missing segment.
+    const int st_fit = fit_and_push(done, s);
+    if (st_fit) return failed_ = st_fit;
+    return st_adv;
+}
 
-    // replay the per-step bookkeeping of SplineInterpolators::solout_with (nbody.rs:371-400) for `done` steps
+// the per-step bookkeeping of SplineInterpolators::solout_with (nbody.rs:371-400) replayed for `done` steps, the
+// least-squares fit of every window they completed, and the push of the polynomials into the solution
+int NBodyPropagator::fit_and_push(int64_t done, hipStream_t s) {
+    const int n = (int)interp_.size();
+    NBodyIntegration &ig = *integ_;
     std::vector<uint64_t> first;
     std::vector<uint8_t> deg;
     std::vector<uint32_t> nwin(n, 0), carry_src(n, 0), carry_cnt(n, 0);
@@ -179,90 +192,75 @@ int NBodyPropagator::run_batch(int64_t k) {
         }
     }
     const int64_t W = (int64_t)first.size();
-    if (W > 0) {
-        // Sharded system (eph_prop_shard): this rank samples and fits only the bodies it owns -- the windows of
-        // bodies [lo, hi) are the contiguous range [qlo, qhi) of the window list -- and the fitted polynomials
-        // are all-gathered (equal slices of world x wmax windows, 25 doubles each: 24 coefficients + ncoef) so
-        // that every rank holds the whole Vec<UniformSpline>. The window bookkeeping above is identical on
-        // every rank, so all ranks agree on the ranges.
-        const bool sharded = ig.sharded();
-        const int world = ig.shard_world(), rank = ig.shard_rank(), slice = ig.shard_slice();
-        std::vector<int64_t> qstart(n + 1, 0);
-        for (int b = 0; b < n; ++b) qstart[b + 1] = qstart[b] + nwin[b];
-        auto body_lo = [&](int r) { return std::min<int64_t>((int64_t)r * slice, n); };
-        const int64_t qlo = sharded ? qstart[body_lo(rank)] : 0, qhi = sharded ? qstart[body_lo(rank + 1)] : W;
-        int64_t wmax = 0;
-        for (int r = 0; r < world && sharded; ++r) wmax = std::max(wmax, qstart[body_lo(r + 1)] - qstart[body_lo(r)]);
-        DevBuf<uint64_t> d_first;
-        DevBuf<uint8_t> d_deg;
-        DevBuf<double> d_co, d_all;
-        DevBuf<int32_t> d_nc;
-        DevBuf<uint32_t> d_src, d_cnt;
-        DevBuf<uint64_t> d_region;
-        int st;
-        if ((st = d_first.alloc(W)) || (st = d_deg.alloc(W)) || (st = d_co.alloc((size_t)W * kDiv * 3)) ||
-            (st = d_nc.alloc(W)) || (st = d_src.alloc(n)) || (st = d_cnt.alloc(n)) || (st = d_region.alloc(n)))
+    if (W == 0) return EPH_OK;
+    // Sharded system (eph_prop_shard): this rank samples and fits only the bodies it owns -- the windows of
+    // bodies [lo, hi) are the contiguous range [qlo, qhi) of the window list -- and the fitted polynomials
+    // are all-gathered (equal slices of world x wmax windows, 25 doubles each: 24 coefficients + ncoef) so
+    // that every rank holds the whole Vec<UniformSpline>. The window bookkeeping above is identical on
+    // every rank, so all ranks agree on the ranges.
+    const bool sharded = ig.sharded();
+    const int world = ig.shard_world(), rank = ig.shard_rank(), slice = ig.shard_slice();
+    std::vector<int64_t> qstart(n + 1, 0);
+    for (int b = 0; b < n; ++b) qstart[b + 1] = qstart[b] + nwin[b];
+    auto body_lo = [&](int r) { return std::min<int64_t>((int64_t)r * slice, n); };
+    const int64_t qlo = sharded ? qstart[body_lo(rank)] : 0, qhi = sharded ? qstart[body_lo(rank + 1)] : W;
+    int64_t wmax = 0;
+    for (int r = 0; r < world && sharded; ++r) wmax = std::max(wmax, qstart[body_lo(r + 1)] - qstart[body_lo(r)]);
+    int st;
+    // scratch is grow-only and lives with the propagator: a steady run allocates nothing per batch
+    if ((st = d_first_.reserve(W)) || (st = d_deg_.reserve(W)) || (st = d_co_.reserve((size_t)W * kDiv * 3)) ||
+        (st = d_nc_.reserve(W)) || (st = d_src_.reserve(n)) || (st = d_cnt_.reserve(n)) || (st = d_region_.reserve(n)))
+        return st;
+    EPH_HIP(hipMemcpyAsync(d_first_.p, first.data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_deg_.p, deg.data(), sizeof(uint8_t) * W, hipMemcpyHostToDevice, s));
+    if (qhi > qlo &&
+        (st = launch_lsq_fit(s, qhi - qlo, d_first_.p + qlo, d_deg_.p + qlo, direction_ < 0, log_.p,
+                             d_co_.p + qlo * kDiv * 3, d_nc_.p + qlo)))
+        return st;
+    std::vector<double> co((size_t)W * kDiv * 3), all;
+    std::vector<int32_t> nc(W);
+    const size_t rec = (size_t)kDiv * 3 + 1;                      // doubles per window in the exchange buffer
+    const size_t slice_d = (size_t)std::max<int64_t>(wmax, 1) * rec;
+    if (sharded) {
+        // device-side: pack this rank's windows into its slice of the exchange buffer, all-gather in place,
+        // one copy of the whole buffer to the host (which owns the Vec<UniformSpline>)
+        if ((st = d_all_.reserve(slice_d * world))) return st;
+        if ((st = launch_pack_records(s, qhi - qlo, d_co_.p + qlo * kDiv * 3, d_nc_.p + qlo,
+                                      d_all_.p + (size_t)rank * slice_d)))
             return st;
-        EPH_HIP(hipMemcpyAsync(d_first.p, first.data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, s));
-        EPH_HIP(hipMemcpyAsync(d_deg.p, deg.data(), sizeof(uint8_t) * W, hipMemcpyHostToDevice, s));
-        if (qhi > qlo &&
-            (st = launch_lsq_fit(s, qhi - qlo, d_first.p + qlo, d_deg.p + qlo, direction_ < 0, log_.p,
-                                 d_co.p + qlo * kDiv * 3, d_nc.p + qlo)))
-            return st;
-        std::vector<double> co((size_t)W * kDiv * 3);
-        std::vector<int32_t> nc(W);
-        if (sharded) {
-            const size_t rec = (size_t)kDiv * 3 + 1;                  // doubles per window in the exchange buffer
-            const size_t slice_d = (size_t)std::max<int64_t>(wmax, 1) * rec;
-            if ((st = d_all.alloc(slice_d * world))) return st;
-            std::vector<double> mine(slice_d, 0.0), all(slice_d * world);
-            std::vector<double> own_co((size_t)(qhi - qlo) * kDiv * 3);
-            std::vector<int32_t> own_nc((size_t)(qhi - qlo));
-            if (qhi > qlo) {
-                EPH_HIP(hipMemcpyAsync(own_co.data(), d_co.p + qlo * kDiv * 3, sizeof(double) * own_co.size(),
-                                       hipMemcpyDeviceToHost, s));
-                EPH_HIP(hipMemcpyAsync(own_nc.data(), d_nc.p + qlo, sizeof(int32_t) * own_nc.size(),
-                                       hipMemcpyDeviceToHost, s));
-            }
-            EPH_HIP(hipStreamSynchronize(s));
-            for (int64_t q = 0; q < qhi - qlo; ++q) {
-                std::copy(own_co.begin() + q * kDiv * 3, own_co.begin() + (q + 1) * kDiv * 3, mine.begin() + q * rec);
-                mine[q * rec + kDiv * 3] = (double)own_nc[q];
-            }
-            EPH_HIP(hipMemcpyAsync(d_all.p + (size_t)rank * slice_d, mine.data(), sizeof(double) * slice_d,
-                                   hipMemcpyHostToDevice, s));
-            if ((st = ig.gather_buffer(d_all.p, sizeof(double) * slice_d))) return st;
-            EPH_HIP(hipMemcpyAsync(all.data(), d_all.p, sizeof(double) * all.size(), hipMemcpyDeviceToHost, s));
-            EPH_HIP(hipStreamSynchronize(s));
-            for (int r = 0; r < world; ++r) {
-                const int64_t a0 = qstart[body_lo(r)], a1 = qstart[body_lo(r + 1)];
-                for (int64_t q = a0; q < a1; ++q) {
-                    const double *src = all.data() + (size_t)r * slice_d + (size_t)(q - a0) * rec;
-                    std::copy(src, src + kDiv * 3, co.begin() + q * kDiv * 3);
-                    nc[q] = (int32_t)src[kDiv * 3];
-                }
-            }
-        } else {
-            EPH_HIP(hipMemcpyAsync(co.data(), d_co.p, sizeof(double) * co.size(), hipMemcpyDeviceToHost, s));
-            EPH_HIP(hipMemcpyAsync(nc.data(), d_nc.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, s));
-        }
-        EPH_HIP(hipMemcpyAsync(d_src.p, carry_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
-        EPH_HIP(hipMemcpyAsync(d_cnt.p, carry_cnt.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
-        EPH_HIP(hipMemcpyAsync(d_region.p, log_off_.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice, s));
-        if ((st = launch_carry(s, n, d_region.p, d_src.p, d_cnt.p, log_.p))) return st;
-        EPH_HIP(hipStreamSynchronize(s));
-        int64_t q = 0;
-        for (int b = 0; b < n; ++b) {
-            UniformSpline &traj = solution_.splines[b];
-            for (uint32_t w = 0; w < nwin[b]; ++w, ++q) {
-                Polynomial poly;
-                poly.ncoef = nc[q];
-                std::copy(co.begin() + q * kDiv * 3, co.begin() + (q + 1) * kDiv * 3, &poly.c[0][0]);
-                if (direction_ > 0) traj.push_back(poly); else traj.push_front(poly);   // push_at_bound
+        if ((st = ig.gather_buffer(d_all_.p, sizeof(double) * slice_d))) return st;
+        all.resize(slice_d * world);
+        EPH_HIP(hipMemcpyAsync(all.data(), d_all_.p, sizeof(double) * all.size(), hipMemcpyDeviceToHost, s));
+    } else {
+        EPH_HIP(hipMemcpyAsync(co.data(), d_co_.p, sizeof(double) * co.size(), hipMemcpyDeviceToHost, s));
+        EPH_HIP(hipMemcpyAsync(nc.data(), d_nc_.p, sizeof(int32_t) * W, hipMemcpyDeviceToHost, s));
+    }
+    EPH_HIP(hipMemcpyAsync(d_src_.p, carry_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_cnt_.p, carry_cnt.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+    EPH_HIP(hipMemcpyAsync(d_region_.p, log_off_.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice, s));
+    if ((st = launch_carry(s, n, d_region_.p, d_src_.p, d_cnt_.p, log_.p))) return st;
+    EPH_HIP(hipStreamSynchronize(s));
+    if (sharded) {
+        for (int r = 0; r < world; ++r) {
+            const int64_t a0 = qstart[body_lo(r)], a1 = qstart[body_lo(r + 1)];
+            for (int64_t q = a0; q < a1; ++q) {
+                const double *src = all.data() + (size_t)r * slice_d + (size_t)(q - a0) * rec;
+                std::copy(src, src + kDiv * 3, co.begin() + q * kDiv * 3);
+                nc[q] = (int32_t)src[kDiv * 3];
             }
         }
     }
-    return st_adv;
+    int64_t q = 0;
+    for (int b = 0; b < n; ++b) {
+        UniformSpline &traj = solution_.splines[b];
+        for (uint32_t w = 0; w < nwin[b]; ++w, ++q) {
+            Polynomial poly;
+            poly.ncoef = nc[q];
+            std::copy(co.begin() + q * kDiv * 3, co.begin() + (q + 1) * kDiv * 3, &poly.c[0][0]);
+            if (direction_ > 0) traj.push_back(poly); else traj.push_front(poly);   // push_at_bound
+        }
+    }
+    return EPH_OK;
 }
 
 int NBodyPropagator::step_n(int64_t k) {
@@ -322,6 +320,7 @@ int64_t NBodyPropagator::steps_until_reached(double t, int64_t cap) const {
 }
 
 int NBodyPropagator::step_to(double t) {   // IncrementalPropagator::step_to  ephemeris/src/lib.rs:49-60
+    if (failed_) return failed_;
     for (;;) {
         if (has_reached(t)) return EPH_OK;
         int64_t k = integ_->started() ? steps_until_reached(t, kmax_) : 1;
@@ -332,6 +331,7 @@ int NBodyPropagator::step_to(double t) {   // IncrementalPropagator::step_to  ep
 }
 
 int NBodyPropagator::take_solution(std::unique_ptr<Solution> *out) {   // nbody.rs:182-189
+    if (failed_) return failed_;
     std::unique_ptr<Solution> old(new Solution(std::move(solution_)));
     solution_ = new_solution();
     *out = std::move(old);

@@ -128,3 +128,30 @@ def test_spline_container_operations(ea):
                 assert got is None, ("between", at, end)
             else:
                 assert got is not None and _same(got, want), ("between", at, end)
+
+
+def test_solution_create_zeroes_rows_beyond_ncoef_and_append_rejects_aliasing(ea):
+    """eph_solution_create keeps only ncoef rows of each polynomial (the rest +0.0, the invariant of the fit kernel);
+    eph_solution_append(s, s) is refused (the reference's `append` consumes `other`: no aliasing there)."""
+    poly = np.arange(24, dtype=np.float64).reshape(8, 3) + 1.0
+    sol = ea.Solution.from_parts([0.0], [8.0], [[poly[:3]]])
+    co, nc = sol.coeffs(0)
+    assert nc[0] == 3 and np.array_equal(co[0, :3], poly[:3]) and not co[0, 3:].any()
+    # hand the library junk in the rows beyond ncoef: it must not come back
+    import ctypes
+    lib = ea._lib()
+    out = ctypes.c_void_p()
+    start = np.array([0.0]); interval = np.array([8.0]); npoly = np.array([1], dtype=np.int64)
+    ncoef = np.array([3], dtype=np.int32)
+    dp, ip, lp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    st = lib.eph_solution_create(1, start.ctypes.data_as(dp), interval.ctypes.data_as(dp), npoly.ctypes.data_as(lp),
+                                 poly.ctypes.data_as(dp), ncoef.ctypes.data_as(ip), ctypes.byref(out))
+    assert st == 0
+    got = np.zeros((1, 8, 3)); gn = np.zeros(1, dtype=np.int32)
+    assert lib.eph_solution_coeffs(out, 0, got.ctypes.data_as(dp), gn.ctypes.data_as(ip)) == 0
+    assert np.array_equal(got[0, :3], poly[:3]) and not got[0, 3:].any()
+    assert lib.eph_solution_append(out, out, 1) != 0
+    assert lib.eph_solution_append(out, out, -1) != 0
+    lib.eph_solution_destroy(out)
+    with pytest.raises(ValueError):
+        sol.append(sol)
