@@ -1664,3 +1664,8 @@ int orc_hermite_eval(int64_t n, const double *t, const double *pos, const double
     }
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* The reference's own convergence test on Double<DVec3> (ephemeris/tests/solar_system_convergence.rs) */
+/* ------------------------------------------------------------------------------------------------ */
+#include "convergence_double.inc"

@@ -149,6 +149,16 @@ double orc_cr_pow(double x, double y);
 double orc_doc_test_decay(const char *method, int adaptive, double h, double h_max, double atol, double rtol,
                           double t_end, uint32_t *steps);
 
+/* ---- the reference's convergence test on Double<DVec3> (ephemeris/tests/solar_system_convergence.rs) ---- */
+/* Integration::solve of the generic steppers on the compensated variable type of :12-110; out_y / out_dy hold
+ * (value, error) per component: [n][3][2]. max_steps <= 0: run to the bound. Returns the StepError status. */
+int orc_double_solve(int n, const double *pos, const double *vel, const double *mu, double t0, double bound, double h,
+                     const char *method, int64_t max_steps, double *out_y, double *out_dy, double *end_time);
+/* convergence::<M>(problem, h0) :218-296: the largest h of the doubling sweep whose 1-year error vs the h0/2 run
+ * stays within 10 m / 1 m/s. rows: max_rows x {h [s], position error [m], velocity error [m/s]}. */
+double orc_convergence(int n, const double *pos, const double *vel, const double *mu, double t0, double bound,
+                       const char *method, double h0, int max_rows, double *rows, int *nrows, int *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,8 @@ def lib(native=False):
     if native in _libs:
         return _libs[native]
     path = HERE / ("libeph_oracle_native.so" if native else "libeph_oracle.so")
-    if not path.exists() or path.stat().st_mtime < (HERE / "eph_oracle.c").stat().st_mtime:
+    srcs = ("eph_oracle.c", "eph_oracle.h", "convergence_double.inc", "coeff_tables.inc", "cr_pow_tables.inc")
+    if not path.exists() or path.stat().st_mtime < max((HERE / f).stat().st_mtime for f in srcs):
         build(native)
     L = C.CDLL(str(path))
     vp = C.c_void_p
@@ -54,6 +55,11 @@ def lib(native=False):
     L.orc_newtonian_gravity_eval.argtypes = [C.c_int, _dp, _dp, _dp]
     L.orc_newtonian_gravity_eval.restype = None
     L.orc_pair_counter.restype = C.c_uint64
+    L.orc_double_solve.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_int64,
+                                   _dp, _dp, _dp]
+    L.orc_convergence.restype = C.c_double
+    L.orc_convergence.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_char_p, C.c_double, C.c_int, _dp,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_nbody_new.restype = vp
     L.orc_nbody_new.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_char_p]
     L.orc_nbody_clone.restype = vp
@@ -330,6 +336,30 @@ def poly_eval_and_deriv(coeffs, ncoef, tau):
     v, d = np.zeros(3), np.zeros(3)
     lib().orc_poly_eval_and_deriv(int(ncoef), _ptr(coeffs), float(tau), _ptr(v), _ptr(d))
     return v, d
+
+
+def double_solve(pos, vel, mu, t0, bound, h, method, max_steps=0, native=False):
+    """The reference's convergence-test integrator (generic steppers on Double<DVec3>,
+    ephemeris/tests/solar_system_convergence.rs:12-216). -> (status, y[n,3,2], dy[n,3,2], end_time); [..., 0] = value,
+    [..., 1] = error."""
+    pos, vel, mu = _f64(pos), _f64(vel), _f64(mu)
+    n = len(mu)
+    y, dy, end = np.zeros((n, 3, 2)), np.zeros((n, 3, 2)), np.zeros(1)
+    st = lib(native).orc_double_solve(n, _ptr(pos), _ptr(vel), _ptr(mu), t0, bound, h, method.encode(), int(max_steps),
+                                      _ptr(y), _ptr(dy), _ptr(end))
+    return st, y, dy, float(end[0])
+
+
+def convergence(pos, vel, mu, t0, bound, method, h0=75.0, native=False):
+    """convergence::<M>(problem, h0) of solar_system_convergence.rs:218-296 -> (converged h [s], rows of
+    (h, position error [m], velocity error [m/s]))."""
+    pos, vel, mu = _f64(pos), _f64(vel), _f64(mu)
+    rows, nrows, status = np.zeros((32, 3)), C.c_int(), C.c_int()
+    h = lib(native).orc_convergence(len(mu), _ptr(pos), _ptr(vel), _ptr(mu), t0, bound, method.encode(), h0, 32,
+                                    _ptr(rows), C.byref(nrows), C.byref(status))
+    if status.value:
+        raise RuntimeError(f"StepError {status.value}")
+    return h, rows[:nrows.value].copy()
 
 
 def set_pair_variant(variant, native=False):

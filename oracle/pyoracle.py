@@ -174,6 +174,63 @@ class LinearMultistep2:
         self.lm_i += 1
 
 
+class Double:
+    """Double<T> of the reference's convergence test (ephemeris/tests/solar_system_convergence.rs:12-110): a value
+    with a running error term; Add/Sub are compensated (two_sum + fast_two_sum), Mul/Div by f64 act on both parts.
+    One instance per DVec3 component (every operator the steppers use is component-wise)."""
+
+    __slots__ = ("value", "error")
+
+    def __init__(self, value, error=0.0):
+        self.value, self.error = value, error
+
+    @staticmethod
+    def two_sum(a, b):            # :30-40
+        value = a + b
+        v = value - a
+        return value, (a - (value - v)) + (b - v)
+
+    @staticmethod
+    def fast_two_sum(a, b):       # :50-59
+        value = a + b
+        return Double(value, b - (value - a))
+
+    def __add__(self, o):         # :62-73
+        sv, se = Double.two_sum(self.value, o.value)
+        return Double.fast_two_sum(sv, (se + self.error) + o.error)
+
+    def __sub__(self, o):         # :75-86 (two_sub(a, b) = two_sum(a, -b) :42-48)
+        sv, se = Double.two_sum(self.value, -o.value)
+        return Double.fast_two_sum(sv, (se + self.error) - o.error)
+
+    def __mul__(self, r):         # :88-98
+        return Double(self.value * r, self.error * r)
+
+    def __truediv__(self, r):     # :100-110
+        return Double(self.value / r, self.error / r)
+
+
+class DoubleProblem:
+    """NBodyProblem<Vec<Double<DVec3>>> + the test's NewtonianGravity (solar_system_convergence.rs:112-216): the force
+    reads `.value` and accumulates into `.value`; error parts of the accelerations stay zero."""
+
+    def __init__(self, pos, vel, mu, t0):
+        self.y = [Vec(*(Double(float(c)) for c in r)) for r in pos]
+        self.dy = [Vec(*(Double(float(c)) for c in r)) for r in vel]
+        self.mu = [float(m) for m in mu]
+        self.time = float(t0)
+        self.evals = 0
+
+    @staticmethod
+    def num(v):
+        return Double(float(v))
+
+    def eval(self, y):
+        self.evals += 1
+        vals = [Vec(c[0].value, c[1].value, c[2].value) for c in y]
+        return [Vec(Double(a[0]), Double(a[1]), Double(a[2])) for a in gravity(vals, self.mu, 0.0)]
+
+
 def horner(coeffs, t, zero):
     r = zero
     for c in reversed(coeffs):

@@ -71,8 +71,10 @@ def test_qt12_state_bitwise(gpu, name, steps, sign, path):
     assert g.eval_count() == o.eval_count()
 
 
-@pytest.mark.parametrize("method", ["Stormer13", "BlanesMoan6B", "BlanesMoan14A", "McLachlanO4", "Ruth"])
+@pytest.mark.parametrize("method", ["Stormer13", "BlanesMoan6B", "BlanesMoan11B", "BlanesMoan14A", "ForestRuth",
+                                    "McLachlanO4", "McLachlanSS17", "Pefrl", "Ruth"])
 def test_other_methods_bitwise(gpu, method):
+    """Both ELM2 tables and every SRKN table the reference defines (methods.rs) as the integrator."""
     s = load_system("simple_solar_system_2433282.5")
     g = gpu.NBodyIntegration(s.pos, s.vel, s.mu, s.epoch, 3600.0, method)
     o = orc.NBody(s.pos, s.vel, s.mu, s.epoch, 3600.0, method)
