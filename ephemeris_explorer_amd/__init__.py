@@ -18,9 +18,15 @@ import numpy as np
 from . import systems  # noqa: F401  (state.json / ephemeris.json / ships readers)
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libephemeris_amd.so"
+import os as _os
+
+# EPH_AMD_PAIR_VARIANT=k (1..3) loads libephemeris_amd_pv<k>.so: the same library built with another evaluation order
+# of the (unpinned) point-mass term -- csrc/device_math.h. Default: the product library.
+_PV = int(_os.environ.get("EPH_AMD_PAIR_VARIANT", "0") or 0)
+LIB_PATH = _HERE / ("libephemeris_amd.so" if _PV == 0 else f"libephemeris_amd_pv{_PV}.so")
 
 FORWARD, BACKWARD = 1, -1
+PATH_FAST = 4
 
 OK = 0
 STEP_SIZE_UNDERFLOW, MAX_ITERATIONS_REACHED, BOUND_REACHED, EVAL_FAILED, SOLOUT_EXIT = 1, 2, 3, 4, 5
@@ -30,7 +36,7 @@ ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = -
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
 
 ABI_SYMBOLS = [
-    "eph_abi_version", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
+    "eph_abi_version", "eph_pair_variant", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
     "eph_device_name", "eph_srkn_coeffs", "eph_elm2_coeffs", "eph_accel_eval",
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
@@ -100,6 +106,9 @@ def _lib():
     L = C.CDLL(str(LIB_PATH))
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.eph_abi_version.restype = i32
+    L.eph_pair_variant.restype = i32
+    if L.eph_pair_variant() != _PV:
+        raise ImportError(f"{LIB_PATH} was built with EPH_PAIR_VARIANT={L.eph_pair_variant()}, expected {_PV}")
     L.eph_status_string.restype = C.c_char_p
     L.eph_status_string.argtypes = [i32]
     L.eph_last_error.restype = C.c_char_p
@@ -324,6 +333,8 @@ class NBodyIntegration:
         _check(self._L.eph_nbody_set_bound(self._h, float(b)), "eph_nbody_set_bound")
 
     def set_path(self, path):
+        """0 auto | 1 wave kernel | 2 single workgroup | 3 workgroup kernel (all bit-identical to the reference order) |
+        PATH_FAST = 4: opt-in slice-parallel sums, NOT the reference's summation order (include/ephemeris_amd.h)."""
         _check(self._L.eph_nbody_set_path(self._h, int(path)), "eph_nbody_set_path")
 
     def enable_timing(self, on=True):

@@ -22,21 +22,31 @@ def hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not LIB.exists():
+def lib_path(pair_variant=0):
+    return LIB if pair_variant == 0 else HERE / f"libephemeris_amd_pv{pair_variant}.so"
+
+
+def needs_build(pair_variant=0):
+    lib = lib_path(pair_variant)
+    if not lib.exists():
         return True
-    t = LIB.stat().st_mtime
+    t = lib.stat().st_mtime
     return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS) or Path(__file__).stat().st_mtime > t
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, pair_variant=0):
+    """pair_variant 0 = the product library; 1..3 = the same sources with -DEPH_PAIR_VARIANT=k (another evaluation
+    order of the point-mass term whose reference source is absent, csrc/device_math.h) -> libephemeris_amd_pv<k>.so."""
+    LIB = lib_path(pair_variant)
+    if not force and not needs_build(pair_variant):
         return LIB
     objs = []
     procs = []
+    suffix = "" if pair_variant == 0 else f".pv{pair_variant}"
+    flags = FLAGS + ([] if pair_variant == 0 else [f"-DEPH_PAIR_VARIANT={pair_variant}"])
     for src in SOURCES:
-        obj = CSRC / (src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+        obj = CSRC / (src.rsplit(".", 1)[0] + suffix + ".o")
+        cmd = [hipcc(), *flags, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -52,5 +62,16 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_all(force=False, verbose=False):
+    """The product library and the three pair-variant builds, compiled concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(4) as ex:
+        return list(ex.map(lambda k: build(force, verbose, k), range(4)))
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    pv = int(sys.argv[sys.argv.index("--pair-variant") + 1]) if "--pair-variant" in sys.argv else 0
+    if "--all" in sys.argv:
+        print(build_all(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, pair_variant=pv))

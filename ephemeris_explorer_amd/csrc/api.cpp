@@ -50,6 +50,7 @@ struct eph_prop {
 extern "C" {
 
 int32_t eph_abi_version(void) { return EPH_ABI_VERSION; }
+int32_t eph_pair_variant(void) { return EPH_PAIR_VARIANT; }
 
 const char *eph_status_string(int32_t st) {
     switch (st) {
@@ -183,7 +184,7 @@ int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count) {
     return EPH_OK;
 }
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path) {
-    if (!h || !h->p || path < 0 || path > 3) return EPH_ERR_BAD_ARGUMENT;
+    if (!h || !h->p || path < 0 || path > EPH_PATH_FAST) return EPH_ERR_BAD_ARGUMENT;
     h->p->set_path(path);
     return EPH_OK;
 }

@@ -43,11 +43,36 @@ __device__ __forceinline__ double rcp_inrange(double p) {
 
 // THE point-mass kernel of the path, 1 / r^3 from n2 = |d|^2, in the one place it is defined for every kernel
 // (force kernels, k_lm_small, the spacecraft sweeps). It restates `particular`'s acceleration_paired /
-// acceleration_at (source absent): inv = 1 / (n2 * sqrt(n2)), IEEE sqrt, multiply, divide. If the
-// crate's order turns out to differ, change these two functions and the same-named function of the CPU restatement
-// the tests check against together.
-__device__ __forceinline__ double inv_r3_inrange(double n2) { return rcp_inrange(n2 * sqrt_inrange(n2)); }
-__device__ __forceinline__ double inv_r3_ieee(double n2) { return 1.0 / (n2 * sqrt(n2)); }
+// acceleration_at, whose source (git rev d490707a) is not on disk -- DESIGN.md §2: "parity unpinned" at this one
+// boundary. The evaluation order is therefore a BUILD FLAG, not an edit: -DEPH_PAIR_VARIANT=k selects
+//     0 (default, the published crate's form)   inv = 1 / (n2 * sqrt(n2))
+//     1                                         r = sqrt(n2) ; inv = 1 / (r * r * r)
+//     2                                         s = 1 / sqrt(n2) ; inv = s * s * s
+//     3                                         inv = (1 / n2) * (1 / sqrt(n2))
+// with IEEE sqrt / divide in every form (the CPU restatement the tests check against has the same four). `python -m ephemeris_explorer_amd.build --pair-variant k` builds
+// libephemeris_amd_pv<k>.so; tests/test_gpu_variants.py checks each against the oracle in the same variant.
+// Only variant 0 has the hand-interleaved tile pipeline of wave_force (kernels.hip pair_stage); the others run
+// the same kernels with the compiler's schedule.
+#ifndef EPH_PAIR_VARIANT
+#define EPH_PAIR_VARIANT 0
+#endif
+static_assert(EPH_PAIR_VARIANT >= 0 && EPH_PAIR_VARIANT <= 3, "EPH_PAIR_VARIANT must be 0..3");
+constexpr int kPairVariant = EPH_PAIR_VARIANT;
+// in_range(n2) keeps every intermediate of every variant inside the exponent range where the stripped sequences
+// equal the compiler's IEEE expansions: n2 in [2^-300, 2^300) => sqrt in [2^-150, 2^150), products and reciprocals
+// within [2^-450, 2^450].
+__device__ __forceinline__ double inv_r3_inrange(double n2) {
+    if constexpr (kPairVariant == 1) { const double r = sqrt_inrange(n2); return rcp_inrange(r * r * r); }
+    else if constexpr (kPairVariant == 2) { const double s = rcp_inrange(sqrt_inrange(n2)); return s * s * s; }
+    else if constexpr (kPairVariant == 3) return rcp_inrange(n2) * rcp_inrange(sqrt_inrange(n2));
+    else return rcp_inrange(n2 * sqrt_inrange(n2));
+}
+__device__ __forceinline__ double inv_r3_ieee(double n2) {
+    if constexpr (kPairVariant == 1) { const double r = sqrt(n2); return 1.0 / (r * r * r); }
+    else if constexpr (kPairVariant == 2) { const double s = 1.0 / sqrt(n2); return s * s * s; }
+    else if constexpr (kPairVariant == 3) return (1.0 / n2) * (1.0 / sqrt(n2));
+    else return 1.0 / (n2 * sqrt(n2));
+}
 
 // a / b, IEEE correctly rounded, with the reciprocal refinement shared between numerators: the compiler's f64
 // division is  r = rcp(b) + two Newton steps;  q = a*r;  e = fma(-b, q, a);  q = fma(e, r, q)  inside the scaling

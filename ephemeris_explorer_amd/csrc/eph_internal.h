@@ -17,6 +17,11 @@
 
 #include "../../include/ephemeris_amd.h"
 
+// evaluation order of the point-mass term (device_math.h); a build flag, see eph_pair_variant()
+#ifndef EPH_PAIR_VARIANT
+#define EPH_PAIR_VARIANT 0
+#endif
+
 namespace eph {
 
 constexpr int kMaxOrder = 16;   // ELM2 orders: 12 (QT12), 13 (Stormer13)
@@ -97,7 +102,10 @@ int launch_kick_drift(hipStream_t s, int n, int npad, const double *a, double *v
                       const double *mu, Body4 *pos_out);
 int launch_lm_predict(hipStream_t s, const LmArgs &a);              // y_{m+1} from the ring (no force)
 int launch_lm_step(hipStream_t s, const LmArgs &a);                 // one fused step, all CUs
-int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps);  // n <= 64: nsteps steps, one workgroup
+int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps);
+// opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
+int fast_slices(int npad);                                          // S
+int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial /*[S][3][npad]*/, unsigned *ticket /*[npad/64], zeroed*/);  // n <= 64: nsteps steps, one workgroup
 int lm_bodies_per_wave(int n);
 int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step);
 // carry: samples [src[b], src[b]+cnt[b]) of body b's region move to its front (src[b] == 0: nothing to do)

@@ -95,6 +95,7 @@ public:
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
     void set_path(int p) { path_ = p; }
+    int path() const { return path_; }
     // path 1 -> per-step launches with the one-wave-per-block force, 3 -> with the workgroup-specialised force
     int force_kind() const { return path_ == 1 ? 1 : (path_ == 3 ? 2 : 0); }
     void set_sampling(const SampleArgs &s) { samp_ = s; }   // consumed by the next advance() batch
@@ -154,6 +155,8 @@ private:
     SampleArgs samp_{};
     DevBuf<Body4> P_[2];
     DevBuf<double> Y_, A_, V_, ASR_, mu_, stage_;
+    DevBuf<double> fast_partial_;             // EPH_PATH_FAST scratch: [S][3][npad] partial sums
+    DevBuf<unsigned> fast_ticket_;            // and one arrival counter per 64-body block
 };
 
 // Polynomial<DVec3> (SmallVec<[DVec3; 8]>)   ephemeris/src/trajectory.rs:337-396

@@ -4,6 +4,7 @@
 // operation order and must stay un-fused.
 //
 // Reference citations are relative to the reference repository root.
+#include <algorithm>
 #include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
@@ -344,12 +345,16 @@ __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double i
             unsigned worst = 0u;
 #pragma unroll
             for (int b = 0; b < BPW; ++b) worst = max(worst, range_key(w.pre[PH][b].n2));
-            if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
+            const bool all_in_range = __builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0;
+            if (kPairVariant == 0 && all_in_range) {        // the hand-interleaved stream restates variant 0 only
                 tile_step_fast<BPW, PH>(w, xi, yi, zi, row_cur, tile_nxt, lane);
             } else {                                        // an operand near the end of the exponent range
 #pragma unroll
                 for (int b = 0; b < BPW; ++b) {
-                    pair_finish<false>(w.pre[PH][b], w.mu[PH], w.c[3 * b], w.c[3 * b + 1], w.c[3 * b + 2]);
+                    if (kPairVariant != 0 && all_in_range)
+                        pair_finish<true>(w.pre[PH][b], w.mu[PH], w.c[3 * b], w.c[3 * b + 1], w.c[3 * b + 2]);
+                    else
+                        pair_finish<false>(w.pre[PH][b], w.mu[PH], w.c[3 * b], w.c[3 * b + 1], w.c[3 * b + 2]);
                     w.pre[PH ^ 1][b] = pair_pre(xi[b], yi[b], zi[b], w.src[PH]);
                 }
 #pragma unroll
@@ -700,6 +705,135 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
         const int nslot = (a.cur + L - 1) % L;
         a.Y[(size_t)nslot * lvl + off] = ynext;
         reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// OPT-IN FAST PATH (eph_nbody_set_path(.., EPH_PATH_FAST)): the same pair arithmetic (IEEE sqrt / divide, no
+// contraction), but NOT the reference's summation order -- SURVEY §7 "hard parts", north_star's "tile-parallel
+// partial sums". It exists to measure what bit-exactness costs; the default path stays the ordered one.
+//
+// Work split: lane = target body (a block of 64 consecutive bodies per wave), every lane of a wave works on the SAME
+// source body, fetched with scalar loads (s_load_dwordx8 through the constant address space: no LDS, no vector
+// loads, no transposition in the loop). The sources are cut into S slices; wave (block, slice) accumulates its
+// slice in source order into three registers per lane. A workgroup = 4 slices of one block (one wave per SIMD).
+// The S partial sums of a body are combined in slice order by whichever workgroup of the block finishes LAST
+// (a ticket counter per block), which then also does the Cowell velocity, the solout sample and the predictor
+// for its 64 bodies -- still one launch per step, and deterministic: the value never depends on arrival order.
+//   a_i = ((p_0 + p_1) + ... + p_{S-1}),  p_s = ((0 + c(i, j0)) + c(i, j0 + 1)) + ...   (j over slice s, j != i)
+// ------------------------------------------------------------------------------------------------------
+constexpr int kFastWaves = 4;                          // waves (= slices) per workgroup
+constexpr int kFastUnroll = 4;                         // sources per range check / loop trip
+constexpr int kFastMaxSlices = 64;
+
+template <bool DIAG>
+__device__ __forceinline__ void fast_slice(const __attribute__((address_space(4))) Body4 *src, int j0, int j1, int i,
+                                           double xi, double yi, double zi, double &ax, double &ay, double &az) {
+    auto fetch = [&](int j, Body4 (&p)[kFastUnroll]) {
+#pragma unroll
+        for (int u = 0; u < kFastUnroll; ++u) { p[u].x = src[j + u].x; p[u].y = src[j + u].y; p[u].z = src[j + u].z; p[u].mu = src[j + u].mu; }
+    };
+    Body4 nxt[kFastUnroll];
+    fetch(j0, nxt);
+    for (int j = j0; j < j1; j += kFastUnroll) {       // j1 - j0 is a multiple of kFastUnroll (padded sources: mu = 0)
+        Body4 pj[kFastUnroll];
+#pragma unroll
+        for (int u = 0; u < kFastUnroll; ++u) pj[u] = nxt[u];
+        fetch(min(j + kFastUnroll, j1 - kFastUnroll), nxt);   // next group's scalar loads in flight under this one's arithmetic
+        PairPre pre[kFastUnroll];
+        unsigned worst = 0u;
+#pragma unroll
+        for (int u = 0; u < kFastUnroll; ++u) {
+            pre[u] = pair_pre(xi, yi, zi, pj[u]);
+            worst = max(worst, range_key(pre[u].n2));
+        }
+        double c[3 * kFastUnroll];
+        if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
+#pragma unroll
+            for (int u = 0; u < kFastUnroll; ++u) pair_finish<true>(pre[u], pj[u].mu, c[3 * u], c[3 * u + 1], c[3 * u + 2]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kFastUnroll; ++u) pair_finish<false>(pre[u], pj[u].mu, c[3 * u], c[3 * u + 1], c[3 * u + 2]);
+        }
+#pragma unroll
+        for (int u = 0; u < kFastUnroll; ++u) {
+            if (DIAG && j + u == i) continue;          // the body itself (n2 = 0 -> NaN): not a source
+            ax = ax + c[3 * u];
+            ay = ay + c[3 * u + 1];
+            az = az + c[3 * u + 2];
+        }
+    }
+}
+
+// partial: [S][3][npad] scratch; ticket: [npad / 64] zero-initialised counters (left at zero on exit)
+template <int L>
+__global__ void __launch_bounds__(64 * kFastWaves) k_lm_step_fast(const LmArgs a, int S, int slice_len,
+                                                                  double *__restrict__ partial,
+                                                                  unsigned *__restrict__ ticket) {
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgs_per_block = S / kFastWaves;
+    const int block = blockIdx.x / wgs_per_block;
+    const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
+    const int i = block * 64 + lane;
+    const int ic = min(i, a.n - 1);
+    const size_t lvl = (size_t)3 * a.npad;
+
+    // history of the (component, body) item this thread would finish if its workgroup turns out to be the last one:
+    // issued now so the loads land under the pair loop
+    const int fc = tid >> 6, fb = block * 64 + lane;            // threads 0..191: component fc of body fb
+    const bool fin = tid < 192 && fb < a.n;
+    const size_t off = (size_t)(fin ? fc : 0) * a.npad + (fin ? fb : 0);
+    double yv[L], av[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int slot = (a.cur + j) % L;
+        yv[j] = a.Y[slot * lvl + off];
+        av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
+    }
+
+    const auto *src = (const __attribute__((address_space(4))) Body4 *)(unsigned long long)a.pos_cur;
+    const double xi = a.pos_cur[ic].x, yi = a.pos_cur[ic].y, zi = a.pos_cur[ic].z;
+    const int j0 = slice * slice_len, j1 = min(j0 + slice_len, a.npad);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (j0 < j1) {
+        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        else fast_slice<false>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+    }
+    double *pp = partial + (size_t)slice * lvl + i;
+    pp[0] = ax;
+    pp[(size_t)a.npad] = ay;
+    pp[(size_t)2 * a.npad] = az;
+
+    __threadfence();                                    // release this wave's partials (agent scope: other XCDs)
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&ticket[block], 1u) == (unsigned)(wgs_per_block - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                    // acquire the other workgroups' partials
+    if (tid == 0) ticket[block] = 0u;                   // ready for the next launch
+    if (!fin) return;
+    double anew = 0.0;
+    {
+        const double *q = partial + (size_t)fc * a.npad + fb;
+        for (int sl = 0; sl < S; ++sl) anew = anew + q[(size_t)sl * lvl];
+    }
+    a.A[(size_t)a.cur * lvl + off] = anew;
+    {
+        double prev[L];
+#pragma unroll
+        for (int j = 0; j < L - 1; ++j) prev[j] = av[j + 1];
+        prev[L - 1] = 0.0;
+        a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
+    }
+    maybe_sample(a.samp, fb, fc, a.step, yv[0]);
+    if (a.do_predict) {
+        av[0] = anew;
+        const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
+        const int nslot = (a.cur + L - 1) % L;
+        a.Y[(size_t)nslot * lvl + off] = ynext;
+        reinterpret_cast<double *>(a.pos_next + fb)[fc] = ynext;
     }
 }
 
@@ -1278,6 +1412,25 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
     if (a.L == 12) return launch_lm_step_L<12>(s, a);
     if (a.L == 13) return launch_lm_step_L<13>(s, a);
     return EPH_ERR_UNSUPPORTED;
+}
+// slices of the fast path: enough waves for two per SIMD (2048), a multiple of the workgroup's 4, at most 64
+int fast_slices(int npad) {
+    static const int forced = [] { const char *e = getenv("EPH_FAST_SLICES"); return e ? atoi(e) : 0; }();
+    int S = forced > 0 ? forced : 2048 / (npad / 64);
+    S = std::max(kFastWaves, std::min(kFastMaxSlices, S));
+    return (S + kFastWaves - 1) / kFastWaves * kFastWaves;
+}
+int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, unsigned *ticket) {
+    if (a.n <= 0) return EPH_OK;
+    if (a.lo != 0 || a.hi != a.n) return EPH_ERR_UNSUPPORTED;          // the fast path is not sharded
+    const int S = fast_slices(a.npad);
+    int slice_len = (a.npad + S - 1) / S;
+    slice_len = (slice_len + kFastUnroll - 1) / kFastUnroll * kFastUnroll;
+    const dim3 grid((unsigned)(a.npad / 64 * (S / kFastWaves))), block(64 * kFastWaves);
+    if (a.L == 12) hipLaunchKernelGGL(k_lm_step_fast<12>, grid, block, 0, s, a, S, slice_len, partial, ticket);
+    else if (a.L == 13) hipLaunchKernelGGL(k_lm_step_fast<13>, grid, block, 0, s, a, S, slice_len, partial, ticket);
+    else return EPH_ERR_UNSUPPORTED;
+    return done("k_lm_step_fast");
 }
 int launch_lm_predict(hipStream_t s, const LmArgs &a) {
     if (a.n <= 0 || a.hi <= a.lo) return EPH_OK;

@@ -225,7 +225,14 @@ int NBodyIntegration::lm_batch(int64_t k) {
     a.samp = samp_;
     a.kind = force_kind();
     int st;
-    const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3;
+    const bool fast = path_ == EPH_PATH_FAST;
+    if (fast && (n_ <= kSmallN || sharded())) return EPH_ERR_UNSUPPORTED;
+    if (fast && !fast_partial_.p) {
+        if ((st = fast_partial_.alloc((size_t)fast_slices(npad_) * 3 * npad_)) || (st = fast_ticket_.alloc(npad_ / 64)))
+            return st;
+        EPH_HIP(hipMemsetAsync(fast_ticket_.p, 0, sizeof(unsigned) * (npad_ / 64), stream_));
+    }
+    const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3 && !fast;
     if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
     if (timing_) EPH_HIP(hipEventRecord(ev0_, stream_));
     if (persistent) {
@@ -249,7 +256,8 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.pos_next = P_[pp_ ^ 1].p;
             a.do_predict = s < k;
             a.step = (uint32_t)s;
-            if ((st = launch_lm_step(stream_, a))) return st;
+            if ((st = fast ? launch_lm_step_fast(stream_, a, fast_partial_.p, fast_ticket_.p) : launch_lm_step(stream_, a)))
+                return st;
             if (a.do_predict && (st = gather_packed(a.pos_next))) return st;
         }
         if (timing_) kernel_launches_ += (uint64_t)k;

@@ -50,6 +50,12 @@ typedef enum eph_status {
 #define EPH_BACKWARD (-1)
 
 int32_t eph_abi_version(void);
+/* Which evaluation order of the point-mass term 1/r^3 this library was built with (-DEPH_PAIR_VARIANT=k, 0..3;
+ * csrc/device_math.h). Stands in for `particular::gravity::newtonian::AccelerationPaired::acceleration_paired`
+ * (crate `particular` 0.8.0-dev @ d490707a, Cargo.lock:4277-4285; call sites ephemeris/src/propagators/nbody.rs:29,
+ * ephemeris_explorer/src/dynamics/spacecraft.rs:73), whose source is not in the reference tree: 0 = the published
+ * crate's form 1/(n2*sqrt(n2)), the default build. */
+int32_t eph_pair_variant(void);
 const char *eph_status_string(int32_t status);
 /* text of the last HIP error seen by the calling thread ("" if none) */
 const char *eph_last_error(void);
@@ -94,7 +100,12 @@ void eph_nbody_destroy(eph_nbody *h);
 int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count);
 /* Which device path `advance` uses: 0 = auto, 1 = one launch per step with the one-wave-per-block force kernel,
  * 2 = persistent single workgroup (n <= 64 only), 3 = one launch per step with the workgroup-specialised force
- * kernel. All paths produce identical bits; for tests and tuning. */
+ * kernel. Paths 0-3 produce identical bits (the reference's summation order); for tests and tuning.
+ * 4 = EPH_PATH_FAST, OPT-IN: steady multistep steps with slice-parallel partial sums combined in slice order -- the
+ * same pair arithmetic but NOT the summation order of NewtonianGravity::eval (nbody.rs:22-38), so results differ from
+ * the reference in the last bits of every acceleration (deterministic run to run). Unsharded systems of more than
+ * 64 bodies; start-up steps and SRKN methods keep the ordered kernels. DESIGN.md "what bit-exactness costs". */
+#define EPH_PATH_FAST 4
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path);
 /* device time of the steady-state kernels launched by this handle so far, measured with HIP events on the
  * handle's stream: total milliseconds and launch count (used by bench.py for the roofline figure) */

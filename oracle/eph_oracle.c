@@ -1287,7 +1287,7 @@ static int craft_rhs(void *ctx, double t, const double *y, double *dy) {
         const v3 bp = poly_eval(p, tau);
         const v3 d = v3_sub(bp, pos);
         const double n2 = v3_dot(d, d);
-        const double inv = 1.0 / (n2 * sqrt(n2));
+        const double inv = inv_r3(n2);                 /* acceleration_at::<false>: same crate routine as the pairs */
         acc = v3_add(acc, v3_scale(d, c->mu[b] * inv));
     }
     /* manoeuvre_acceleration: Segment::acceleration  spacecraft.rs:102-116,272-281 */

@@ -1,0 +1,86 @@
+"""-m gpu: the OPT-IN fast path (eph_nbody_set_path(h, EPH_PATH_FAST)): slice-parallel partial sums combined in slice
+order instead of the reference's ordered chain. It is NOT bit-identical to the reference and is never the default;
+these tests pin what it does promise: determinism, and closeness to the ordered path at the level of summation
+round-off. The measured divergence over 1e5 steps is reported by bench.py --path fast."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+H = 1.0 / 1024.0
+FAST = 4
+
+
+@pytest.mark.parametrize("n", [100, 1000, 4096, 5000])
+def test_fast_path_is_deterministic_and_close_to_the_ordered_path(gpu, n):
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(n)
+    exact = gpu.NBodyIntegration(pos, vel, mu, 0.0, H)
+    runs = []
+    for _ in range(2):
+        g = gpu.NBodyIntegration(pos, vel, mu, 0.0, H)
+        g.set_path(FAST)
+        g.advance(12 + 40)
+        runs.append((g.state(), g.acc()))
+    exact.advance(12 + 40)
+    (p0, v0, t0, c0), a0 = runs[0]
+    (p1, v1, t1, c1), a1 = runs[1]
+    assert (t0, c0) == (t1, c1) == exact.state()[2:]
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1) and np.array_equal(a0, a1)   # run-to-run identical
+    pe, ve = exact.state()[:2]
+    ae = exact.acc()
+    # same pair arithmetic, different summation order: accelerations agree to summation round-off
+    scale = np.abs(ae).max()
+    assert np.abs(a0 - ae).max() < 1e-11 * scale
+    assert 0.0 < np.abs(p0 - pe).max() < 1e-11                # 40 steps: round-off level, but NOT identical
+    assert np.abs(v0 - ve).max() < 1e-10
+
+
+def test_fast_path_refuses_what_it_does_not_cover(gpu):
+    from conftest import load_system
+    s = load_system("full_solar_system_2433282.5")
+    g = gpu.NBodyIntegration(s.pos, s.vel, s.mu, s.epoch, s.dt)
+    g.set_path(FAST)
+    g.advance(12)                                             # start-up runs the ordered kernels
+    with pytest.raises(gpu.EphemerisError):                   # 32 bodies: one workgroup, nothing to slice
+        g.advance(1)
+    with pytest.raises(gpu.EphemerisError):
+        g.set_path(5)
+
+
+def test_fast_path_with_solout_sampling(gpu):
+    """The fused step still samples for the solout: the propagator on the fast path produces splines that agree with the
+    ordered path's to round-off."""
+    from ephemeris_explorer_amd.workloads import plummer
+    n = 256
+    pos, vel, mu = plummer(n)
+    count = np.full(n, 2, np.uint32)
+    degree = np.full(n, 6, np.uint32)
+    a = gpu.NBodyPropagator(pos, vel, mu, 0.0, H, gpu.FORWARD, count, degree)
+    b = gpu.NBodyPropagator(pos, vel, mu, 0.0, H, gpu.FORWARD, count, degree)
+    b.integration().set_path(FAST)
+    sa, sb = a.propagate(200 * H), b.propagate(200 * H)
+    for body in (0, 100, 255):
+        assert sa.info(body) == sb.info(body)
+        ca, cb = sa.coeffs(body)[0], sb.coeffs(body)[0]
+        assert np.abs(ca - cb).max() < 1e-9 and not np.array_equal(ca, cb)
+
+
+def test_fast_path_divergence_at_the_metric_size(gpu):
+    """N = 4096, 1000 steps against the oracle's committed positions (tests/golden/plummer4096_horizon.npz): the
+    figure bench.py --path fast reports for 10^k steps up to 1e5, here bounded for the first three checkpoints."""
+    from ephemeris_explorer_amd.workloads import plummer
+    fx = np.load(GOLDEN / "plummer4096_horizon.npz")
+    pos, vel, mu = plummer(4096)
+    g = gpu.NBodyIntegration(pos, vel, mu, 0.0, H)
+    g.set_path(FAST)
+    done = 0
+    for c, bound in ((10, 0.0), (100, 1e-12), (1000, 1e-9)):
+        g.advance(c - done)
+        done = c
+        d = np.abs(g.state()[0] - fx[f"pos_{c}"]).max()
+        if c == 10:
+            assert d == 0.0                                   # still inside the (ordered) start-up
+        else:
+            assert 0.0 < d < bound, (c, d)

@@ -1,0 +1,99 @@
+"""-m gpu: the point-mass evaluation order as a build flag (csrc/device_math.h, -DEPH_PAIR_VARIANT=k).
+
+The reference takes 1/r^3 from the crate `particular` (0.8.0-dev @ d490707a), whose source is not in its tree; the
+product's default build restates the published crate's form (variant 0). Should the pinned revision evaluate it in
+another order, the fix is a rebuild with a flag, and this test shows each alternative build is bit-identical to the
+CPU restatement switched to the same order (orc.set_pair_variant) on every kernel family that evaluates the term:
+k_accel (wave and workgroup forms), the fused multistep kernels, the single-workgroup kernel and the spacecraft sweep.
+Each variant runs in its own process: the library is chosen at import (EPH_AMD_PAIR_VARIANT)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+k = int(sys.argv[2])
+import ephemeris_explorer_amd as ea
+from ephemeris_explorer_amd.systems import load_system, load_ship
+from ephemeris_explorer_amd.workloads import plummer
+from oracle import orc
+assert ea._lib().eph_pair_variant() == k
+orc.set_pair_variant(k)
+orc.set_pair_variant(k, native=True)
+same = lambda a, b: np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+root = sys.argv[1] + "/tests/golden/systems/"
+# seam 1 at the sizes of the three force kernels
+rng = np.random.default_rng(k)
+for n in (40, 1000, 4096):
+    pos, mu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
+    assert same(ea.accel_eval(pos, mu), orc.gravity(pos, mu)), ("accel", n)
+# the variant differs from variant 0 somewhere (the flag does something)
+orc.set_pair_variant(0)
+base = orc.gravity(pos, mu)
+orc.set_pair_variant(k)
+assert not same(base, orc.gravity(pos, mu))
+# single-workgroup multistep kernel + solout (32 bodies), per-step kernels (300 and 4096 bodies)
+s = load_system(root + "full_solar_system_2433282.5")
+g = ea.NBodyPropagator.from_system(s)
+o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+g.step_n(400)
+for _ in range(400):
+    assert o.step() == 0
+assert same(g.state()[0], o.state()[0]) and same(g.state()[1], o.state()[1]), "k_lm_small"
+sg, so = g.take_solution(), o.take_solution()
+for b in range(s.n):
+    assert sg.info(b) == so.info(b) and same(sg.coeffs(b)[0], so.coeffs(b)[0]), ("spline", b)
+orc.set_gravity_threads(8, native=True)
+for n, steps in ((300, 12 + 20), (4096, 12 + 3)):
+    pos, vel, mu = plummer(n)
+    g2 = ea.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
+    o2 = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0, native=True)
+    g2.advance(steps)
+    assert o2.advance(steps) == 0
+    assert same(g2.state()[0], o2.state()[0]) and same(g2.state()[1], o2.state()[1]), ("k_lm_step", n)
+# the spacecraft sweep (thread-per-craft and wave-per-craft kernels)
+ship = load_ship(root + "full_solar_system_2433282.5/ships/Mars Transfer Ship.json")
+g.step_to(ship.start + 2 * 86400.0)
+assert o.step_to(ship.start + 2 * 86400.0) == 0
+sg2, so2 = g.take_solution(), o.take_solution()
+sg.append(sg2)
+assert so.append(so2)
+eph = ea.Ephemeris(sg, s.mu)
+for ncraft in (2, 20000):
+    pos = np.repeat(ship.pos[None], ncraft, 0) + np.arange(ncraft)[:, None] * 1e-2
+    vel = np.repeat(ship.vel[None], ncraft, 0)
+    batch = ea.SpacecraftBatch(eph, ship.start, pos, vel, "Verner87", max_knots=256)
+    batch.propagate(ship.start + 3 * 3600.0)
+    assert (batch.status()["status"] == 0).all()
+    for i in (0, ncraft - 1):
+        c = orc.Craft(so, s.mu, ship.start, pos[i], vel[i], "Verner87")
+        assert c.step_to(ship.start + 3 * 3600.0) == 0
+        kt, kp, kv = batch.knots(i)
+        ot, op, ov = c.knots()
+        assert same(kt, ot) and same(kp, op) and same(kv, ov), ("craft", ncraft, i)
+print("variant", k, "ok")
+'''
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_pair_variant_build_matches_oracle_variant(gpu, variant):
+    from ephemeris_explorer_amd import build as b
+    lib = b.build(pair_variant=variant)
+    assert lib.exists()
+    env = dict(os.environ, EPH_AMD_PAIR_VARIANT=str(variant))
+    r = subprocess.run([sys.executable, "-c", SCRIPT, str(ROOT), str(variant)], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert f"variant {variant} ok" in r.stdout
+
+
+def test_default_build_is_variant_zero(gpu):
+    assert gpu._lib().eph_pair_variant() == 0
