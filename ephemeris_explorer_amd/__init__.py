@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
-    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_debug_pow", "eph_debug_div",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_debug_pow", "eph_debug_div",
 ]
 
 
@@ -185,6 +185,7 @@ def _lib():
     L.eph_craft_batch_destroy.argtypes = [vp]
     L.eph_craft_batch_destroy.restype = None
     L.eph_hermite_eval.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _u8p]
+    L.eph_hermite_join.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _i64p]
     L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
     L.eph_debug_div.argtypes = [i64, _dp, _dp, _dp, _dp]
     if L.eph_abi_version() != 1:
@@ -718,6 +719,19 @@ def hermite_eval(t, pos, vel, at, with_velocity=True):
     _check(_lib().eph_hermite_eval(len(t), _p(t), _p(pos), _p(vel), m, _p(at), _p(op), _p(ov) if with_velocity else None,
                                    _p(inside, _u8p)), "eph_hermite_eval")
     return op, (ov if with_velocity else None), inside.astype(bool)
+
+
+def hermite_join(lhs, rhs):
+    """SpacecraftPropagator::join(lhs, rhs) (ephemeris/src/propagators/spacecraft.rs:558-561) on (t, pos, vel) knot
+    arrays -> the joined (t, pos, vel). Host only."""
+    lt, lp, lv = _f64(lhs[0]).ravel(), _f64(lhs[1]).reshape(-1, 3), _f64(lhs[2]).reshape(-1, 3)
+    rt, rp, rv = _f64(rhs[0]).ravel(), _f64(rhs[1]).reshape(-1, 3), _f64(rhs[2]).reshape(-1, 3)
+    cap = len(lt) + len(rt)
+    t, p, v = np.zeros(max(cap, 1)), np.zeros((max(cap, 1), 3)), np.zeros((max(cap, 1), 3))
+    n = C.c_int64()
+    _check(_lib().eph_hermite_join(len(lt), _p(lt), _p(lp), _p(lv), len(rt), _p(rt), _p(rp), _p(rv), cap, _p(t), _p(p),
+                                   _p(v), C.byref(n)), "eph_hermite_join")
+    return t[:n.value].copy(), p[:n.value].copy(), v[:n.value].copy()
 
 
 def debug_div(a, b):

@@ -457,4 +457,32 @@ int32_t eph_debug_wg_cycles(int64_t *out8) {
     return debug_wg_cycles((long long *)out8);
 }
 
+// SpacecraftPropagator::join  spacecraft.rs:558-561 = CubicHermiteSpline::clear_after (trajectory.rs:842-845) + extend
+// (:847-849). Host only.
+int32_t eph_hermite_join(int64_t n_lhs, const double *t_lhs, const double *pos_lhs, const double *vel_lhs,
+                         int64_t n_rhs, const double *t_rhs, const double *pos_rhs, const double *vel_rhs,
+                         int64_t capacity, double *t_out, double *pos_out, double *vel_out, int64_t *n_out) {
+    if (n_lhs < 0 || n_rhs < 0 || capacity < 0 || !n_out || (n_lhs > 0 && (!t_lhs || !pos_lhs || !vel_lhs)) ||
+        (n_rhs > 0 && (!t_rhs || !pos_rhs || !vel_rhs)))
+        return EPH_ERR_BAD_ARGUMENT;
+    // rhs.start(): self.0.first().map(|i| i.0).unwrap_or(Epoch::MIN)   trajectory.rs:756-758
+    const double at = n_rhs > 0 ? t_rhs[0] : -1.7976931348623157e308;
+    int64_t keep = 0;
+    for (int64_t k = 0; k < n_lhs; ++k) keep += at > t_lhs[k] ? 1 : 0;        // retain(|(k, _)| &at > k)
+    *n_out = keep + n_rhs;
+    if (*n_out > capacity || (*n_out > 0 && (!t_out || !pos_out || !vel_out))) return EPH_ERR_BAD_ARGUMENT;
+    int64_t w = 0;
+    for (int64_t k = 0; k < n_lhs; ++k) {                                     // w <= k: in place on the lhs arrays is fine
+        if (!(at > t_lhs[k])) continue;
+        t_out[w] = t_lhs[k];
+        for (int c = 0; c < 3; ++c) { pos_out[3 * w + c] = pos_lhs[3 * k + c]; vel_out[3 * w + c] = vel_lhs[3 * k + c]; }
+        ++w;
+    }
+    for (int64_t k = 0; k < n_rhs; ++k, ++w) {                                // self.0.extend(rhs.0)
+        t_out[w] = t_rhs[k];
+        for (int c = 0; c < 3; ++c) { pos_out[3 * w + c] = pos_rhs[3 * k + c]; vel_out[3 * w + c] = vel_rhs[3 * k + c]; }
+    }
+    return EPH_OK;
+}
+
 }  // extern "C"

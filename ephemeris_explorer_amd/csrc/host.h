@@ -156,7 +156,6 @@ private:
     DevBuf<Body4> P_[2];
     DevBuf<double> Y_, A_, V_, ASR_, mu_, stage_;
     DevBuf<double> fast_partial_;             // EPH_PATH_FAST scratch: [S][3][npad] partial sums
-    DevBuf<unsigned> fast_ticket_;            // and one arrival counter per 64-body block
 };
 
 // Polynomial<DVec3> (SmallVec<[DVec3; 8]>)   ephemeris/src/trajectory.rs:337-396

@@ -511,8 +511,13 @@ __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
 // which therefore gets fewer bodies; the hardware interleaves the two and the adds' bubbles get filled.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kWgBodies = 16;
-constexpr int kWgPairWaves = 4;
-constexpr int kWgThreads = 64 * (kWgPairWaves + 1);  // + 1 chain wave (wave 4: lands on the SIMD of wave 0)
+constexpr int kWgPairWaves = 4;                      // index of the chain wave (wave 4: lands on the SIMD of wave 0)
+// Role layouts (waves of a workgroup go to the four SIMDs round-robin: wave k -> SIMD k % 4):
+//   0: 5 waves  -- pair waves of 2/5/5/4 bodies + the chain wave (one wave per SIMD, the chain shares SIMD 0)
+//   1: 8 waves  -- pair waves of 1/3/3/3 bodies, the chain wave, pair waves of 2/2/2 bodies: SIMDs 1-3 carry TWO pair
+//                  waves (5 bodies together) that fill each other's dependency stalls; SIMD 0 the chain + one body
+constexpr int wg_threads(int layout) { return layout == 1 ? 64 * 8 : 64 * 5; }
+constexpr int kWgDefaultLayout = 0;
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
 constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave
@@ -601,7 +606,7 @@ __device__ __forceinline__ double chain_full_pf(const double *row, const double 
 }
 
 // Returns on chain-wave lane ch < 48: component ch%3 of body i0 + ch/3. All 320 threads must call it.
-template <typename PosPtr>
+template <int LAYOUT, typename PosPtr>
 __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg = 0) {
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = (n + kTile - 1) / kTile;
@@ -610,14 +615,28 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
     // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
     // under the denser f64 stream and the step gets slower.)
-    switch (wave) {
-        case 0: wg_pair_wave<2>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
-        case 1: wg_pair_wave<5>(pos, n, i0, 2, C, lane, tiles, tdiag, dbg); return 0.0;
-        case 2: wg_pair_wave<5>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg); return 0.0;
-        case 3: wg_pair_wave<4>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
-        default: break;
+    if constexpr (LAYOUT == 1) {
+        switch (wave) {
+            case 0: wg_pair_wave<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 1: wg_pair_wave<3>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave<3>(pos, n, i0, 4, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave<3>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 5: wg_pair_wave<2>(pos, n, i0, 10, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 6: wg_pair_wave<2>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 7: wg_pair_wave<2>(pos, n, i0, 14, C, lane, tiles, tdiag, dbg); return 0.0;
+            default: break;
+        }
+    } else {
+        switch (wave) {
+            case 0: wg_pair_wave<2>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 1: wg_pair_wave<5>(pos, n, i0, 2, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave<5>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave<4>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+            default: break;
+        }
     }
-    // chain wave (raising its priority with s_setprio was measured: 4-5 us slower per evaluation)
+    if (dbg & 8) __builtin_amdgcn_s_setprio(3);        // tuning: chain wave ahead of the pair wave(s) on its SIMD
+    // chain wave (raising its priority with s_setprio was measured in layout 0: 4-5 us slower per evaluation)
     const int ch = lane < kWgRows ? lane : kWgRows - 1;
     const double *row = C + ch * kRow;
     const int gself = (i0 % kTile) / kWgBodies;
@@ -652,7 +671,8 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     return accL + acc;
 }
 
-__global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
+template <int LAYOUT>
+__global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
                                                          const double *__restrict__ acc_init,
                                                          double *__restrict__ acc_out, int dbg, int lo, int hi) {
     __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
@@ -661,13 +681,13 @@ __global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const 
     const int my_i = i0 + lane / 3, cc = lane % 3;
     const bool owner = (tid >> 6) == kWgPairWaves && lane < kWgRows && my_i < hi;
     const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
-    const double a = wg_force(pos, n, i0, init, C, tid, dbg);
+    const double a = wg_force<LAYOUT>(pos, n, i0, init, C, tid, dbg);
     if (owner) acc_out[cc * npad + my_i] = a;
 }
 
 // One launch per integrator step, workgroup-specialised force (see k_lm_step for the step structure).
-template <int L>
-__global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
+template <int L, int LAYOUT>
+__global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs a) {
     __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool chain_wave = (tid >> 6) == kWgPairWaves;
@@ -687,7 +707,7 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
             av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
         }
     }
-    const double anew = wg_force(a.pos_cur, a.n, i0, 0.0, C, tid);
+    const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
     if (!owner) return;
 
     a.A[(size_t)a.cur * lvl + off] = anew;
@@ -717,9 +737,9 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
 // source body, fetched with scalar loads (s_load_dwordx8 through the constant address space: no LDS, no vector
 // loads, no transposition in the loop). The sources are cut into S slices; wave (block, slice) accumulates its
 // slice in source order into three registers per lane. A workgroup = 4 slices of one block (one wave per SIMD).
-// The S partial sums of a body are combined in slice order by whichever workgroup of the block finishes LAST
-// (a ticket counter per block), which then also does the Cowell velocity, the solout sample and the predictor
-// for its 64 bodies -- still one launch per step, and deterministic: the value never depends on arrival order.
+// The S partial sums of a body are combined in slice order
+// by a second small launch (k_fast_finish), which also does the Cowell velocity, the solout sample and the
+// predictor -- deterministic: the value never depends on which wave finishes first.
 //   a_i = ((p_0 + p_1) + ... + p_{S-1}),  p_s = ((0 + c(i, j0)) + c(i, j0 + 1)) + ...   (j over slice s, j != i)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFastWaves = 4;                          // waves (= slices) per workgroup
@@ -765,26 +785,42 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
     }
 }
 
-// partial: [S][3][npad] scratch; ticket: [npad / 64] zero-initialised counters (left at zero on exit)
-template <int L>
-__global__ void __launch_bounds__(64 * kFastWaves) k_lm_step_fast(const LmArgs a, int S, int slice_len,
-                                                                  double *__restrict__ partial,
-                                                                  unsigned *__restrict__ ticket) {
-    __shared__ unsigned s_last;
+// partial: [S][3][npad] scratch. Two launches per step: the kernel boundary is the release/acquire between the
+// slice sums and their combination. (First version: one launch with a per-block arrival ticket, the last workgroup
+// of a block combining -- measured 66 / 96 / 166 us per step at 16 / 32 / 64 slices, N = 4096: the agent-scope
+// fence each workgroup needs before its ticket costs ~0.13 us and they serialise; gpurun_out r02a.)
+__global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npad, const Body4 *__restrict__ pos,
+                                                                  int S, int slice_len, double *__restrict__ partial) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wgs_per_block = S / kFastWaves;
     const int block = blockIdx.x / wgs_per_block;
     const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
     const int i = block * 64 + lane;
-    const int ic = min(i, a.n - 1);
-    const size_t lvl = (size_t)3 * a.npad;
+    const int ic = min(i, n - 1);
+    const auto *src = (const __attribute__((address_space(4))) Body4 *)(unsigned long long)pos;
+    const double xi = pos[ic].x, yi = pos[ic].y, zi = pos[ic].z;
+    const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (j0 < j1) {
+        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        else fast_slice<false>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+    }
+    double *pp = partial + (size_t)slice * 3 * npad + i;
+    pp[0] = ax;
+    pp[(size_t)npad] = ay;
+    pp[(size_t)2 * npad] = az;
+}
 
-    // history of the (component, body) item this thread would finish if its workgroup turns out to be the last one:
-    // issued now so the loads land under the pair loop
-    const int fc = tid >> 6, fb = block * 64 + lane;            // threads 0..191: component fc of body fb
-    const bool fin = tid < 192 && fb < a.n;
-    const size_t off = (size_t)(fin ? fc : 0) * a.npad + (fin ? fb : 0);
+// thread per (component, body): partial sums combined in slice order, then the rest of the fused step
+template <int L>
+__global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, const double *__restrict__ partial) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * a.npad) return;
+    const int cc = t / a.npad, my_i = t % a.npad;               // consecutive threads = consecutive bodies: coalesced
+    if (my_i >= a.n) return;
+    const size_t lvl = (size_t)3 * a.npad;
+    const size_t off = (size_t)cc * a.npad + my_i;
     double yv[L], av[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
@@ -792,33 +828,8 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_lm_step_fast(const LmArgs a
         yv[j] = a.Y[slot * lvl + off];
         av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
     }
-
-    const auto *src = (const __attribute__((address_space(4))) Body4 *)(unsigned long long)a.pos_cur;
-    const double xi = a.pos_cur[ic].x, yi = a.pos_cur[ic].y, zi = a.pos_cur[ic].z;
-    const int j0 = slice * slice_len, j1 = min(j0 + slice_len, a.npad);
-    double ax = 0.0, ay = 0.0, az = 0.0;
-    if (j0 < j1) {
-        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
-        else fast_slice<false>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
-    }
-    double *pp = partial + (size_t)slice * lvl + i;
-    pp[0] = ax;
-    pp[(size_t)a.npad] = ay;
-    pp[(size_t)2 * a.npad] = az;
-
-    __threadfence();                                    // release this wave's partials (agent scope: other XCDs)
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&ticket[block], 1u) == (unsigned)(wgs_per_block - 1);
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                    // acquire the other workgroups' partials
-    if (tid == 0) ticket[block] = 0u;                   // ready for the next launch
-    if (!fin) return;
     double anew = 0.0;
-    {
-        const double *q = partial + (size_t)fc * a.npad + fb;
-        for (int sl = 0; sl < S; ++sl) anew = anew + q[(size_t)sl * lvl];
-    }
+    for (int sl = 0; sl < S; ++sl) anew = anew + partial[(size_t)sl * lvl + off];
     a.A[(size_t)a.cur * lvl + off] = anew;
     {
         double prev[L];
@@ -827,13 +838,13 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_lm_step_fast(const LmArgs a
         prev[L - 1] = 0.0;
         a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
     }
-    maybe_sample(a.samp, fb, fc, a.step, yv[0]);
+    maybe_sample(a.samp, my_i, cc, a.step, yv[0]);
     if (a.do_predict) {
         av[0] = anew;
         const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
         const int nslot = (a.cur + L - 1) % L;
         a.Y[(size_t)nslot * lvl + off] = ynext;
-        reinterpret_cast<double *>(a.pos_next + fb)[fc] = ynext;
+        reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
     }
 }
 
@@ -1352,6 +1363,16 @@ int lm_bodies_per_wave(int n) {
     return 1;
 }
 
+// workgroup kernel tuning knobs (read once): EPH_WG_LAYOUT = 0 | 1 (role layout), EPH_DEBUG_WG bit mask
+// (1 no chain, 2 no pair work, 4 cycle accounting into g_wg_cycles, 8 chain wave at raised priority)
+static int wg_layout() {
+    static const int v = [] { const char *e = getenv("EPH_WG_LAYOUT"); return e ? atoi(e) : kWgDefaultLayout; }();
+    return v == 1 ? 1 : 0;
+}
+static int wg_debug_flags() {
+    static const int v = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
+    return v;
+}
 // which per-step force kernel: 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
 int force_kernel_kind(int n, int requested) {
     if (requested == 1 || requested == 2) return requested;
@@ -1371,9 +1392,12 @@ int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double 
     const int nt = hi - lo;                            // targets of this launch; the kernel choice follows them
     if (n <= 0 || nt <= 0) return EPH_OK;
     if (force_kernel_kind(nt, kind) == 2) {
-        static const int dbg = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
-        hipLaunchKernelGGL(k_accel_wg, dim3((nt + kWgBodies - 1) / kWgBodies), dim3(kWgThreads), 0, s, n, npad, pos,
-                           acc_init, acc_out, dbg, lo, hi);
+        const int dbg = wg_debug_flags();
+        const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
+        if (wg_layout() == 1)
+            hipLaunchKernelGGL(k_accel_wg<1>, grid, dim3(wg_threads(1)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+        else
+            hipLaunchKernelGGL(k_accel_wg<0>, grid, dim3(wg_threads(0)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
         return done("k_accel_wg");
     }
     const int bpw = lm_bodies_per_wave(nt);
@@ -1403,9 +1427,14 @@ static int launch_lm_step_L(hipStream_t s, const LmArgs &a) {
 int launch_lm_step(hipStream_t s, const LmArgs &a) {
     if (a.n <= 0 || a.hi <= a.lo) return EPH_OK;
     if (force_kernel_kind(a.hi - a.lo, a.kind) == 2) {
-        const dim3 grid((a.hi - a.lo + kWgBodies - 1) / kWgBodies), block(kWgThreads);
-        if (a.L == 12) hipLaunchKernelGGL(k_lm_step_wg<12>, grid, block, 0, s, a);
-        else if (a.L == 13) hipLaunchKernelGGL(k_lm_step_wg<13>, grid, block, 0, s, a);
+        const dim3 grid((a.hi - a.lo + kWgBodies - 1) / kWgBodies);
+        LmArgs b = a;
+        b.wg_flags = wg_debug_flags() & 8;             // only the priority knob; the cycle accounting is k_accel_wg's
+        const int lay = wg_layout();
+        if (a.L == 12 && lay == 1) hipLaunchKernelGGL((k_lm_step_wg<12, 1>), grid, dim3(wg_threads(1)), 0, s, b);
+        else if (a.L == 12) hipLaunchKernelGGL((k_lm_step_wg<12, 0>), grid, dim3(wg_threads(0)), 0, s, b);
+        else if (a.L == 13 && lay == 1) hipLaunchKernelGGL((k_lm_step_wg<13, 1>), grid, dim3(wg_threads(1)), 0, s, b);
+        else if (a.L == 13) hipLaunchKernelGGL((k_lm_step_wg<13, 0>), grid, dim3(wg_threads(0)), 0, s, b);
         else return EPH_ERR_UNSUPPORTED;
         return done("k_lm_step_wg");
     }
@@ -1420,17 +1449,19 @@ int fast_slices(int npad) {
     S = std::max(kFastWaves, std::min(kFastMaxSlices, S));
     return (S + kFastWaves - 1) / kFastWaves * kFastWaves;
 }
-int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, unsigned *ticket) {
+int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial) {
     if (a.n <= 0) return EPH_OK;
     if (a.lo != 0 || a.hi != a.n) return EPH_ERR_UNSUPPORTED;          // the fast path is not sharded
     const int S = fast_slices(a.npad);
     int slice_len = (a.npad + S - 1) / S;
     slice_len = (slice_len + kFastUnroll - 1) / kFastUnroll * kFastUnroll;
-    const dim3 grid((unsigned)(a.npad / 64 * (S / kFastWaves))), block(64 * kFastWaves);
-    if (a.L == 12) hipLaunchKernelGGL(k_lm_step_fast<12>, grid, block, 0, s, a, S, slice_len, partial, ticket);
-    else if (a.L == 13) hipLaunchKernelGGL(k_lm_step_fast<13>, grid, block, 0, s, a, S, slice_len, partial, ticket);
+    hipLaunchKernelGGL(k_fast_partial, dim3((unsigned)(a.npad / 64 * (S / kFastWaves))), dim3(64 * kFastWaves), 0, s, a.n,
+                       a.npad, a.pos_cur, S, slice_len, partial);
+    const dim3 grid((3 * a.npad + 255) / 256), block(256);
+    if (a.L == 12) hipLaunchKernelGGL(k_fast_finish<12>, grid, block, 0, s, a, S, partial);
+    else if (a.L == 13) hipLaunchKernelGGL(k_fast_finish<13>, grid, block, 0, s, a, S, partial);
     else return EPH_ERR_UNSUPPORTED;
-    return done("k_lm_step_fast");
+    return done("k_fast_partial / k_fast_finish");
 }
 int launch_lm_predict(hipStream_t s, const LmArgs &a) {
     if (a.n <= 0 || a.hi <= a.lo) return EPH_OK;

@@ -228,9 +228,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
     const bool fast = path_ == EPH_PATH_FAST;
     if (fast && (n_ <= kSmallN || sharded())) return EPH_ERR_UNSUPPORTED;
     if (fast && !fast_partial_.p) {
-        if ((st = fast_partial_.alloc((size_t)fast_slices(npad_) * 3 * npad_)) || (st = fast_ticket_.alloc(npad_ / 64)))
-            return st;
-        EPH_HIP(hipMemsetAsync(fast_ticket_.p, 0, sizeof(unsigned) * (npad_ / 64), stream_));
+        if ((st = fast_partial_.alloc((size_t)fast_slices(npad_) * 3 * npad_))) return st;
     }
     const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3 && !fast;
     if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
@@ -256,7 +254,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.pos_next = P_[pp_ ^ 1].p;
             a.do_predict = s < k;
             a.step = (uint32_t)s;
-            if ((st = fast ? launch_lm_step_fast(stream_, a, fast_partial_.p, fast_ticket_.p) : launch_lm_step(stream_, a)))
+            if ((st = fast ? launch_lm_step_fast(stream_, a, fast_partial_.p) : launch_lm_step(stream_, a)))
                 return st;
             if (a.do_predict && (st = gather_packed(a.pos_next))) return st;
         }

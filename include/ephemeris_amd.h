@@ -303,6 +303,18 @@ void eph_craft_batch_destroy(eph_craft_batch *b);
 int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos_xyz, const double *vel_xyz, int64_t m,
                          const double *at, double *out_pos_xyz, double *out_vel_xyz, uint8_t *inside);
 
+/* SpacecraftPropagator::join(lhs, rhs) (ephemeris/src/propagators/spacecraft.rs:558-561; the app's
+ * PredictionTarget::merge, ephemeris_explorer/src/dynamics/spacecraft.rs:830-841): lhs.clear_after(rhs.start())
+ * -- keep the knots with t < rhs.start() (trajectory.rs:842-845; rhs.start() of an empty spline is Epoch::MIN,
+ * :756-758) -- then lhs.extend(rhs) (:847-849). Host only (knot lists are host data). Writes the joined spline
+ * to the *_out arrays (capacity knots; t_out / pos_out / vel_out may be the lhs arrays themselves) and its length
+ * to *n_out; when capacity is too small nothing is written, *n_out is the needed length and the status is
+ * EPH_ERR_BAD_ARGUMENT. This is what stitches the slab drained by eph_craft_batch_knots onto the trajectory the
+ * caller already holds. */
+int32_t eph_hermite_join(int64_t n_lhs, const double *t_lhs, const double *pos_lhs, const double *vel_lhs,
+                         int64_t n_rhs, const double *t_rhs, const double *pos_rhs, const double *vel_rhs,
+                         int64_t capacity, double *t_out, double *pos_out, double *vel_out, int64_t *n_out);
+
 /* Test hook: the step-size controller's correctly rounded pow(x[i], y) on the device */
 int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out);
 /* test hook: a[i] / b[i] through the shared-reciprocal division of k_craft_wave and through the compiler's IEEE

@@ -796,3 +796,11 @@ class Spline:
             return None
         return Spline(self.start + self.interval * float(a), self.interval,
                       [self.polys[i] for i in range(a, b + 1) if i < len(self.polys)])
+
+
+def hermite_join(lhs, rhs):
+    """SpacecraftPropagator::join (ephemeris/src/propagators/spacecraft.rs:558-561): lhs.clear_after(rhs.start()) --
+    retain the knots with `at > t` (trajectory.rs:842-845), rhs.start() = first knot or Epoch::MIN (:756-758) -- then
+    lhs.extend(rhs) (:847-849). Splines are lists of (t, pos, vel)."""
+    at = rhs[0][0] if rhs else EPOCH_MIN
+    return [k for k in lhs if at > k[0]] + list(rhs)

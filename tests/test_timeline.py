@@ -155,3 +155,34 @@ def test_solution_create_zeroes_rows_beyond_ncoef_and_append_rejects_aliasing(ea
     lib.eph_solution_destroy(out)
     with pytest.raises(ValueError):
         sol.append(sol)
+
+
+def test_hermite_join_matches_restatement(ea):
+    """eph_hermite_join = SpacecraftPropagator::join (ephemeris/src/propagators/spacecraft.rs:558-561), host logic."""
+    rng = np.random.default_rng(21)
+    for case in range(200):
+        nl, nr = int(rng.integers(0, 12)), int(rng.integers(0, 8))
+        lt = np.sort(rng.choice(np.arange(0.0, 400.0, 10.0), nl, replace=False))
+        # rhs starts at a knot of lhs (the resume case), between knots, before everything or after everything
+        start = float(rng.choice(list(lt) + [lt[0] - 5.0 if nl else 0.0, (lt[-1] + 5.0) if nl else 1.0, 155.0]))
+        rt = start + np.arange(nr) * 7.5
+        lp, lv, rp, rv = rng.normal(size=(nl, 3)), rng.normal(size=(nl, 3)), rng.normal(size=(nr, 3)), rng.normal(size=(nr, 3))
+        want = po.hermite_join([(lt[k], tuple(lp[k]), tuple(lv[k])) for k in range(nl)],
+                               [(rt[k], tuple(rp[k]), tuple(rv[k])) for k in range(nr)])
+        t, p, v = ea.hermite_join((lt, lp, lv), (rt, rp, rv))
+        assert len(t) == len(want), case
+        for k, (wt, wp, wv) in enumerate(want):
+            assert t[k] == wt and tuple(p[k]) == wp and tuple(v[k]) == wv, (case, k)
+        if nr == 0:
+            assert len(t) == 0                               # rhs.start() of an empty spline is Epoch::MIN
+    # capacity too small: nothing written, needed length reported
+    import ctypes
+    lib = ea._lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    lt, z = np.array([0.0, 1.0, 2.0]), np.zeros((3, 3))
+    rt = np.array([1.5, 2.5])
+    out_t, out_p, n = np.full(2, -1.0), np.zeros((2, 3)), ctypes.c_int64()
+    st = lib.eph_hermite_join(3, lt.ctypes.data_as(dp), z.ctypes.data_as(dp), z.ctypes.data_as(dp), 2,
+                              rt.ctypes.data_as(dp), z.ctypes.data_as(dp), z.ctypes.data_as(dp), 2,
+                              out_t.ctypes.data_as(dp), out_p.ctypes.data_as(dp), out_p.ctypes.data_as(dp), ctypes.byref(n))
+    assert st == -1 and n.value == 4 and (out_t == -1.0).all()
