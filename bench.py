@@ -93,6 +93,22 @@ def cpu_baseline(pos, vel, mu, steps):
     return base, o
 
 
+def sharded_cpu_baseline(pos, mu, n, evals=2):
+    """One steady QuinlanTremaine12 step of a large system is one NewtonianGravity::eval plus O(N) work, and the oracle's
+    start-up alone would take half an hour at 65 536 bodies: the bounded sample is `evals` force evaluations of the same
+    system by the oracle (single thread, triangular pair loop like the reference)."""
+    from oracle import orc
+    orc.build(native=True)
+    t0 = time.perf_counter()
+    for _ in range(evals):
+        orc.gravity(pos, mu, native=True)
+    dt = time.perf_counter() - t0
+    return {"value": n * evals / dt, "unit": "body-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{evals} NewtonianGravity::eval of the same {n}-body system (a steady multistep step = one "
+                      "evaluation + O(N)); start-up not run on the CPU", "seconds": dt,
+            "ns_per_pair": dt / evals / (n * (n - 1) / 2) * 1e9}
+
+
 def craft_main(args):
     """BASELINE.json configs[3] (bounded): full_solar_system ephemeris + spacecraft sharded over the ranks in
     contiguous blocks (independent given the ephemeris, which every rank rebuilds bit-identically: no data-path
@@ -117,6 +133,7 @@ def craft_main(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    backend_is_nccl = world > 1 and os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl"
     sysdir = ROOT / "tests/golden/systems/full_solar_system_2433282.5"
     s = load_system(sysdir)
     ship = load_ship(sysdir / "ships" / "Mars Transfer Ship.json")
@@ -134,6 +151,7 @@ def craft_main(args):
         b.propagate(t_end)
         return b
 
+    from ephemeris_explorer_amd.parallel import gather_craft_states
     for _ in range(args.warmup if args.warmup < 3 else 2):
         sweep()
 
@@ -144,27 +162,74 @@ def craft_main(args):
 
     barrier()
     t0 = time.perf_counter()
-    steps_local, ms = 0, 0.0
+    steps_local, attempts_local, ms = 0, 0, 0.0
     nsweeps = max(1, min(args.steps, 5))
+    table = None
     for _ in range(nsweeps):
         b = sweep()
         st = b.status()
         assert (st["status"] == 0).all()
         steps_local += int(st["steps"].sum())
+        attempts_local += int(st["attempts"].sum())
         ms += b.kernel_ms()
+        # the sweep's one exchange step: final states of all craft on every rank -- ncclAllGather over
+        # xGMI for world > 1 (north_star: "RCCL over xGMI only for the embarrassingly-parallel spacecraft sweep")
+        table = gather_craft_states(b.state(), args.craft, dist, device="cuda" if backend_is_nccl else "cpu")
     barrier()
     elapsed = time.perf_counter() - t0
+    assert table.shape == (args.craft, 7) and np.isfinite(table).all() and (table[:, 0] >= t_end).all()
     units, elapsed = reduce_timing(elapsed, steps_local, dist, device="cuda")
     if rank == 0:
-        print(json.dumps({
+        # per craft-attempt 13 evaluations x B bodies x (Horner + index + point mass) ~ 74 flop; 56 B knot
+        # written per ACCEPTED step (the ephemeris rows stay in L1/L2)
+        flop = attempts_local * 13.0 * s.n * 74.0
+        launch_s = ms * 1e-3 / nsweeps
+        out = {
             "metric": "craft-steps/s", "value": units / elapsed, "unit": "accepted integrator steps/s",
             "n_gpus": world, "steps": nsweeps, "warmup": 2, "ms_per_step": elapsed / nsweeps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"full_solar_system ephemeris + {args.craft} craft x {args.craft_days} d, Verner87 "
-                                   "tol 1e-3 (BASELINE.json configs[3], bounded)", "parallelism": f"craft sharded x{world}"},
-            "kernel_ms_rank0": ms, "includes": "batch creation (H2D of the shard) + sweep kernel"}), flush=True)
+                                   "tol 1e-3 (BASELINE.json configs[3], bounded)", "parallelism": f"craft sharded x{world}",
+                       "exchange": "1 all-gather of the final states per sweep (56 B per craft)" if world > 1 else "none (1 rank)"},
+            "kernel_ms_rank0": ms, "includes": "batch creation (H2D of the shard) + sweep kernel + result all-gather",
+            "roofline": {"bound": "hbm", "achieved": 56.0 * steps_local / nsweeps / launch_s / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": 56.0 * steps_local / nsweeps / launch_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_craft_propagate<13,false,false,2>", "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": 56.0 * steps_local / nsweeps,
+                         "note": "rank 0's shard; the sweep is f64-VALU bound (every ephemeris row is an L1 hit), see fp64"},
+            "fp64": {"bound": "fp64_valu", "achieved": flop / nsweeps / launch_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flop / nsweeps / launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "flop_per_launch": flop / nsweeps, "attempts_per_launch": attempts_local / nsweeps,
+                     "count": "13 stages x 32 bodies x 74 flop per attempt (SURVEY 8(d))"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = craft_cpu_baseline(s, ship, pos, vel, t_end, args.craft_days)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def craft_cpu_baseline(s, ship, pos, vel, t_end, craft_days, sample=1000):
+    """The oracle (port of SpacecraftPropagator::step, one thread) on the first `sample` craft of the same sweep against
+    the oracle's own ephemeris of the same system; the per-craft rate is what a CPU core does, the whole-workload figure
+    would be an extrapolation and is not printed."""
+    from oracle import orc
+    orc.build()
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert o.step_to(s.epoch + (craft_days + 40.0) * 86400.0) == 0
+    eph = o.take_solution()
+    n = min(sample, len(pos))
+    t0 = time.perf_counter()
+    steps = 0
+    for i in range(n):
+        c = orc.Craft(eph, s.mu, ship.start, pos[i], vel[i], "Verner87")
+        assert c.step_to(t_end) == 0
+        steps += len(c.knots()[0]) - 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "accepted integrator steps/s", "cores": 1, "kind": "port",
+            "sample": f"the first {n} craft of the same sweep ({craft_days} d each, Verner87 tol 1e-3), single thread; "
+                      "craft are independent, so the rate per core carries over -- not extrapolated to the full batch here",
+            "seconds": dt, "craft": n}
 
 
 def main():
@@ -181,6 +246,13 @@ def main():
                          "spacecraft) | nbody-sharded: ONE system of --bodies (default 65536, configs[4] in f64) "
                          "partitioned by target body over the ranks, one RCCL all-gather per step (strong scaling)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl", help="nbody-sharded exchange")
+    ap.add_argument("--path", choices=["exact", "fast"], default="exact",
+                    help="exact (default): the reference's summation order, bit-identical to the CPU path | fast: the "
+                         "opt-in slice-parallel sums (EPH_PATH_FAST) -- a second, separately labelled line "
+                         "(config.workload ..._fast) with its measured divergence from the reference order")
+    ap.add_argument("--horizon", type=int, default=100000,
+                    help="parity horizon: max |dpos| vs the oracle's committed positions at every 10^k-th step up to this "
+                         "many steps (tests/golden/plummer4096_horizon.npz; 0 = skip)")
     ap.add_argument("--craft", type=int, default=262144)
     ap.add_argument("--craft-days", type=float, default=0.25)
     args = ap.parse_args()
@@ -223,7 +295,12 @@ def main():
     # rank r integrates its own replica (seed + r): independent systems, no exchange -- or, sharded, every rank
     # builds the SAME system and owns n/world target bodies of it
     pos, vel, mu = plummer(n, seed=20260926 + (0 if sharded else rank))
+    fast = args.path == "fast"
+    if fast and sharded:
+        raise SystemExit("--path fast is not sharded")
     g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    if fast:
+        g.set_path(ea.PATH_FAST)
     if sharded:
         from ephemeris_explorer_amd.parallel import shard_nbody
         shard_nbody(g, dist, transport=args.transport, device="cuda")
@@ -272,11 +349,15 @@ def main():
                         "bodies_per_gpu": nt, "method": "QuinlanTremaine12",
                         "parallelism": f"target-partition x{world}, 1 all-gather of {32 * n} B per step "
                                        f"({args.transport})"} if sharded else
-                       {"workload": f"plummer_{n}_f64_qt12 (BASELINE.json configs[2]; h=1/1024, seed 20260926+rank)",
-                        "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}"}),
+                       {"workload": f"plummer_{n}_f64_qt12{'_fast' if fast else ''} (BASELINE.json configs[2]; h=1/1024, "
+                                    "seed 20260926+rank)" + ("; OPT-IN fast path: slice-parallel partial sums, NOT the "
+                                                             "reference's summation order" if fast else ""),
+                        "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}",
+                        "path": args.path}),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_lm_step_wg<12>" if 2048 < nt < 8192 else "k_lm_step<BPW,12>",
+                         "kernel": ("k_fast_partial + k_fast_finish<12>" if fast else
+                                    "k_lm_step_wg<12,LAYOUT>" if 2048 < nt < 8192 else "k_lm_step<BPW,12>"),
                          "launch_us": launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * nt,
                          "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see fp64"
@@ -297,10 +378,31 @@ def main():
             out["cpu_baseline"] = base
             # parity beside the number: a fresh GPU run of the same steps vs the oracle
             c = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            if fast:
+                c.set_path(ea.PATH_FAST)
             nsteps = o.state()[3]                            # the oracle went on for the all-cores sample
             c.advance(nsteps)
             dp = np.abs(c.state()[0] - o.state()[0]).max()
             out["parity"] = {"max_abs_dpos": float(dp), "steps": int(nsteps), "vs": "oracle (port)"}
+        if world == 1 and not args.no_cpu_baseline and sharded:
+            out["cpu_baseline"] = sharded_cpu_baseline(pos, mu, n)
+        fx = ROOT / "tests" / "golden" / "plummer4096_horizon.npz"
+        if world == 1 and n == N_BODIES and not sharded and args.horizon > 0 and fx.exists():
+            # north_star: "positions within 1e-9 AU of the reference over 1e5 steps": max |dpos| against the oracle's
+            # committed positions (generator tests/golden/make_plummer_horizon.py) at every 10^k-th step
+            ref = np.load(fx)
+            c = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            if fast:
+                c.set_path(ea.PATH_FAST)
+            done, hz = 0, {}
+            for k in (int(x) for x in ref["checkpoints"]):
+                if k > args.horizon:
+                    break
+                c.advance(k - done)
+                done = k
+                hz[str(k)] = float(np.abs(c.state()[0] - ref[f"pos_{k}"]).max())
+            out.setdefault("parity", {})["horizon_max_abs_dpos"] = hz
+            out["parity"]["horizon_vs"] = "oracle positions, tests/golden/plummer4096_horizon.npz (N-body units: length scale 1)"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

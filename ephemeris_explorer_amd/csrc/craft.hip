@@ -1397,6 +1397,16 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
         if (st) return st;
         std::unique_ptr<eph_craft_batch> b(new eph_craft_batch());
         if (!find_erk(method, &b->rk) || !b->rk.has_embedded) return EPH_ERR_BAD_ARGUMENT;
+        // ERKN integrates y'' = f(t, y) (P::ODE: SecondOrderODE, nystrom/explicit.rs:60): the spacecraft model is one
+        // only while no burn is expressed in a frame built from the velocity (ReferenceFrame::Relative -> TNB of the
+        // relative state, dynamics/spacecraft.rs:281-293). The reference cannot even express that combination.
+        if (b->rk.nystrom == 2 && burn_offset)
+            for (int64_t q = burn_offset[0]; q < burn_offset[n_craft]; ++q)
+                if (burn_ref[q] >= 0) {
+                    set_last_error_text("Tsitouras75Nystrom (ERKN) needs a velocity-independent right-hand side: "
+                                        "burns must use the inertial frame");
+                    return EPH_ERR_UNSUPPORTED;
+                }
         b->eph = e;
         b->n = n_craft;
         b->max_knots = max_knots;

@@ -59,7 +59,7 @@ struct ErkCoeffs {             // ERK + embedded pair; A[s][j] for j < s   (inte
     int fsal = 0, has_embedded = 0;
     double A[16][16], B[16], C[16], E[16];
     // nystrom = 1: ERKNG pair (runge_kutta/nystrom/explicit_generalized.rs:14-41), at most 8 stages:
-    // A = AP, A2 = AV, B = BP, B2 = BV, E = EP, E2 = EV
+    // A = AP, A2 = AV, B = BP, B2 = BV, E = EP, E2 = EV. nystrom = 2: ERKN (nystrom/explicit.rs), the same with A2 = 0
     int nystrom = 0;
     double A2[8][8], B2[8], E2[8];
 };

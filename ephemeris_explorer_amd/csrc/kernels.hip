@@ -516,7 +516,9 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 //   0: 5 waves  -- pair waves of 2/5/5/4 bodies + the chain wave (one wave per SIMD, the chain shares SIMD 0)
 //   1: 8 waves  -- pair waves of 1/3/3/3 bodies, the chain wave, pair waves of 2/2/2 bodies: SIMDs 1-3 carry TWO pair
 //                  waves (5 bodies together) that fill each other's dependency stalls; SIMD 0 the chain + one body
-constexpr int wg_threads(int layout) { return layout == 1 ? 64 * 8 : 64 * 5; }
+//   2: 8 waves  -- wave 0 only keeps the barrier count, pair waves of 3/3/3, the chain wave, pair waves of 3/2/2: the
+//                  chain wave has SIMD 0 to itself; SIMDs 1-3 carry 6 / 5 / 5 bodies in two waves each
+constexpr int wg_threads(int layout) { return layout >= 1 ? 64 * 8 : 64 * 5; }
 constexpr int kWgDefaultLayout = 0;
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
@@ -615,7 +617,18 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
     // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
     // under the denser f64 stream and the step gets slower.)
-    if constexpr (LAYOUT == 1) {
+    if constexpr (LAYOUT == 2) {
+        switch (wave) {
+            case 0: for (int t = 0; t <= tiles; ++t) __syncthreads(); return 0.0;   // tiles + 1 barriers, like every wave
+            case 1: wg_pair_wave<3>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave<3>(pos, n, i0, 3, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave<3>(pos, n, i0, 6, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 5: wg_pair_wave<3>(pos, n, i0, 9, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 6: wg_pair_wave<2>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 7: wg_pair_wave<2>(pos, n, i0, 14, C, lane, tiles, tdiag, dbg); return 0.0;
+            default: break;
+        }
+    } else if constexpr (LAYOUT == 1) {
         switch (wave) {
             case 0: wg_pair_wave<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
             case 1: wg_pair_wave<3>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg); return 0.0;
@@ -828,8 +841,17 @@ __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, cons
         yv[j] = a.Y[slot * lvl + off];
         av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
     }
+    // all loads of a group of 16 slices in flight before the ordered adds (one load per add would pay the memory
+    // latency S times: measured 11 us for this kernel at S = 32)
     double anew = 0.0;
-    for (int sl = 0; sl < S; ++sl) anew = anew + partial[(size_t)sl * lvl + off];
+    for (int base = 0; base < S; base += 16) {
+        double pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[u] = base + u < S ? partial[(size_t)(base + u) * lvl + off] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (base + u < S) anew = anew + pv[u];
+    }
     a.A[(size_t)a.cur * lvl + off] = anew;
     {
         double prev[L];
@@ -1367,7 +1389,7 @@ int lm_bodies_per_wave(int n) {
 // (1 no chain, 2 no pair work, 4 cycle accounting into g_wg_cycles, 8 chain wave at raised priority)
 static int wg_layout() {
     static const int v = [] { const char *e = getenv("EPH_WG_LAYOUT"); return e ? atoi(e) : kWgDefaultLayout; }();
-    return v == 1 ? 1 : 0;
+    return v == 1 || v == 2 ? v : 0;
 }
 static int wg_debug_flags() {
     static const int v = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
@@ -1394,7 +1416,9 @@ int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double 
     if (force_kernel_kind(nt, kind) == 2) {
         const int dbg = wg_debug_flags();
         const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
-        if (wg_layout() == 1)
+        if (wg_layout() == 2)
+            hipLaunchKernelGGL(k_accel_wg<2>, grid, dim3(wg_threads(2)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+        else if (wg_layout() == 1)
             hipLaunchKernelGGL(k_accel_wg<1>, grid, dim3(wg_threads(1)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
         else
             hipLaunchKernelGGL(k_accel_wg<0>, grid, dim3(wg_threads(0)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
@@ -1431,7 +1455,9 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
         LmArgs b = a;
         b.wg_flags = wg_debug_flags() & 8;             // only the priority knob; the cycle accounting is k_accel_wg's
         const int lay = wg_layout();
-        if (a.L == 12 && lay == 1) hipLaunchKernelGGL((k_lm_step_wg<12, 1>), grid, dim3(wg_threads(1)), 0, s, b);
+        if (a.L == 12 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<12, 2>), grid, dim3(wg_threads(2)), 0, s, b);
+        else if (a.L == 13 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<13, 2>), grid, dim3(wg_threads(2)), 0, s, b);
+        else if (a.L == 12 && lay == 1) hipLaunchKernelGGL((k_lm_step_wg<12, 1>), grid, dim3(wg_threads(1)), 0, s, b);
         else if (a.L == 12) hipLaunchKernelGGL((k_lm_step_wg<12, 0>), grid, dim3(wg_threads(0)), 0, s, b);
         else if (a.L == 13 && lay == 1) hipLaunchKernelGGL((k_lm_step_wg<13, 1>), grid, dim3(wg_threads(1)), 0, s, b);
         else if (a.L == 13) hipLaunchKernelGGL((k_lm_step_wg<13, 0>), grid, dim3(wg_threads(0)), 0, s, b);

@@ -43,6 +43,30 @@ def reduce_timing(elapsed_s, units_local, dist=None, device="cpu"):
     return float(u.item()), float(t.item())
 
 
+def gather_craft_states(state, n_total, dist=None, device="cpu"):
+    """The result exchange of the massless sweep (`ncclAllGather` of the final states): every rank holds the
+    final (t, position, velocity) of its contiguous block of spacecraft (`shard_range`); returns the [n_total, 7] array of
+    all of them on every rank. One all-gather of equal, zero-padded slices -- RCCL over xGMI with backend "nccl" and
+    device="cuda" (56 B per craft: 56 MB for 1e6), gloo on CPU in the tests. `state` = SpacecraftBatch.state()."""
+    import numpy as np
+    import torch
+    mine = np.concatenate([state["t"][:, None], state["pos"], state["vel"]], axis=1)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert len(mine) == n_total
+        return mine
+    rank, world = dist.get_rank(), dist.get_world_size()
+    width = -(-n_total // world)                                  # largest block of shard_range
+    lo, hi = shard_range(n_total, rank, world)
+    assert hi - lo == len(mine)
+    send = torch.zeros((width, 7), dtype=torch.float64, device=device)
+    send[: hi - lo] = torch.from_numpy(mine).to(device)
+    recv = torch.empty((world * width, 7), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    recv = recv.cpu().numpy().reshape(world, width, 7)
+    return np.concatenate([recv[r, : shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0]]
+                           for r in range(world)], axis=0)
+
+
 def _hip():
     lib = C.CDLL("libamdhip64.so")
     lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

@@ -906,7 +906,8 @@ typedef int (*ode_fn)(void *ctx, double t, const double *y, double *dy);
 typedef struct {
     int stages, order, order_embedded, fsal, dim;
     /* nystrom = 0: ERK (A, B, C, E). nystrom = 1: ERKNG on a SecondOrderState (y = state[0..2], dy = state[3..5]):
-     * A = AP, A2 = AV, B = BP, B2 = BV, E = EP, E2 = EV; k[s][0..2] = dk[s] */
+     * A = AP, A2 = AV, B = BP, B2 = BV, E = EP, E2 = EV; k[s][0..2] = dk[s]. nystrom = 2: ERKN (nystrom/explicit.rs),
+     * the same without AV */
     int nystrom;
     double A[ERK_MAX_STAGES][ERK_MAX_STAGES], B[ERK_MAX_STAGES], C[ERK_MAX_STAGES], E[ERK_MAX_STAGES];
     double A2[ERK_MAX_STAGES][ERK_MAX_STAGES], B2[ERK_MAX_STAGES], E2[ERK_MAX_STAGES];
@@ -919,7 +920,29 @@ static const EPH_ERKNG_TABLE *find_erkng(const char *name) {
     return NULL;
 }
 
+static const EPH_ERKN_TABLE *find_erkn(const char *name) {
+    for (int i = 0; i < EPH_N_ERKN_TABLES; ++i)
+        if (!strcmp(eph_erkn_tables[i].name, name)) return &eph_erkn_tables[i];
+    return NULL;
+}
+
 static int erk_init(erk_t *r, const char *name, int dim, const double *state) {
+    const EPH_ERKN_TABLE *n = find_erkn(name);
+    if (n) {                                                  /* ERKN<C, [V; STAGES], V>::from_problem  nystrom/explicit.rs:64-72 */
+        if (n->stages > ERK_MAX_STAGES || dim != 6) return ORC_BAD_ARGUMENT;
+        memset(r, 0, sizeof(*r));
+        r->nystrom = 2;                                       /* y'' = f(t, y): no stage velocities, no AV */
+        r->stages = n->stages; r->order = n->order; r->order_embedded = n->order_embedded; r->fsal = n->fsal; r->dim = 6;
+        int idx = 0;
+        for (int s = 0; s < n->stages; ++s) {
+            for (int j = 0; j < s; ++j) r->A[s][j] = ratio_f64(n->A[idx++]);
+            r->B[s] = ratio_f64(n->BP[s]); r->B2[s] = ratio_f64(n->BV[s]); r->C[s] = ratio_f64(n->C[s]);
+            r->E[s] = ratio_f64(n->EP[s]); r->E2[s] = ratio_f64(n->EV[s]);
+        }
+        for (int s = 0; s < n->stages; ++s)                   /* dk = [state.dy.clone(); STAGES] */
+            for (int d = 0; d < 3; ++d) r->k[s][d] = state[3 + d];
+        return ORC_OK;
+    }
     const EPH_ERKNG_TABLE *g = find_erkng(name);
     if (g) {                                                  /* ERKNG<C, [V; STAGES], V>::from_problem  explicit_generalized.rs:87-95 */
         if (g->stages > ERK_MAX_STAGES || dim != 6) return ORC_BAD_ARGUMENT;
@@ -990,7 +1013,44 @@ static int erkng_advance(erk_t *r, double h, double *time, double *state, ode_fn
     r->i += 1;
     return ORC_OK;
 }
+/* ERKN::advance  integration/src/runge_kutta/nystrom/explicit.rs:74-121 (SecondOrderODE: y'' = f(t, y)). The
+ * right-hand side is handed the UNCHANGED current velocity in sv[3..5] only because ode_fn takes a flat 6-vector; a
+ * SecondOrderODE never reads it (craft_rhs does only for frame-relative burns, which orc_craft_new refuses here). */
+static int erkn_advance(erk_t *r, double h, double *time, double *state, ode_fn f, void *ctx, uint64_t *evals) {
+    const int S = r->stages;
+    double *y = state, *dy = state + 3;
+    for (int s = 0; s < S; ++s) {
+        if (r->fsal && s == 0 && r->i > 0) {                  /* self.dk.swap(s, STAGES - 1); continue  :79-82 */
+            for (int d = 0; d < 3; ++d) { double t = r->k[0][d]; r->k[0][d] = r->k[S - 1][d]; r->k[S - 1][d] = t; }
+            continue;
+        }
+        const double ti = *time + h * r->C[s];
+        double sv[6], out[6];
+        const double hc = h * r->C[s];
+        for (int d = 0; d < 3; ++d) { sv[d] = y[d]; sv[d] = sv[d] + dy[d] * hc; sv[3 + d] = dy[d]; }   /* :87-90 */
+        for (int j = 0; j < s; ++j) {
+            const double hha = h * h * r->A[s][j];            /* :91-95 */
+            for (int d = 0; d < 3; ++d) sv[d] = sv[d] + r->k[j][d] * hha;
+        }
+        if (evals) (*evals)++;
+        int st = f(ctx, ti, sv, out);                         /* problem.ode.eval(ti, &self.yi, self.dk[s].zero())  :97 */
+        if (st) return st;
+        for (int d = 0; d < 3; ++d) r->k[s][d] = out[3 + d];
+    }
+    for (int d = 0; d < 3; ++d) y[d] = y[d] + dy[d] * h;      /* :102-104 */
+    for (int i = 0; i < S; ++i) {                             /* :105-116 */
+        const double hhbp = h * h * r->B[i], hbv = h * r->B2[i];
+        for (int d = 0; d < 3; ++d) {
+            y[d] = y[d] + r->k[i][d] * hhbp;
+            dy[d] = dy[d] + r->k[i][d] * hbv;
+        }
+    }
+    *time = *time + h;
+    r->i += 1;
+    return ORC_OK;
+}
 static int erk_advance(erk_t *r, double h, double *time, double *state, ode_fn f, void *ctx, uint64_t *evals) {
+    if (r->nystrom == 2) return erkn_advance(r, h, time, state, f, ctx, evals);
     if (r->nystrom) return erkng_advance(r, h, time, state, f, ctx, evals);
     double yi[ERK_MAX_DIM];
     const int S = r->stages, D = r->dim;
@@ -1021,7 +1081,7 @@ static int erk_advance(erk_t *r, double h, double *time, double *state, ode_fn f
 /* RKEmbedded::error  explicit.rs:123-132 */
 static void erk_error(const erk_t *r, double h, double *err) {
     for (int d = 0; d < r->dim; ++d) err[d] = 0.0;
-    if (r->nystrom) {                                         /* explicit_generalized.rs:153-170 */
+    if (r->nystrom) {                                         /* explicit_generalized.rs:153-170 = explicit.rs:137-157 */
         for (int i = 0; i < r->stages; ++i) {
             const double hhep = h * h * r->E[i], hev = h * r->E2[i];
             for (int d = 0; d < 3; ++d) {
@@ -1549,7 +1609,11 @@ orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, c
                          const double *burn_start, const double *burn_end, const double *burn_acc,
                          const int32_t *burn_ref) {
     const EPH_ERK_TABLE *tab = find_erk(method);
-    if (!((tab && tab->E) || find_erkng(method)) || strlen(method) >= 32) return NULL;
+    if (!((tab && tab->E) || find_erkng(method) || find_erkn(method)) || strlen(method) >= 32) return NULL;
+    /* ERKN needs P::ODE: SecondOrderODE (nystrom/explicit.rs:60); the spacecraft model is one only while no burn's
+     * frame depends on the velocity (ReferenceFrame::Relative -> TNB of the relative STATE, dynamics/spacecraft.rs:281-293) */
+    if (find_erkn(method))
+        for (int i = 0; i < nburns; ++i) if (burn_ref[i] >= 0) return NULL;
     orc_craft *c = calloc(1, sizeof(*c));
     c->eph = eph;
     c->mu = malloc(sizeof(double) * (size_t)(eph->n > 0 ? eph->n : 1));

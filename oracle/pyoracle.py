@@ -472,6 +472,48 @@ class Erkng:
         return ey + edy
 
 
+class Erkn(Erkng):
+    """ERKN + embedded error (integration/src/runge_kutta/nystrom/explicit.rs:53-157; Tsitouras75Nystrom): y'' = f(t, y).
+    Stage positions only -- the right-hand side is shown the unchanged current velocity (a SecondOrderODE never reads
+    it). Update and error are ERKNG's (inherited)."""
+
+    def __init__(self, name, state):
+        t = tables()["methods"][name]
+        self.A = [[_ratio(r) for r in row] for row in t["A"]["ratio"]]
+        self.BP, self.BV = [_ratio(r) for r in t["BP"]["ratio"]], [_ratio(r) for r in t["BV"]["ratio"]]
+        self.EP, self.EV = [_ratio(r) for r in t["EP"]["ratio"]], [_ratio(r) for r in t["EV"]["ratio"]]
+        self.C = [_ratio(r) for r in t["C"]["ratio"]]
+        self.fsal = t["FSAL"]
+        self.lower = min(int(t["ORDER"]), int(t["ORDER_EMBEDDED"]))
+        self.i = 0
+        self.k = [list(state[3:]) for _ in self.C]
+
+    def advance(self, h, t, state, f):
+        S = len(self.C)
+        y, dy = list(state[:3]), list(state[3:])
+        for s in range(S):
+            if self.fsal and s == 0 and self.i > 0:
+                self.k[0], self.k[S - 1] = self.k[S - 1], self.k[0]
+                continue
+            ti = t + h * self.C[s]
+            hc = h * self.C[s]
+            yi = [a + v * hc for a, v in zip(y, dy)]
+            for j in range(s):
+                hha = h * h * self.A[s][j]
+                yi = [a + kk * hha for a, kk in zip(yi, self.k[j])]
+            out = f(ti, yi + list(dy))
+            if out is None:
+                return None
+            self.k[s] = out[3:]
+        y = [a + v * h for a, v in zip(y, dy)]
+        for i in range(S):
+            hhbp, hbv = h * h * self.BP[i], h * self.BV[i]
+            y = [a + kk * hhbp for a, kk in zip(y, self.k[i])]
+            dy = [a + kk * hbv for a, kk in zip(dy, self.k[i])]
+        self.i += 1
+        return t + h, y + dy
+
+
 class Craft:
     """SpacecraftPropagator with an adaptive ERK pair and the CubicHermiteSpline solout
     (ephemeris/src/propagators/spacecraft.rs:415-695, integration/src/runge_kutta/mod.rs:188-285,396-440,
@@ -630,7 +672,8 @@ class Craft:
                 self.apsides.insert(j, rec)
 
     def reset(self):
-        self.rk = (Erkng if "AP" in tables()["methods"][self.method] else Erk)(self.method, self.y)
+        tab = tables()["methods"][self.method]
+        self.rk = (Erkng if "AP" in tab else Erkn if "BP" in tab else Erk)(self.method, self.y)
         self.next_h = self.h_init
         self.n = 0
 

@@ -38,6 +38,14 @@ def _worker(rank, world, port, out):
     uid = parallel.broadcast_unique_id(dist, lambda: bytes(range(128)))     # rank 0's id reaches every rank
     assert uid == bytes(range(128))
     lo, hi = parallel.shard_range(1001, rank, world)
+    # the massless sweep's result exchange: ragged blocks (501 + 500 craft) all-gathered into the full table
+    idx = np.arange(lo, hi, dtype=np.float64)
+    state = {"t": idx * 2.0, "pos": np.stack([idx, idx + 0.25, idx + 0.5], axis=1), "vel": -np.stack([idx, idx, idx], axis=1)}
+    table = parallel.gather_craft_states(state, 1001, dist)
+    assert table.shape == (1001, 7)
+    all_idx = np.arange(1001, dtype=np.float64)
+    assert np.array_equal(table[:, 0], all_idx * 2.0) and np.array_equal(table[:, 2], all_idx + 0.25)
+    assert np.array_equal(table[:, 6], -all_idx)
     out[rank] = (total, tmax, lo, hi, float(nb.state()[0].sum()))
     dist.barrier()
     dist.destroy_process_group()

@@ -100,6 +100,31 @@ def test_every_embedded_pair(gpu, simple_system, method):
     assert compare_knots(batch.knots(0), c.knots(), method)
 
 
+def test_erkn_tsitouras75nystrom(gpu, simple_system):
+    """ERKN (integration/src/runge_kutta/nystrom/explicit.rs; Tsitouras75Nystrom): y'' = f(t, y), i.e. the spacecraft
+    model with inertial-frame burns only. Runs the ERKNG kernels with the velocity-stage matrix zeroed; bit-identical
+    to the oracle's separate restatement of ERKN::advance. Both kernel forms (one wave per craft / thread per craft)."""
+    s, sol, eph, osol = simple_system
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    relative = ship_burns(ship, s.names)[:2]
+    inertial = [(b0, b1, acc, -1) for b0, b1, acc, _ in relative]
+    end = ship.start + 3 * 86400.0
+    with pytest.raises(gpu.EphemerisError):                    # a TNB burn needs the velocity: not a SecondOrderODE
+        gpu.SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], "Tsitouras75Nystrom",
+                            gpu.AdaptiveParams.default(1e-3), [relative], max_knots=64)
+    for n in (1, 13000):                                       # wave form, thread form
+        pos = np.repeat(ship.pos[None], n, 0) + np.arange(n)[:, None] * 1e-3
+        vel = np.repeat(ship.vel[None], n, 0)
+        batch = gpu.SpacecraftBatch(eph, ship.start, pos, vel, "Tsitouras75Nystrom", gpu.AdaptiveParams.default(1e-3),
+                                    [inertial] * n, max_knots=4096)
+        batch.propagate(end)
+        assert (batch.status()["status"] == 0).all()
+        for i in sorted({0, n - 1}):
+            c = orc.Craft(osol, s.mu, ship.start, pos[i], vel[i], "Tsitouras75Nystrom", burns=inertial)
+            assert c.step_to(end) == 0
+            assert compare_knots(batch.knots(i), c.knots(), f"ERKN craft {i} of {n}")
+
+
 def test_batch_of_perturbed_craft_and_resume(gpu, simple_system):
     s, sol, eph, osol = simple_system
     ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")

@@ -340,3 +340,26 @@ def test_pair_formula_variants_stay_bounded():
                 assert 0.0 < d < bound, (name, variant, d)
     finally:
         orc.set_pair_variant(0)
+
+
+def test_erkn_table_satisfies_the_nystrom_order_conditions():
+    """Tsitouras75Nystrom (integration/src/methods.rs:1417-1520) as the exact Ratio pairs of the reference: the
+    Runge-Kutta-Nystrom order conditions a transcription slip would break (published rationals: exact to ~1e-18)."""
+    from fractions import Fraction as Fr
+    t = TABLES["methods"]["Tsitouras75Nystrom"]
+    r = lambda nd: Fr(int(nd[0]), int(nd[1]))   # noqa: E731
+    A = [[r(x) for x in row] for row in t["A"]["ratio"]]
+    BP, BV, C = ([r(x) for x in t[k]["ratio"]] for k in ("BP", "BV", "C"))
+    EP, EV = ([r(x) for x in t[k]["ratio"]] for k in ("EP", "EV"))
+    tol = Fr(1, 10 ** 16)
+    assert abs(sum(BV) - 1) < tol and abs(sum(BP) - Fr(1, 2)) < tol
+    assert abs(sum(b * c for b, c in zip(BV, C)) - Fr(1, 2)) < tol
+    assert abs(sum(b * c for b, c in zip(BP, C)) - Fr(1, 6)) < tol
+    assert abs(sum(b * c * c for b, c in zip(BV, C)) - Fr(1, 3)) < tol
+    for row, c in zip(A, C):
+        assert abs(sum(row) - c * c / 2) < tol                 # stage positions are second-order Taylor consistent
+    for bp, bv, c in zip(BP, BV, C):
+        assert abs(bp - bv * (1 - c)) < tol                    # the simplifying assumption b'_i = b_i (1 - c_i)
+    assert abs(sum(EP)) < tol and abs(sum(EV)) < tol           # both solutions are consistent: their difference is O(h^p)
+    assert t["FSAL"] and int(t["ORDER"]) == 7 and int(t["ORDER_EMBEDDED"]) == 5 and C[-1] == 1
+    assert BP[:6] == A[6] and BP[6] == 0                       # FSAL: the last stage is the new point

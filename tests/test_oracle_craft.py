@@ -61,9 +61,13 @@ def test_reference_spacecraft_scenario(scenario):
         assert distance("Mars", "1951-01-01 00:00:00") < 10_000.0
 
 
-@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "CashKarp45", "Fine45"])
+@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "CashKarp45", "Fine45", "Tsitouras75Nystrom"])
 def test_c_oracle_equals_python_restatement_massless(scenario, method):
     s, eph, ship, burns = scenario
+    if method == "Tsitouras75Nystrom":       # ERKN: y'' = f(t, y) -- the ship's burns re-expressed in the inertial frame
+        with pytest.raises(ValueError):      # a frame-relative burn makes the right-hand side velocity dependent
+            orc.Craft(eph, s.mu, ship.start, ship.pos, ship.vel, method, burns=burns)
+        burns = [(b0, b1, acc, -1) for b0, b1, acc, _ in burns]
     pe = []
     for b in range(s.n):
         st, iv, n = eph.info(b)
