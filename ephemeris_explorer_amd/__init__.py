@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
-    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_debug_pow", "eph_debug_div",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div",
 ]
 
 
@@ -81,6 +81,19 @@ _u8p = C.POINTER(C.c_uint8)
 _i64p = C.POINTER(C.c_int64)
 _L = None
 KNOTS_FULL = 6
+
+
+class PlotView(C.Structure):
+    """eph_plot_view: camera position, the floating-origin grid's affine map and the simulation time."""
+    _fields_ = [("camera_position", C.c_double * 3), ("grid_matrix3", C.c_double * 9), ("grid_translation", C.c_double * 3),
+                ("cell_offset", C.c_double * 3), ("current", C.c_double)]
+
+
+class PlotRequest(C.Structure):
+    """eph_plot_request = PlotConfig + PlotSource (ephemeris_explorer/src/ui/world/plot.rs:15-83)."""
+    _fields_ = [("source_body", C.c_int32), ("reference_body", C.c_int32), ("knot_first", C.c_int64),
+                ("knot_count", C.c_int64), ("start", C.c_double), ("end", C.c_double), ("bound", C.c_int32),
+                ("enabled", C.c_int32), ("tan2_angular_resolution", C.c_double), ("max_points", C.c_int64)]
 
 
 class AdaptiveParams(C.Structure):
@@ -185,6 +198,8 @@ def _lib():
     L.eph_craft_batch_destroy.argtypes = [vp]
     L.eph_craft_batch_destroy.restype = None
     L.eph_hermite_eval.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _u8p]
+    L.eph_plot_points.argtypes = [vp, C.POINTER(PlotView), i64, C.POINTER(PlotRequest), i64, _dp, _dp, _dp, i64, _dp,
+                                  C.POINTER(C.c_float), _i64p, _i32p, _dp]
     L.eph_hermite_join.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _i64p]
     L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
     L.eph_debug_div.argtypes = [i64, _dp, _dp, _dp, _dp]
@@ -719,6 +734,39 @@ def hermite_eval(t, pos, vel, at, with_velocity=True):
     _check(_lib().eph_hermite_eval(len(t), _p(t), _p(pos), _p(vel), m, _p(at), _p(op), _p(ov) if with_velocity else None,
                                    _p(inside, _u8p)), "eph_hermite_eval")
     return op, (ov if with_velocity else None), inside.astype(bool)
+
+
+def plot_points(ephemeris, view, requests, knots=None):
+    """compute_plot_points_parallel + PlotPoints::new (ephemeris_explorer/src/ui/world/plot.rs:93-149,272-374) for a batch
+    of plots. view: dict(camera_position, grid_matrix3 (3x3, columns = axes), grid_translation, cell_offset, current);
+    requests: list of dict(source_body | knots=(first, count), reference_body, start, end, bound, enabled,
+    tan2_angular_resolution, max_points); knots: (t, pos, vel) arrays the hermite sources index into.
+    -> list of (status, failed_at, t[k], xyz[k, 3] float32)."""
+    v = PlotView()
+    v.camera_position[:] = [float(x) for x in view["camera_position"]]
+    m = np.asarray(view.get("grid_matrix3", np.eye(3)), dtype=np.float64)
+    v.grid_matrix3[:] = [float(m[r, c]) for c in range(3) for r in range(3)]          # column major
+    v.grid_translation[:] = [float(x) for x in view.get("grid_translation", (0.0, 0.0, 0.0))]
+    v.cell_offset[:] = [float(x) for x in view.get("cell_offset", (0.0, 0.0, 0.0))]
+    v.current = float(view["current"])
+    n = len(requests)
+    arr = (PlotRequest * max(n, 1))()
+    cap = 1
+    for i, r in enumerate(requests):
+        first, count = r.get("knots", (0, 0))
+        arr[i] = PlotRequest(int(r.get("source_body", -1)), int(r.get("reference_body", -1)), int(first), int(count),
+                             float(r["start"]), float(r["end"]), int(r.get("bound", 0)), int(r.get("enabled", 1)),
+                             float(r["tan2_angular_resolution"]), int(r["max_points"]))
+        cap = max(cap, int(r["max_points"]))
+    kt, kp, kv = (np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3))) if knots is None else (_f64(knots[0]).ravel(),
+                                                                                        _f64(knots[1]).reshape(-1, 3),
+                                                                                        _f64(knots[2]).reshape(-1, 3))
+    ot, ox = np.zeros((max(n, 1), cap)), np.zeros((max(n, 1), cap, 3), dtype=np.float32)
+    cnt, st, fail = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1))
+    _check(_lib().eph_plot_points(ephemeris._h, C.byref(v), n, arr, len(kt), _p(kt), _p(kp), _p(kv), cap, _p(ot),
+                                  ox.ctypes.data_as(C.POINTER(C.c_float)), _p(cnt, _i64p), _p(st, _i32p), _p(fail)),
+           "eph_plot_points")
+    return [(int(st[i]), float(fail[i]), ot[i, :cnt[i]].copy(), ox[i, :cnt[i]].copy()) for i in range(n)]
 
 
 def hermite_join(lhs, rhs):

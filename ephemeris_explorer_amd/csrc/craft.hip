@@ -1178,6 +1178,212 @@ __global__ void __launch_bounds__(256) k_hermite_eval(long long nk, const double
     inside[q] = 1;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Adaptive plot sampling: compute_plot_points_parallel + PlotPoints::new + angular_distance
+// (ephemeris_explorer/src/ui/world/plot.rs:93-149,272-374,429-436), one thread per plotted trajectory.
+// ------------------------------------------------------------------------------------------------------
+struct PlotArgs {
+    long long n_plots;
+    int n_bodies;
+    const BodyEntry *bodies;
+    const double *coeffs;
+    const int *ncoef;
+    const eph_plot_request *req;
+    eph_plot_view view;
+    const double *knot_t, *knot_pos, *knot_vel;
+    long long capacity;
+    double *out_t;
+    float *out_xyz;
+    long long *out_count;
+    int *out_status;
+    double *out_failed_at;
+};
+// UniformSpline::state_vector / position of body b  (trajectory.rs:449-470)
+__device__ bool plot_body_sv(const PlotArgs &a, int b, double t, V3 &pos, V3 &vel) {
+    const BodyEntry be = a.bodies[b];
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) return false;
+    const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+    const int nc = a.ncoef[be.coeff_off + idx];
+    double rp[3], rv[3];
+    for (int c = 0; c < 3; ++c) {                     // Polynomial::eval_and_deriv
+        const double first = nc ? co[c] : 0.0;
+        const double last = nc ? co[(nc - 1) * 3 + c] : 0.0;
+        double e = last, d = last;
+        for (int k = nc - 2; k >= 1; --k) {
+            e = e * tau + co[k * 3 + c];
+            d = d * tau + e;
+        }
+        e = e * tau + first;
+        rp[c] = e;
+        rv[c] = d / be.interval;
+    }
+    pos = {rp[0], rp[1], rp[2]};
+    vel = {rv[0], rv[1], rv[2]};
+    return true;
+}
+__device__ bool plot_body_pos(const PlotArgs &a, int b, double t, V3 &out) {
+    const BodyEntry be = a.bodies[b];
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) return false;
+    const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+    const int nc = a.ncoef[be.coeff_off + idx];
+    V3 bp = {0.0, 0.0, 0.0};
+    for (int k = nc - 1; k >= 0; --k) {               // Polynomial::eval (Horner)
+        bp.x = bp.x * tau + co[k * 3 + 0];
+        bp.y = bp.y * tau + co[k * 3 + 1];
+        bp.z = bp.z * tau + co[k * 3 + 2];
+    }
+    out = bp;
+    return true;
+}
+// CubicHermiteSpline::state_vector (trajectory.rs:766-797) on knots [0, nk) of t / pos / vel
+__device__ bool plot_hermite_sv(long long nk, const double *t, const double *pos, const double *vel, double x, V3 &p, V3 &v) {
+    long long lo = 0, hi = nk, hit = -1;
+    while (lo < hi) {                                 // binary_search_by(|(t, _)| t.cmp(&at))
+        const long long mid = lo + (hi - lo) / 2;
+        const double tm = t[mid];
+        if (tm == x) { hit = mid; break; }
+        if (tm < x) lo = mid + 1; else hi = mid;
+    }
+    if (hit >= 0) {
+        p = {pos[hit * 3], pos[hit * 3 + 1], pos[hit * 3 + 2]};
+        v = {vel[hit * 3], vel[hit * 3 + 1], vel[hit * 3 + 2]};
+        return true;
+    }
+    if (lo == 0 || lo >= nk) return false;            // i.checked_sub(1)? / self.0.get(i + 1)?
+    const long long i = lo - 1;
+    const double b0 = t[i], dt = t[i + 1] - b0;
+    const double dt_recip = 1.0 / dt;
+    const double dt_recip_2 = dt_recip * dt_recip;
+    const double dt_recip_3 = dt_recip * dt_recip_2;
+    const double s = x - b0;
+    double op[3], ov[3];
+    for (int c = 0; c < 3; ++c) {
+        const double v0 = pos[i * 3 + c], v1 = pos[(i + 1) * 3 + c], d0 = vel[i * 3 + c], d1 = vel[(i + 1) * 3 + c];
+        const double dt_val = v1 - v0;
+        const double a2 = dt_val * dt_recip_2 * 3.0 - (d0 * 2.0 + d1) * dt_recip;
+        const double a3 = dt_val * dt_recip_3 * -2.0 + (d0 + d1) * dt_recip_2;
+        op[c] = (((a3 * s + a2) * s) + d0) * s + v0;
+        ov[c] = ((a3 * s * 3.0 + a2 * 2.0) * s) + d0;
+    }
+    p = {op[0], op[1], op[2]};
+    v = {ov[0], ov[1], ov[2]};
+    return true;
+}
+// glam DMat3::mul_vec3: ((x_axis * v.x) + (y_axis * v.y)) + (z_axis * v.z)   (glam 0.30.10)
+__device__ __forceinline__ V3 mat3_mul(const double (&m)[9], V3 v) {
+    const V3 x = {m[0], m[1], m[2]}, y = {m[3], m[4], m[5]}, z = {m[6], m[7], m[8]};
+    return add(add(scale(x, v.x), scale(y, v.y)), scale(z, v.z));
+}
+// angular_distance  plot.rs:429-436: DVec3::normalize = self * self.length().recip()
+__device__ __forceinline__ double plot_angular_distance(V3 cam, V3 p1, V3 p2) {
+    const V3 d1 = sub(p1, cam), d2 = sub(p2, cam);
+    const V3 v1 = scale(d1, length_recip(d1)), v2 = scale(d2, length_recip(d2));
+    const V3 w = cross(v1, v2);
+    const double d = dot(v1, v2);
+    return dot(w, w) / (d * d);
+}
+__device__ __forceinline__ double ord_clamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+__global__ void __launch_bounds__(64) k_plot_points(const PlotArgs a) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_plots) return;
+    const eph_plot_request rq = a.req[p];
+    a.out_count[p] = 0;
+    a.out_status[p] = EPH_OK;
+    a.out_failed_at[p] = 0.0;
+    const bool src_body = rq.source_body >= 0;
+    const double *kt = a.knot_t + rq.knot_first, *kp = a.knot_pos + 3 * rq.knot_first, *kv = a.knot_vel + 3 * rq.knot_first;
+    const long long nk = rq.knot_count;
+    // RelativeTrajectory bounds / segment count  trajectory.rs:277-308
+    double start, end;
+    long long segs;
+    if (src_body) {
+        const BodyEntry be = a.bodies[rq.source_body];
+        start = be.start; end = be.start + be.span; segs = be.npoly;
+    } else {
+        start = nk > 0 ? kt[0] : -1.7976931348623157e308;          // Epoch::MIN / MAX of an empty spline :756-763
+        end = nk > 0 ? kt[nk - 1] : 1.7976931348623157e308;
+        segs = nk > 0 ? nk - 1 : 0;
+    }
+    double rstart = 0.0, rend = 0.0;
+    if (rq.reference_body >= 0) {
+        const BodyEntry rb = a.bodies[rq.reference_body];
+        rstart = rb.start; rend = rb.start + rb.span;
+        start = rstart < start ? start : rstart;                    // Ord::max / Ord::min
+        end = rend < end ? rend : end;
+        segs = rb.npoly < segs ? rb.npoly : segs;
+    }
+    if (!rq.enabled || segs == 0 || start > end) return;            // plot.enabled && !relative.is_empty()  :324
+    const double current = a.view.current;
+    const double current_clamped = ord_clamp(current, start, end);
+    double tmin = ord_clamp(rq.start, start, end), tmax = ord_clamp(rq.end, start, end);
+    if (rq.bound == 1) tmin = current_clamped < tmin ? tmin : current_clamped;      // min.max(current_clamped)
+    else if (rq.bound == 2) tmax = current_clamped < tmax ? current_clamped : tmax; // max.min(current_clamped)
+    if (tmin >= tmax) return;
+    // translation: reference.position(current.clamp(r.start(), r.end())).unwrap()  :355-361
+    V3 tr = {0.0, 0.0, 0.0};
+    if (rq.reference_body >= 0) {
+        const double tc = ord_clamp(current, rstart, rend);
+        if (!plot_body_pos(a, rq.reference_body, tc, tr)) { a.out_status[p] = EPH_EVAL_FAILED; a.out_failed_at[p] = tc; return; }
+    }
+    const V3 cam = {a.view.camera_position[0], a.view.camera_position[1], a.view.camera_position[2]};
+    const V3 cell = {a.view.cell_offset[0], a.view.cell_offset[1], a.view.cell_offset[2]};
+    const V3 gt = {a.view.grid_translation[0], a.view.grid_translation[1], a.view.grid_translation[2]};
+    // |t| Some(root.to_global_sv(relative.state_vector(t)? + translation))
+    auto eval = [&](double t, V3 &gp, V3 &gv) -> bool {
+        V3 rp = {0.0, 0.0, 0.0}, rv = {0.0, 0.0, 0.0};              // reference first (trajectory.rs:329-333)
+        if (rq.reference_body >= 0 && !plot_body_sv(a, rq.reference_body, t, rp, rv)) return false;
+        V3 sp, sv;
+        if (src_body ? !plot_body_sv(a, rq.source_body, t, sp, sv) : !plot_hermite_sv(nk, kt, kp, kv, t, sp, sv)) return false;
+        const V3 pos = add(sub(sp, rp), tr);
+        const V3 vel = add(sub(sv, rv), V3{0.0, 0.0, 0.0});         // + StateVector::from_position(..).velocity
+        gp = add(mat3_mul(a.view.grid_matrix3, sub(pos, cell)), gt);   // transform_point3(point - cell_to_float)
+        gv = mat3_mul(a.view.grid_matrix3, vel);                    // transform_vector3
+        return true;
+    };
+    if (rq.max_points == 0) return;                                 // :101-103
+    const double target = rq.tan2_angular_resolution * rq.tan2_angular_resolution;
+    double previous_time = tmin;
+    V3 ppos, pvel;
+    if (!eval(previous_time, ppos, pvel)) { a.out_status[p] = EPH_EVAL_FAILED; a.out_failed_at[p] = previous_time; return; }
+    double delta = tmax - previous_time;
+    bool have_est = false;
+    double estimated = 0.0;
+    double *ot = a.out_t + p * a.capacity;
+    float *ox = a.out_xyz + p * a.capacity * 3;
+    long long np = 0;
+    auto push = [&](double t, V3 q) { ot[np] = t; ox[3 * np] = (float)q.x; ox[3 * np + 1] = (float)q.y; ox[3 * np + 2] = (float)q.z; ++np; };
+    push(previous_time, ppos);
+    while (previous_time < tmax && np < rq.max_points) {
+        double t, next_error;
+        V3 cpos, cvel;
+        for (unsigned trial = 0;; ++trial) {
+            if (have_est && estimated > 0.0) delta = delta * 0.9 * sqrt(sqrt(target / estimated));
+            t = previous_time + delta;
+            if (t > tmax) t = tmax;
+            delta = t - previous_time;
+            const V3 extrapolated = add(ppos, scale(pvel, delta));
+            if (!eval(t, cpos, cvel)) { a.out_count[p] = np; a.out_status[p] = EPH_EVAL_FAILED; a.out_failed_at[p] = t; return; }
+            const double error = plot_angular_distance(cam, extrapolated, cpos) / 16.0;
+            if (error <= target) { next_error = error; break; }
+            have_est = true;
+            estimated = error;
+            if (trial >= (1u << 20)) { a.out_count[p] = np; a.out_status[p] = EPH_MAX_ITERATIONS_REACHED; a.out_failed_at[p] = t; return; }
+        }
+        previous_time = t;
+        ppos = cpos;
+        pvel = cvel;
+        have_est = true;
+        estimated = next_error;
+        push(t, ppos);
+    }
+    a.out_count[p] = np;
+}
+
 // few spacecraft: one wave each (k_craft_wave, k_craft_events<true>); many: one thread each. Measured crossover on
 // MI355X, Verner87, 32 bodies: see scripts/bench_craft_small.py and profiles/README.md
 static bool craft_wave_form(long long n_craft) {
@@ -1774,6 +1980,64 @@ int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos, con
         EPH_HIP(hipMemcpy(op, dop.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
         if (ov) EPH_HIP(hipMemcpy(ov, dov.p, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
         EPH_HIP(hipMemcpy(inside, din.p, m, hipMemcpyDeviceToHost));
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+
+int32_t eph_plot_points(const eph_ephemeris *e, const eph_plot_view *view, int64_t n_plots, const eph_plot_request *requests,
+                        int64_t n_knots, const double *knot_t, const double *knot_pos, const double *knot_vel,
+                        int64_t capacity, double *out_t, float *out_xyz, int64_t *out_count, int32_t *out_status,
+                        double *out_failed_at) {
+    try {
+        if (!e || !view || n_plots < 0 || n_knots < 0 || capacity < 0 || (n_plots > 0 && (!requests || !out_count || !out_status || !out_failed_at)) ||
+            (n_knots > 0 && (!knot_t || !knot_pos || !knot_vel)) || (n_plots > 0 && capacity > 0 && (!out_t || !out_xyz)))
+            return EPH_ERR_BAD_ARGUMENT;
+        for (int64_t p = 0; p < n_plots; ++p) {
+            const eph_plot_request &r = requests[p];
+            if (r.source_body >= e->n_bodies || r.reference_body >= e->n_bodies || r.reference_body < -1 || r.source_body < -1 ||
+                r.max_points < 0 || r.max_points > capacity || r.bound < 0 || r.bound > 2)
+                return EPH_ERR_BAD_ARGUMENT;
+            if (r.source_body < 0 && (r.knot_first < 0 || r.knot_count < 0 || r.knot_first + r.knot_count > n_knots))
+                return EPH_ERR_BAD_ARGUMENT;
+        }
+        int st = check_device();
+        if (st) return st;
+        if (n_plots == 0) return EPH_OK;
+        EPH_HIP(hipSetDevice(e->device));
+        const size_t nk = (size_t)std::max<int64_t>(n_knots, 1), np = (size_t)n_plots, cap = (size_t)std::max<int64_t>(capacity, 1);
+        DevBuf<eph_plot_request> d_req;
+        DevBuf<double> d_kt, d_kp, d_kv, d_t, d_fail;
+        DevBuf<float> d_xyz;
+        DevBuf<long long> d_cnt;
+        DevBuf<int> d_st;
+        if ((st = d_req.alloc(np)) || (st = d_kt.alloc(nk)) || (st = d_kp.alloc(3 * nk)) || (st = d_kv.alloc(3 * nk)) ||
+            (st = d_t.alloc(np * cap)) || (st = d_xyz.alloc(3 * np * cap)) || (st = d_cnt.alloc(np)) || (st = d_st.alloc(np)) ||
+            (st = d_fail.alloc(np)))
+            return st;
+        EPH_HIP(hipMemcpy(d_req.p, requests, sizeof(eph_plot_request) * np, hipMemcpyHostToDevice));
+        if (n_knots) {
+            EPH_HIP(hipMemcpy(d_kt.p, knot_t, sizeof(double) * n_knots, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(d_kp.p, knot_pos, sizeof(double) * 3 * n_knots, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(d_kv.p, knot_vel, sizeof(double) * 3 * n_knots, hipMemcpyHostToDevice));
+        }
+        PlotArgs a{};
+        a.n_plots = n_plots; a.n_bodies = e->n_bodies;
+        a.bodies = e->bodies.p; a.coeffs = e->coeffs.p; a.ncoef = e->ncoef.p;
+        a.req = d_req.p; a.view = *view;
+        a.knot_t = d_kt.p; a.knot_pos = d_kp.p; a.knot_vel = d_kv.p;
+        a.capacity = capacity; a.out_t = d_t.p; a.out_xyz = d_xyz.p; a.out_count = d_cnt.p; a.out_status = d_st.p;
+        a.out_failed_at = d_fail.p;
+        hipLaunchKernelGGL(k_plot_points, dim3((unsigned)((n_plots + 63) / 64)), dim3(64), 0, nullptr, a);
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) { set_last_error("k_plot_points", he); return EPH_ERR_HIP; }
+        static_assert(sizeof(long long) == sizeof(int64_t), "count type");
+        EPH_HIP(hipMemcpy(out_count, d_cnt.p, sizeof(int64_t) * np, hipMemcpyDeviceToHost));
+        EPH_HIP(hipMemcpy(out_status, d_st.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost));
+        EPH_HIP(hipMemcpy(out_failed_at, d_fail.p, sizeof(double) * np, hipMemcpyDeviceToHost));
+        if (capacity > 0) {
+            EPH_HIP(hipMemcpy(out_t, d_t.p, sizeof(double) * np * cap, hipMemcpyDeviceToHost));
+            EPH_HIP(hipMemcpy(out_xyz, d_xyz.p, sizeof(float) * 3 * np * cap, hipMemcpyDeviceToHost));
+        }
         return EPH_OK;
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }

@@ -519,7 +519,7 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 //   2: 8 waves  -- wave 0 only keeps the barrier count, pair waves of 3/3/3, the chain wave, pair waves of 3/2/2: the
 //                  chain wave has SIMD 0 to itself; SIMDs 1-3 carry 6 / 5 / 5 bodies in two waves each
 constexpr int wg_threads(int layout) { return layout >= 1 ? 64 * 8 : 64 * 5; }
-constexpr int kWgDefaultLayout = 0;
+constexpr int kWgDefaultLayout = 1;   // measured at N = 4096 (us per step): layout 0 47.8, 1 44.8, 2 48.9 (gpurun_out r02c)
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
 constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave

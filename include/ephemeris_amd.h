@@ -303,6 +303,40 @@ void eph_craft_batch_destroy(eph_craft_batch *b);
 int32_t eph_hermite_eval(int64_t nknots, const double *t, const double *pos_xyz, const double *vel_xyz, int64_t m,
                          const double *at, double *out_pos_xyz, double *out_vel_xyz, uint8_t *inside);
 
+/* ---- adaptive plot sampling (ephemeris_explorer/src/ui/world/plot.rs) -------------------------------
+ * compute_plot_points_parallel (:272-374) + PlotPoints::new (:93-149) + angular_distance (:429-436) for a batch of
+ * plotted trajectories, one device thread per plot (the sampler is a sequential adaptive loop per trajectory; the app
+ * runs one per body and ship every frame). A plot's source is a body of the ephemeris (PredictionTrajectory::
+ * UniformSpline) or a ship's CubicHermiteSpline given as knots; its optional reference is a body (PlotSource.reference).
+ * What the UI contributes is passed in as numbers: the camera position and the floating-origin grid's affine map
+ * (GridExt::to_global_sv, floating_origin.rs:28-50: M * (p - cell_offset) + T for points, M * v for vectors). */
+typedef struct eph_plot_view {
+    double camera_position[3];   /* camera_transform.translation().as_dvec3()   plot.rs:430 */
+    double grid_matrix3[9];      /* local_floating_origin().grid_transform().matrix3, column major (x_axis, y_axis, z_axis) */
+    double grid_translation[3];  /* .grid_transform().translation */
+    double cell_offset[3];       /* grid.cell_to_float(&origin.cell()) */
+    double current;              /* sim_time.current(), seconds since 1958-01-01 TAI */
+} eph_plot_view;
+typedef struct eph_plot_request {      /* PlotConfig + PlotSource  plot.rs:15-83 */
+    int32_t source_body;         /* >= 0: body of the ephemeris; -1: the hermite knots [knot_first, knot_first + knot_count) */
+    int32_t reference_body;      /* body index or -1 (None) */
+    int64_t knot_first, knot_count;
+    double start, end;           /* PlotConfig.start / .end */
+    int32_t bound;               /* PlotBound: 0 None, 1 Start, 2 End */
+    int32_t enabled;
+    double tan2_angular_resolution;   /* (plot.threshold * ARC_MINUTE * perspective.fov) as f64   :326-327 */
+    int64_t max_points;
+} eph_plot_request;
+/* out_t[p][k], out_xyz[p][k][3] (f32: `as_vec3()`), k < out_count[p] <= capacity (capacity >= every max_points).
+ * out_status[p]: EPH_OK; EPH_EVAL_FAILED with out_failed_at[p] = the epoch where the reference's closure returns None
+ * (the app then panics, :369); EPH_MAX_ITERATIONS_REACHED when the step-size search did not end within 2^20 trials (a
+ * NaN error estimate makes the reference spin forever). Plots that draw nothing (disabled, empty relative trajectory,
+ * min >= max) have count 0 and EPH_OK. */
+int32_t eph_plot_points(const eph_ephemeris *e, const eph_plot_view *view, int64_t n_plots, const eph_plot_request *requests,
+                        int64_t n_knots, const double *knot_t, const double *knot_pos_xyz, const double *knot_vel_xyz,
+                        int64_t capacity, double *out_t, float *out_xyz, int64_t *out_count, int32_t *out_status,
+                        double *out_failed_at);
+
 /* SpacecraftPropagator::join(lhs, rhs) (ephemeris/src/propagators/spacecraft.rs:558-561; the app's
  * PredictionTarget::merge, ephemeris_explorer/src/dynamics/spacecraft.rs:830-841): lhs.clear_after(rhs.start())
  * -- keep the knots with t < rhs.start() (trajectory.rs:842-845; rhs.start() of an empty spline is Epoch::MIN,

@@ -847,3 +847,81 @@ def hermite_join(lhs, rhs):
     lhs.extend(rhs) (:847-849). Splines are lists of (t, pos, vel)."""
     at = rhs[0][0] if rhs else EPOCH_MIN
     return [k for k in lhs if at > k[0]] + list(rhs)
+
+
+# ---- adaptive plot sampling (ephemeris_explorer/src/ui/world/plot.rs:93-149,318-374,429-436) ---------------------------
+def _f32(x):
+    import struct
+    return struct.unpack("f", struct.pack("f", x))[0]            # DVec3::as_vec3: `as f32`, round to nearest
+
+
+def angular_distance(cam, p1, p2):
+    """plot.rs:429-436 -- tan^2 of the angle between p1 and p2 seen from the camera. glam DVec3::normalize =
+    self * (1 / self.length()), length = sqrt(x*x + y*y + z*z) (glam 0.30.10, Cargo.lock:2890-2892)."""
+    def normalize(v):
+        r = 1.0 / math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        return v * r
+    v1, v2 = normalize(p1 - cam), normalize(p2 - cam)
+    w = Vec(v1[1] * v2[2] - v2[1] * v1[2], v1[2] * v2[0] - v2[2] * v1[0], v1[0] * v2[1] - v2[0] * v1[1])
+    d = v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]
+    return (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) / (d * d)   # wedge.length_squared() / v1.dot(v2).powi(2)
+
+
+def plot_points_new(evaluate, tmin, tmax, cam, tan2_angular_resolution, max_points, max_inner=100000):
+    """PlotPoints::new (plot.rs:93-149). evaluate(t) -> (position Vec, velocity Vec) in global space, or None.
+    Returns ("ok", [(t, (x, y, z) as f32)]) or ("err", t) where the reference returns Err(t). The reference's inner
+    loop never ends if the error is NaN; `max_inner` turns that into ("stuck", t)."""
+    if max_points == 0:
+        return "ok", []
+    target = tan2_angular_resolution * tan2_angular_resolution
+    previous_time = tmin
+    previous = evaluate(previous_time)
+    if previous is None:
+        return "err", previous_time
+    delta = tmax - previous_time
+    estimated = None
+    points = [(previous_time, tuple(_f32(c) for c in previous[0]))]
+    while previous_time < tmax and len(points) < max_points:
+        inner = 0
+        while True:
+            if estimated is not None and estimated > 0.0:
+                delta = delta * 0.9 * math.sqrt(math.sqrt(target / estimated))
+            t = previous_time + delta
+            if t > tmax:
+                t = tmax
+            delta = t - previous_time
+            extrapolated = previous[0] + previous[1] * delta
+            current = evaluate(t)
+            if current is None:
+                return "err", t
+            error = angular_distance(cam, extrapolated, current[0]) / 16.0
+            if error <= target:
+                break
+            estimated = error
+            inner += 1
+            if inner >= max_inner:
+                return "stuck", t
+        previous_time, previous, estimated = t, current, error
+        points.append((t, tuple(_f32(c) for c in previous[0])))
+    return "ok", points
+
+
+def plot_window(traj_bounds, ref_bounds, plot_start, plot_end, bound, current):
+    """compute_plot_points_parallel :329-352: (min, max) of the plotted span, or None when nothing is drawn.
+    traj_bounds / ref_bounds = (start, end, segment_count) (ref_bounds None without a reference); bound 0 None, 1 Start,
+    2 End. Ord::clamp / max / min on Epoch (total order on f64 seconds, ftime/src/duration.rs:162-180)."""
+    clamp = lambda x, lo, hi: lo if x < lo else (hi if x > hi else x)      # noqa: E731
+    start, end, segs = traj_bounds
+    if ref_bounds is not None:
+        start, end, segs = max(start, ref_bounds[0]), min(end, ref_bounds[1]), min(segs, ref_bounds[2])
+    if segs == 0 or start > end:                    # is_empty(); clamp(min > max) would panic in the reference
+        return None
+    current_clamped = clamp(current, start, end)
+    tmin, tmax = clamp(plot_start, start, end), clamp(plot_end, start, end)
+    if bound == 1:
+        tmin = tmin if current_clamped < tmin else current_clamped          # Ord::max
+    elif bound == 2:
+        tmax = current_clamped if current_clamped < tmax else tmax          # Ord::min
+    if tmin >= tmax:
+        return None
+    return tmin, tmax

@@ -63,10 +63,13 @@ def test_fast_path_with_solout_sampling(gpu):
     b = gpu.NBodyPropagator(pos, vel, mu, 0.0, H, gpu.FORWARD, count, degree)
     b.integration().set_path(FAST)
     sa, sb = a.propagate(200 * H), b.propagate(200 * H)
-    for body in (0, 100, 255):
-        assert sa.info(body) == sb.info(body)
+    differing = 0
+    for body in range(n):
+        assert sa.info(body) == sb.info(body) and sa.info(body)[2] == 12
         ca, cb = sa.coeffs(body)[0], sb.coeffs(body)[0]
-        assert np.abs(ca - cb).max() < 1e-9 and not np.array_equal(ca, cb)
+        assert np.abs(ca - cb).max() < 1e-9
+        differing += not np.array_equal(ca, cb)
+    assert differing > n // 4            # round-off level, but not the ordered path's bits
 
 
 def test_fast_path_divergence_at_the_metric_size(gpu):
