@@ -31,6 +31,65 @@ def export_state(system, solution, at, path):
     Path(path).write_text(json.dumps({"name": system.name, "epoch": format_epoch(at), "bodies": bodies}, indent=4))
 
 
+class Run:
+    """What the headless flow produced: the system, the forward / backward Vec<UniformSpline> and per ship the batch (knot
+    slabs, events) -- `main` prints a summary of it, tests compare it with the CPU restatement."""
+
+    def __init__(self, system):
+        self.system, self.forward, self.backward = system, None, None
+        self.fwd_prop, self.bwd_prop = None, None
+        self.ships = []          # (ShipFile, burns or None, SpacecraftBatch or None, reason skipped or None)
+        self.ephemeris_seconds = 0.0
+
+
+def run(system_dir, years=2.0, backward=True):
+    """load a system directory -> +-`years` of ephemeris (forward and backward propagators concurrently, as
+    compute_ephemerides_bodies does, load/mod.rs:673-687) -> every ship under ships/ with the app's SpacecraftSolout."""
+    import threading
+    system = load_system(system_dir)
+    r = Run(system)
+    t0 = time.time()
+    # forward and backward propagators run concurrently, one host thread and one HIP stream each -- the reference
+    # runs them as two async tasks (prediction.rs:422-443, load/mod.rs:673-687)
+    r.fwd_prop = NBodyPropagator.from_system(system, FORWARD)
+    r.bwd_prop = NBodyPropagator.from_system(system, BACKWARD) if backward else None
+    sols = {}
+
+    def go(key, prop, until):
+        sols[key] = prop.propagate(until)
+
+    threads = [threading.Thread(target=go, args=("f", r.fwd_prop, system.epoch + years * SEC_PER_YEAR))]
+    if r.bwd_prop is not None:
+        threads.append(threading.Thread(target=go, args=("b", r.bwd_prop, system.epoch - years * SEC_PER_YEAR)))
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if "f" not in sols or (r.bwd_prop is not None and "b" not in sols):
+        raise SystemExit("ephemeris propagation failed")
+    r.forward, r.backward = sols["f"], sols.get("b")
+    r.ephemeris_seconds = time.time() - t0
+
+    system_dir = Path(system_dir)
+    ships = sorted((system_dir / "ships").glob("*.json")) if (system_dir / "ships").is_dir() else []
+    eph = Ephemeris(r.forward, system.mu) if ships else None
+    soi = soi_radii(system)
+    for path in ships:
+        ship = load_ship(path)
+        try:
+            burns = [(b.start, b.start + b.duration, b.acceleration,
+                      system.names.index(b.reference) if b.reference else -1) for b in ship.burns]
+        except ValueError as e:
+            r.ships.append((ship, None, None, f"burn reference not in this system: {e}"))
+            continue
+        batch = SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator,
+                                AdaptiveParams.default(ship.tolerance), [burns], max_knots=1 << 18)
+        batch.enable_events(soi, max_transitions=256, max_apsides=1 << 16)      # the app's SpacecraftSolout
+        batch.propagate(ship.end)
+        r.ships.append((ship, burns, batch, None))
+    return r
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("system", type=Path)
@@ -40,55 +99,23 @@ def main(argv=None):
                     help='write a state.json at "YYYY-MM-DD HH:MM:SS" from the forward ephemeris')
     args = ap.parse_args(argv)
 
-    system = load_system(args.system)
+    r = run(args.system, args.years, not args.no_backward)
+    system, sol_f, fwd, bwd = r.system, r.forward, r.fwd_prop, r.bwd_prop
     out = {"system": system.name, "bodies": system.n, "dt_s": system.dt, "epoch": format_epoch(system.epoch)}
-    t0 = time.time()
-    # forward and backward propagators run concurrently, one host thread and one HIP stream each -- the reference
-    # runs them as two async tasks (prediction.rs:422-443, load/mod.rs:673-687)
-    import threading
-    fwd = NBodyPropagator.from_system(system, FORWARD)
-    bwd = None if args.no_backward else NBodyPropagator.from_system(system, BACKWARD)
-    sols = {}
-
-    def run(key, prop, until):
-        sols[key] = prop.propagate(until)
-
-    threads = [threading.Thread(target=run, args=("f", fwd, system.epoch + args.years * SEC_PER_YEAR))]
-    if bwd is not None:
-        threads.append(threading.Thread(target=run, args=("b", bwd, system.epoch - args.years * SEC_PER_YEAR)))
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    if "f" not in sols or (bwd is not None and "b" not in sols):
-        raise SystemExit("ephemeris propagation failed")
-    sol_f = sols["f"]
     out["forward"] = {"reached": format_epoch(fwd.time()), "steps": fwd.state()[3],
                       "polynomials": int(sum(sol_f.info(b)[2] for b in range(system.n)))}
     if bwd is not None:
-        sol_b = sols["b"]
+        sol_b = r.backward
         out["backward"] = {"reached": format_epoch(bwd.time()), "steps": bwd.state()[3],
                            "polynomials": int(sum(sol_b.info(b)[2] for b in range(system.n)))}
-    out["ephemeris_seconds"] = time.time() - t0
-
-    ships = sorted((args.system / "ships").glob("*.json")) if (args.system / "ships").is_dir() else []
-    eph = Ephemeris(sol_f, system.mu) if ships else None
-    soi = soi_radii(system)
+    out["ephemeris_seconds"] = r.ephemeris_seconds
     out["ships"] = []
-    for path in ships:
-        ship = load_ship(path)
+    for ship, burns, batch, skipped in r.ships:
         entry = {"name": ship.name, "integrator": ship.integrator}
-        try:
-            burns = [(b.start, b.start + b.duration, b.acceleration,
-                      system.names.index(b.reference) if b.reference else -1) for b in ship.burns]
-        except ValueError as e:
-            entry["skipped"] = f"burn reference not in this system: {e}"
+        if skipped:
+            entry["skipped"] = skipped
             out["ships"].append(entry)
             continue
-        batch = SpacecraftBatch(eph, ship.start, [ship.pos], [ship.vel], ship.integrator,
-                                AdaptiveParams.default(ship.tolerance), [burns], max_knots=1 << 18)
-        batch.enable_events(soi, max_transitions=256, max_apsides=1 << 16)      # the app's SpacecraftSolout
-        batch.propagate(ship.end)
         st = batch.status()
         fin = batch.state()
         entry.update({"status": int(st["status"][0]), "knots": int(st["nknots"][0]), "steps": int(st["steps"][0]),

@@ -518,7 +518,10 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 //                  waves (5 bodies together) that fill each other's dependency stalls; SIMD 0 the chain + one body
 //   2: 8 waves  -- wave 0 only keeps the barrier count, pair waves of 3/3/3, the chain wave, pair waves of 3/2/2: the
 //                  chain wave has SIMD 0 to itself; SIMDs 1-3 carry 6 / 5 / 5 bodies in two waves each
+//   3: layout 1's roles with ONE barrier per 128 sources (two 64-source tiles, six LDS buffers): half the barriers,
+//                  and every pair wave carries twice as many independent interactions between them
 constexpr int wg_threads(int layout) { return layout >= 1 ? 64 * 8 : 64 * 5; }
+constexpr int wg_bufs(int layout) { return layout == 3 ? 6 : 3; }
 constexpr int kWgDefaultLayout = 1;   // measured at N = 4096 (us per step): layout 0 47.8, 1 44.8, 2 48.9 (gpurun_out r02c)
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
@@ -593,6 +596,76 @@ __device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, 
     if ((dbg & 4) && blockIdx.x == 7 && lane == 0 && b0 == 0) { g_wg_cycles[2] = t_work; g_wg_cycles[3] = t_bar; }
 }
 
+// two 64-source tiles at once (layout 3): 2 x NB independent interactions for the scheduler to interleave
+template <int NB>
+__device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const double (&yi)[NB], const double (&zi)[NB],
+                                              const Body4 &pa, const Body4 &pb, bool ieee, double *tile_a, double *tile_b,
+                                              int b0, int lane) {
+    PairPre pre[2 * NB];
+    unsigned worst = ieee ? kRangeSpan : 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        pre[b] = pair_pre(xi[b], yi[b], zi[b], pa);
+        pre[NB + b] = pair_pre(xi[b], yi[b], zi[b], pb);
+        worst = max(worst, max(range_key(pre[b].n2), range_key(pre[NB + b].n2)));
+    }
+    double c[6 * NB];
+    if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            pair_finish<true>(pre[b], pa.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
+            pair_finish<true>(pre[NB + b], pb.mu, c[3 * (NB + b)], c[3 * (NB + b) + 1], c[3 * (NB + b) + 2]);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            pair_finish<false>(pre[b], pa.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
+            pair_finish<false>(pre[NB + b], pb.mu, c[3 * (NB + b)], c[3 * (NB + b) + 1], c[3 * (NB + b) + 2]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) {
+        tile_a[(3 * b0 + q) * kRow + lane] = c[q];
+        tile_b[(3 * b0 + q) * kRow + lane] = c[3 * NB + q];
+    }
+}
+// Layout 3 barrier schedule (every wave executes TB + 1 barriers, TB = ceil(tiles / 2) "big" tiles of two 64-source
+// tiles): B_0 after tiles 0..3 are in LDS; iteration T: pair waves produce tiles 2T+4, 2T+5 into buffers (2T+4)%6,
+// (2T+5)%6 while the chain wave sums tiles 2T, 2T+1; barrier.
+template <int NB, typename PosPtr>
+__device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag) {
+    double xi[NB], yi[NB], zi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int ii = min(i0 + b0 + b, n - 1);
+        xi[b] = pos[ii].x;
+        yi[b] = pos[ii].y;
+        zi[b] = pos[ii].z;
+    }
+    auto load_src = [&](int t) -> Body4 {
+        const int j = min(t, tiles - 1) * kTile + lane;
+        return pos[j < n ? j : n - 1];
+    };
+    auto produce = [&](int t, const Body4 &pa, const Body4 &pb) {          // tiles t, t + 1 (t even)
+        if (t >= tiles) return;
+        double *ta = C + (t % 6) * kWgBuf, *tb = C + ((t + 1) % 6) * kWgBuf;
+        if (t + 1 < tiles) wg_pair_tile2<NB>(xi, yi, zi, pa, pb, tdiag == t || tdiag == t + 1, ta, tb, b0, lane);
+        else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
+    };
+    const int TB = (tiles + 1) / 2;
+    Body4 pa = load_src(0), pb = load_src(1), na = load_src(2), nb = load_src(3);
+    produce(0, pa, pb);
+    pa = na; pb = nb; na = load_src(4); nb = load_src(5);
+    produce(2, pa, pb);
+    __syncthreads();
+    for (int T = 0; T < TB; ++T) {
+        pa = na; pb = nb;
+        na = load_src(2 * T + 6); nb = load_src(2 * T + 7);
+        produce(2 * T + 4, pa, pb);
+        __syncthreads();
+    }
+}
+
 // chain over a full tile whose first two chunks are already in q[0], q[1]; leaves the first two chunks of the
 // NEXT tile (row_next, complete since the previous barrier) in q[0], q[1]
 __device__ __forceinline__ double chain_full_pf(const double *row, const double *row_next, double2 (&q)[4][8],
@@ -617,7 +690,18 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
     // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
     // under the denser f64 stream and the step gets slower.)
-    if constexpr (LAYOUT == 2) {
+    if constexpr (LAYOUT == 3) {
+        switch (wave) {
+            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
+            case 1: wg_pair_wave_big<3>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
+            case 2: wg_pair_wave_big<3>(pos, n, i0, 4, C, lane, tiles, tdiag); return 0.0;
+            case 3: wg_pair_wave_big<3>(pos, n, i0, 7, C, lane, tiles, tdiag); return 0.0;
+            case 5: wg_pair_wave_big<2>(pos, n, i0, 10, C, lane, tiles, tdiag); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag); return 0.0;
+            case 7: wg_pair_wave_big<2>(pos, n, i0, 14, C, lane, tiles, tdiag); return 0.0;
+            default: break;
+        }
+    } else if constexpr (LAYOUT == 2) {
         switch (wave) {
             case 0: for (int t = 0; t <= tiles; ++t) __syncthreads(); return 0.0;   // tiles + 1 barriers, like every wave
             case 1: wg_pair_wave<3>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
@@ -658,9 +742,31 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     double2 q[4][8];
     long long t_work = 0, t_bar = 0;
     const long long c_start = __builtin_readcyclecounter();
-    __syncthreads();                                  // B_0: tiles 0 and 1 ready
+    __syncthreads();                                  // B_0: tiles 0 and 1 ready (layout 3: 0..3)
     load_chunk(row, 0, q[0]);
     load_chunk(row, 1, q[1]);
+    if constexpr (LAYOUT == 3) {
+        const int TB = (tiles + 1) / 2;
+        for (int T = 0; T < TB; ++T) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int t = 2 * T + hf;
+                if (t >= tiles) break;
+                const double *r = row + (t % 6) * kWgBuf;
+                const double *rn = row + ((t + 1) % 6) * kWgBuf;   // complete since the previous barrier
+                const int cnt = min(kTile, n - t * kTile);
+                if (t != tdiag && cnt == kTile) {
+                    acc = chain_full_pf(r, rn, q, acc);
+                } else {
+                    chain_masked<kWgBodies>(r, cnt, t == tdiag ? gself : -1, li, acc, accL);
+                    load_chunk(rn, 0, q[0]);
+                    load_chunk(rn, 1, q[1]);
+                }
+            }
+            __syncthreads();                          // big tile T consumed, big tile T + 2 ready
+        }
+        return accL + acc;
+    }
     for (int t = 0; t < tiles; ++t) {
         const long long c0 = __builtin_readcyclecounter();
         const double *r = row + (t % kWgBufs) * kWgBuf;
@@ -688,7 +794,7 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
                                                          const double *__restrict__ acc_init,
                                                          double *__restrict__ acc_out, int dbg, int lo, int hi) {
-    __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
+    __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
     const int i0 = lo + blockIdx.x * kWgBodies;
     const int my_i = i0 + lane / 3, cc = lane % 3;
@@ -701,7 +807,7 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad
 // One launch per integrator step, workgroup-specialised force (see k_lm_step for the step structure).
 template <int L, int LAYOUT>
 __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs a) {
-    __shared__ __attribute__((aligned(16))) double C[kWgBufs * kWgBuf];
+    __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool chain_wave = (tid >> 6) == kWgPairWaves;
     const int i0 = a.lo + blockIdx.x * kWgBodies;
@@ -1389,7 +1495,7 @@ int lm_bodies_per_wave(int n) {
 // (1 no chain, 2 no pair work, 4 cycle accounting into g_wg_cycles, 8 chain wave at raised priority)
 static int wg_layout() {
     static const int v = [] { const char *e = getenv("EPH_WG_LAYOUT"); return e ? atoi(e) : kWgDefaultLayout; }();
-    return v == 1 || v == 2 ? v : 0;
+    return v >= 1 && v <= 3 ? v : 0;
 }
 static int wg_debug_flags() {
     static const int v = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
@@ -1416,7 +1522,9 @@ int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double 
     if (force_kernel_kind(nt, kind) == 2) {
         const int dbg = wg_debug_flags();
         const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
-        if (wg_layout() == 2)
+        if (wg_layout() == 3)
+            hipLaunchKernelGGL(k_accel_wg<3>, grid, dim3(wg_threads(3)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+        else if (wg_layout() == 2)
             hipLaunchKernelGGL(k_accel_wg<2>, grid, dim3(wg_threads(2)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
         else if (wg_layout() == 1)
             hipLaunchKernelGGL(k_accel_wg<1>, grid, dim3(wg_threads(1)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
@@ -1455,7 +1563,9 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
         LmArgs b = a;
         b.wg_flags = wg_debug_flags() & 8;             // only the priority knob; the cycle accounting is k_accel_wg's
         const int lay = wg_layout();
-        if (a.L == 12 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<12, 2>), grid, dim3(wg_threads(2)), 0, s, b);
+        if (a.L == 12 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<12, 3>), grid, dim3(wg_threads(3)), 0, s, b);
+        else if (a.L == 13 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<13, 3>), grid, dim3(wg_threads(3)), 0, s, b);
+        else if (a.L == 12 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<12, 2>), grid, dim3(wg_threads(2)), 0, s, b);
         else if (a.L == 13 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<13, 2>), grid, dim3(wg_threads(2)), 0, s, b);
         else if (a.L == 12 && lay == 1) hipLaunchKernelGGL((k_lm_step_wg<12, 1>), grid, dim3(wg_threads(1)), 0, s, b);
         else if (a.L == 12) hipLaunchKernelGGL((k_lm_step_wg<12, 0>), grid, dim3(wg_threads(0)), 0, s, b);

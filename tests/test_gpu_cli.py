@@ -1,0 +1,88 @@
+"""-m gpu: SURVEY 8(f)1 -- the headless flow over the reference's on-disk formats (state.json, ephemeris.json,
+ships/*.json): what cli.run produces on the reference's own `full_solar_system_2433282.5` (32 bodies, 3 ships) compared
+with the CPU restatement, not just counted: forward and backward ephemerides of every body (spline bounds, coefficients,
+trimmed lengths) and, per ship, outcome, every knot and the app's SpacecraftSolout events -- bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import SYSTEMS
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_cli_run_matches_the_restatement(gpu):
+    from ephemeris_explorer_amd import cli
+    from ephemeris_explorer_amd.systems import soi_radii
+    years = 2.0
+    r = cli.run(SYSTEMS / "full_solar_system_2433282.5", years)
+    s = r.system
+    assert s.n == 32 and len(r.ships) == 3
+    span = years * cli.SEC_PER_YEAR
+    oracle_solutions = {}
+    for direction, sol in ((1, r.forward), (-1, r.backward)):
+        o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, direction, s.count, s.degree, native=True)
+        assert o.step_to(s.epoch + direction * span) == 0
+        osol = o.take_solution()
+        oracle_solutions[direction] = osol
+        polys = 0
+        for b in range(s.n):
+            assert sol.info(b) == osol.info(b), (direction, s.names[b])
+            cg, ng = sol.coeffs(b)
+            co, no = osol.coeffs(b)
+            assert np.array_equal(ng, no) and np.array_equal(bits(cg), bits(co)), (direction, s.names[b])
+            polys += len(ng)
+        assert polys > 10000
+    assert r.fwd_prop.time() >= s.epoch + span and r.bwd_prop.time() <= s.epoch - span
+    # ships: the three of the reference's directory, with their burns in Earth / Sun / Mars / Moon / Jupiter ... frames
+    soi = soi_radii(s)
+    osol = oracle_solutions[1]
+    seen = {}
+    for ship, burns, batch, skipped in r.ships:
+        assert skipped is None, skipped
+        c = orc.Craft(osol, s.mu, ship.start, ship.pos, ship.vel, ship.integrator, tol_pos=ship.tolerance,
+                      tol_vel=ship.tolerance, burns=burns, soi_radius=soi)
+        want = c.step_to(ship.end)
+        st = batch.status()
+        assert int(st["status"][0]) == want, ship.name
+        seen[ship.name] = want
+        kt, kp, kv = batch.knots(0)
+        ot, op, ov = c.knots()
+        assert len(kt) == len(ot) and len(kt) > 50, ship.name
+        assert np.array_equal(bits(kt), bits(ot)) and np.array_equal(bits(kp), bits(op)) and np.array_equal(bits(kv), bits(ov)), ship.name
+        (tt, tb), (at, ad, ab, ak) = batch.events(0)
+        ott, otb = c.transitions()
+        oat, oad, oab, oak = c.apsides()
+        assert np.array_equal(bits(tt), bits(ott)) and np.array_equal(tb, otb), ship.name
+        assert np.array_equal(bits(at), bits(oat)) and np.array_equal(bits(ad), bits(oad)), ship.name
+        assert np.array_equal(ab, oab) and np.array_equal(ak, oak), ship.name
+    # the 22-year Voyager plan runs off the end of the +2-year ephemeris: EvalFailed, like the reference's propagator
+    assert seen == {"Mars Transfer Ship": 0, "Moon Transfer Ship": 0, "Voyager Style Ship": orc.EVAL_FAILED}
+
+
+def test_cli_fine45_ship(gpu, tmp_path):
+    """A ships/*.json selecting the app's ERKNG integrator (Fine45, dynamics/spacecraft.rs:797) goes through the headless
+    flow like any other (it used to be skipped)."""
+    import json
+    import shutil
+    from ephemeris_explorer_amd import cli
+    src = SYSTEMS / "sun_earth_moon_2433282.5"
+    dst = tmp_path / "sys"
+    shutil.copytree(src, dst)
+    ship = json.loads((dst / "ships" / "Earth Station.json").read_text())
+    ship["integrator"] = "Fine45"
+    (dst / "ships" / "Earth Station.json").write_text(json.dumps(ship))
+    r = cli.run(dst, 0.1)
+    (sh, burns, batch, skipped), = r.ships
+    assert skipped is None and sh.integrator == "Fine45" and int(batch.status()["status"][0]) == 0
+    o = orc.Propagator(r.system.pos, r.system.vel, r.system.mu, r.system.epoch, r.system.dt, 1, r.system.count, r.system.degree)
+    assert o.step_to(r.system.epoch + 0.1 * cli.SEC_PER_YEAR) == 0
+    c = orc.Craft(o.take_solution(), r.system.mu, sh.start, sh.pos, sh.vel, "Fine45", tol_pos=sh.tolerance, tol_vel=sh.tolerance)
+    assert c.step_to(sh.end) == 0
+    kt, kp, kv = batch.knots(0)
+    ot, op, ov = c.knots()
+    assert np.array_equal(bits(kt), bits(ot)) and np.array_equal(bits(kp), bits(op))
