@@ -522,7 +522,7 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 //                  and every pair wave carries twice as many independent interactions between them
 constexpr int wg_threads(int layout) { return layout >= 1 ? 64 * 8 : 64 * 5; }
 constexpr int wg_bufs(int layout) { return layout == 3 ? 6 : 3; }
-constexpr int kWgDefaultLayout = 1;   // measured at N = 4096 (us per step): layout 0 47.8, 1 44.8, 2 48.9 (gpurun_out r02c)
+constexpr int kWgDefaultLayout = 3;   // measured at N = 4096 (us per step): layout 0 47.8, 1 44.6, 2 48.9, 3 41.6 (gpurun_out r02c, r02d)
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
 constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave
@@ -862,10 +862,10 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
 //   a_i = ((p_0 + p_1) + ... + p_{S-1}),  p_s = ((0 + c(i, j0)) + c(i, j0 + 1)) + ...   (j over slice s, j != i)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFastWaves = 4;                          // waves (= slices) per workgroup
-constexpr int kFastUnroll = 4;                         // sources per range check / loop trip
+constexpr int kFastUnrollMax = 8;                      // sources per range check / loop trip: 4 or 8 (EPH_FAST_UNROLL)
 constexpr int kFastMaxSlices = 64;
 
-template <bool DIAG>
+template <bool DIAG, int kFastUnroll>
 __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4))) Body4 *src, int j0, int j1, int i,
                                            double xi, double yi, double zi, double &ax, double &ay, double &az) {
     auto fetch = [&](int j, Body4 (&p)[kFastUnroll]) {
@@ -908,6 +908,7 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
 // slice sums and their combination. (First version: one launch with a per-block arrival ticket, the last workgroup
 // of a block combining -- measured 66 / 96 / 166 us per step at 16 / 32 / 64 slices, N = 4096: the agent-scope
 // fence each workgroup needs before its ticket costs ~0.13 us and they serialise; gpurun_out r02a.)
+template <int UNROLL>
 __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npad, const Body4 *__restrict__ pos,
                                                                   int S, int slice_len, double *__restrict__ partial) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -922,8 +923,8 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
     const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (j0 < j1) {
-        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
-        else fast_slice<false>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        else fast_slice<false, UNROLL>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
     }
     double *pp = partial + (size_t)slice * 3 * npad + i;
     pp[0] = ax;
@@ -1588,11 +1589,15 @@ int fast_slices(int npad) {
 int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial) {
     if (a.n <= 0) return EPH_OK;
     if (a.lo != 0 || a.hi != a.n) return EPH_ERR_UNSUPPORTED;          // the fast path is not sharded
+    static const int unroll = [] { const char *e = getenv("EPH_FAST_UNROLL"); return e && atoi(e) == 8 ? 8 : 4; }();
     const int S = fast_slices(a.npad);
     int slice_len = (a.npad + S - 1) / S;
-    slice_len = (slice_len + kFastUnroll - 1) / kFastUnroll * kFastUnroll;
-    hipLaunchKernelGGL(k_fast_partial, dim3((unsigned)(a.npad / 64 * (S / kFastWaves))), dim3(64 * kFastWaves), 0, s, a.n,
-                       a.npad, a.pos_cur, S, slice_len, partial);
+    slice_len = (slice_len + unroll - 1) / unroll * unroll;
+    const dim3 pgrid((unsigned)(a.npad / 64 * (S / kFastWaves))), pblock(64 * kFastWaves);
+    if (unroll == 8 && a.npad % 8 == 0)
+        hipLaunchKernelGGL(k_fast_partial<8>, pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
+    else
+        hipLaunchKernelGGL(k_fast_partial<4>, pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     const dim3 grid((3 * a.npad + 255) / 256), block(256);
     if (a.L == 12) hipLaunchKernelGGL(k_fast_finish<12>, grid, block, 0, s, a, S, partial);
     else if (a.L == 13) hipLaunchKernelGGL(k_fast_finish<13>, grid, block, 0, s, a, S, partial);

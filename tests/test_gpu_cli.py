@@ -52,7 +52,7 @@ def test_cli_run_matches_the_restatement(gpu):
         seen[ship.name] = want
         kt, kp, kv = batch.knots(0)
         ot, op, ov = c.knots()
-        assert len(kt) == len(ot) and len(kt) > 50, ship.name
+        assert len(kt) == len(ot) and len(kt) > (50 if want == 0 else 0), ship.name
         assert np.array_equal(bits(kt), bits(ot)) and np.array_equal(bits(kp), bits(op)) and np.array_equal(bits(kv), bits(ov)), ship.name
         (tt, tb), (at, ad, ab, ak) = batch.events(0)
         ott, otb = c.transitions()
@@ -60,7 +60,8 @@ def test_cli_run_matches_the_restatement(gpu):
         assert np.array_equal(bits(tt), bits(ott)) and np.array_equal(tb, otb), ship.name
         assert np.array_equal(bits(at), bits(oat)) and np.array_equal(bits(ad), bits(oad)), ship.name
         assert np.array_equal(ab, oab) and np.array_equal(ak, oak), ship.name
-    # the 22-year Voyager plan runs off the end of the +2-year ephemeris: EvalFailed, like the reference's propagator
+    # the Voyager plan starts in 1977, outside the 1950 +-2-year ephemeris: EvalFailed at once (one knot), like the
+    # reference's propagator
     assert seen == {"Mars Transfer Ship": 0, "Moon Transfer Ship": 0, "Voyager Style Ship": orc.EVAL_FAILED}
 
 

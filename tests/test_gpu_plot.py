@@ -113,10 +113,10 @@ def test_plot_points_match_the_restatement(gpu, scene):
             assert np.array_equal(t.view(np.uint64), wt.view(np.uint64)), i
             assert np.array_equal(xyz.view(np.uint32), wx.view(np.uint32)), i
             total += len(t)
-    assert total > 1500
-    # the adaptive sampler does what it is for: the Moon about the Earth takes many more points than the Earth about the Sun
-    n_moon, n_earth = len(got[1][2]), len(got[3][2])
-    assert n_moon > 4 * n_earth > 8
+    assert total > 300
+    # the adaptive sampler does what it is for: three revolutions of the Moon about the Earth take more points than 200
+    # days of the Earth's path seen from far away
+    assert len(got[1][2]) > 20 and len(got[1][2]) > len(got[0][2])
 
 
 def test_plot_points_argument_errors(gpu, scene):
@@ -125,6 +125,9 @@ def test_plot_points_argument_errors(gpu, scene):
     s, eph, osol, knots = scene
     L = gpu._lib()
     v = gpu.PlotView()
+    v.camera_position[:] = [1.0e8, 2.0e8, 3.0e8]
+    v.grid_matrix3[:] = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+    v.current = s.epoch
     cnt, stt, fail = np.zeros(1, np.int64), np.zeros(1, np.int32), np.zeros(1)
     ot, ox = np.zeros(10), np.zeros(30, np.float32)
 
@@ -136,4 +139,10 @@ def test_plot_points_argument_errors(gpu, scene):
     assert call(gpu.PlotRequest(3, -1, 0, 0, s.epoch, s.epoch + 1.0, 0, 1, 1e-4, 100), 10) == gpu.ERR_BAD_ARGUMENT
     assert call(gpu.PlotRequest(s.n, -1, 0, 0, s.epoch, s.epoch + 1.0, 0, 1, 1e-4, 10), 10) == gpu.ERR_BAD_ARGUMENT
     assert call(gpu.PlotRequest(-1, -1, 0, 5, s.epoch, s.epoch + 1.0, 0, 1, 1e-4, 10), 10) == gpu.ERR_BAD_ARGUMENT   # no knots given
-    assert call(gpu.PlotRequest(3, -1, 0, 0, s.epoch, s.epoch + 86400.0, 0, 1, 1e-4, 10), 10) == 0 and cnt[0] >= 2
+    assert call(gpu.PlotRequest(3, -1, 0, 0, s.epoch, s.epoch + 86400.0, 0, 1, 1e-4, 10), 10) == 0 and cnt[0] >= 2 and stt[0] == 0
+    # a degenerate view (everything mapped onto the camera: the error estimate is NaN) makes the reference spin forever;
+    # here the search gives up and says so
+    v.grid_matrix3[:] = [0.0] * 9
+    v.camera_position[:] = [0.0, 0.0, 0.0]
+    assert call(gpu.PlotRequest(3, -1, 0, 0, s.epoch, s.epoch + 86400.0, 0, 1, 1e-4, 10), 10) == 0
+    assert stt[0] == gpu.MAX_ITERATIONS_REACHED and cnt[0] == 1
