@@ -1511,8 +1511,9 @@ int force_kernel_kind(int n, int requested) {
         return e[1] == 'a' ? 1 : 2;
     }();
     if (forced) return forced;
-    // measured on MI355X (us per step, QT12): n=1024 17 (wg) vs 15 (wave) | 4096: 45-49 vs 56 | 16384: 700 vs 594
-    return (n > 2048 && n < 8192) ? 2 : 1;
+    // measured on MI355X (us per step, QT12; wg = layout 3 | wave): n=1024 17 | 15 (r01), 2048 24.8 | 25.9, 3072 33.5 | 43.9,
+    // 4096 41.6 | 54, 8192 148 | 146, 16384 565 | 569 (gpurun_out r02e)
+    return (n >= 2048 && n < 8192) ? 2 : 1;
 }
 
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind,

@@ -21,6 +21,16 @@ bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
 (dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1) + "\n")
 
 
+for extra in ("bench_fast", "bench_craft", "bench_sharded"):                      # the round's other bench lines
+    f = src / f"{extra}.json"
+    if f.exists() and f.read_text().strip():
+        (dst / f"{tag}_{extra}.json").write_text(json.dumps(json.loads(f.read_text().strip().splitlines()[-1]), indent=1) + "\n")
+for extra in ("fast_stats", "craft_stats"):
+    f = src / f"{extra}_kernel_stats.csv"
+    if f.exists():
+        shutil.copy(f, dst / f"{tag}_{extra.replace('_stats', '')}_kernel_stats.csv")
+
+
 def per_dispatch(name):
     rows = list(csv.DictReader(open(src / f"{name}_counter_collection.csv")))
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -37,6 +47,9 @@ for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
     for k, v in per_dispatch(name).items():
         if "lm_step" in k or "lm_persistent" in k:
             pmc.setdefault(k, {}).update(v)
+if (src / "fast_pmc_sq_counter_collection.csv").exists():
+    fast = {k: v for k, v in per_dispatch("fast_pmc_sq").items() if "k_fast" in k}
+    (dst / f"{tag}_fast_pmc.json").write_text(json.dumps(fast, indent=1) + "\n")
 stats = {r["Name"]: r for r in csv.DictReader(open(src / "stats_kernel_stats.csv"))}
 out = {"note": "per-dispatch averages; SQ_* counters are summed over the chip; FETCH_SIZE/WRITE_SIZE in KiB. "
                "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read, so "

@@ -114,9 +114,8 @@ def test_plot_points_match_the_restatement(gpu, scene):
             assert np.array_equal(xyz.view(np.uint32), wx.view(np.uint32)), i
             total += len(t)
     assert total > 300
-    # the adaptive sampler does what it is for: three revolutions of the Moon about the Earth take more points than 200
-    # days of the Earth's path seen from far away
-    assert len(got[1][2]) > 20 and len(got[1][2]) > len(got[0][2])
+    # the adaptive sampler does what it is for: the step follows the curvature seen from the camera, not a fixed rate
+    assert len(got[1][2]) > 20 and np.ptp(np.diff(got[1][2])) > 0.1 * np.diff(got[1][2]).mean()
 
 
 def test_plot_points_argument_errors(gpu, scene):
