@@ -520,8 +520,10 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 //                  chain wave has SIMD 0 to itself; SIMDs 1-3 carry 6 / 5 / 5 bodies in two waves each
 //   3: layout 1's roles with ONE barrier per 128 sources (two 64-source tiles, six LDS buffers): half the barriers,
 //                  and every pair wave carries twice as many independent interactions between them
+//   4: layout 3's barrier schedule with layout 2's roles (chain wave alone on SIMD 0, pair waves 3/3/3 + 3/2/2)
 constexpr int wg_threads(int layout) { return layout >= 1 ? 64 * 8 : 64 * 5; }
-constexpr int wg_bufs(int layout) { return layout == 3 ? 6 : 3; }
+constexpr bool wg_big(int layout) { return layout == 3 || layout == 4; }
+constexpr int wg_bufs(int layout) { return wg_big(layout) ? 6 : 3; }
 constexpr int kWgDefaultLayout = 3;   // measured at N = 4096 (us per step): layout 0 47.8, 1 44.6, 2 48.9, 3 41.6 (gpurun_out r02c, r02d)
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
@@ -690,7 +692,18 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
     // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
     // under the denser f64 stream and the step gets slower.)
-    if constexpr (LAYOUT == 3) {
+    if constexpr (LAYOUT == 4) {
+        switch (wave) {
+            case 0: for (int T = 0; T <= (tiles + 1) / 2; ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
+            case 1: wg_pair_wave_big<3>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
+            case 2: wg_pair_wave_big<3>(pos, n, i0, 3, C, lane, tiles, tdiag); return 0.0;
+            case 3: wg_pair_wave_big<3>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
+            case 5: wg_pair_wave_big<3>(pos, n, i0, 9, C, lane, tiles, tdiag); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag); return 0.0;
+            case 7: wg_pair_wave_big<2>(pos, n, i0, 14, C, lane, tiles, tdiag); return 0.0;
+            default: break;
+        }
+    } else if constexpr (LAYOUT == 3) {
         switch (wave) {
             case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
             case 1: wg_pair_wave_big<3>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
@@ -745,7 +758,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     __syncthreads();                                  // B_0: tiles 0 and 1 ready (layout 3: 0..3)
     load_chunk(row, 0, q[0]);
     load_chunk(row, 1, q[1]);
-    if constexpr (LAYOUT == 3) {
+    if constexpr (wg_big(LAYOUT)) {
         const int TB = (tiles + 1) / 2;
         for (int T = 0; T < TB; ++T) {
 #pragma unroll
@@ -1496,7 +1509,7 @@ int lm_bodies_per_wave(int n) {
 // (1 no chain, 2 no pair work, 4 cycle accounting into g_wg_cycles, 8 chain wave at raised priority)
 static int wg_layout() {
     static const int v = [] { const char *e = getenv("EPH_WG_LAYOUT"); return e ? atoi(e) : kWgDefaultLayout; }();
-    return v >= 1 && v <= 3 ? v : 0;
+    return v >= 1 && v <= 4 ? v : 0;
 }
 static int wg_debug_flags() {
     static const int v = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
@@ -1524,7 +1537,9 @@ int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double 
     if (force_kernel_kind(nt, kind) == 2) {
         const int dbg = wg_debug_flags();
         const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
-        if (wg_layout() == 3)
+        if (wg_layout() == 4)
+            hipLaunchKernelGGL(k_accel_wg<4>, grid, dim3(wg_threads(4)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+        else if (wg_layout() == 3)
             hipLaunchKernelGGL(k_accel_wg<3>, grid, dim3(wg_threads(3)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
         else if (wg_layout() == 2)
             hipLaunchKernelGGL(k_accel_wg<2>, grid, dim3(wg_threads(2)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
@@ -1565,7 +1580,9 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
         LmArgs b = a;
         b.wg_flags = wg_debug_flags() & 8;             // only the priority knob; the cycle accounting is k_accel_wg's
         const int lay = wg_layout();
-        if (a.L == 12 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<12, 3>), grid, dim3(wg_threads(3)), 0, s, b);
+        if (a.L == 12 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<12, 4>), grid, dim3(wg_threads(4)), 0, s, b);
+        else if (a.L == 13 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<13, 4>), grid, dim3(wg_threads(4)), 0, s, b);
+        else if (a.L == 12 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<12, 3>), grid, dim3(wg_threads(3)), 0, s, b);
         else if (a.L == 13 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<13, 3>), grid, dim3(wg_threads(3)), 0, s, b);
         else if (a.L == 12 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<12, 2>), grid, dim3(wg_threads(2)), 0, s, b);
         else if (a.L == 13 && lay == 2) hipLaunchKernelGGL((k_lm_step_wg<13, 2>), grid, dim3(wg_threads(2)), 0, s, b);
