@@ -94,8 +94,11 @@ struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm
 // a[b] = acc_init[b] (or 0) + sum over the other bodies in the reference order; SoA [3][npad] output
 // kind: 0 = auto by n, 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
 // lo, hi: target bodies [lo, hi) (hi < 0: n); lo must be a multiple of 16
+// kd (optional): the SRKN stage update fused behind the evaluation, per (body, component) of the launch's targets:
+//   v += a * hb ; y += v * ha ; pos_out = y      (symplectic.rs:90-97) -- one launch per stage instead of two
+struct KickDrift { double *v, *y; double hb, ha; Body4 *pos_out; };
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out,
-                 int kind = 0, int lo = 0, int hi = -1);
+                 int kind = 0, int lo = 0, int hi = -1, const KickDrift *kd = nullptr);
 int launch_pack(hipStream_t s, int n, int npad, const double *Yslot, const double *mu, Body4 *pos);
 int launch_copy3(hipStream_t s, int n, int npad, const double *src, double *dst);
 // SRKN stage update: v += a*hb ; y += v*ha ; also publishes packed positions   (symplectic.rs:90-97)

@@ -393,13 +393,21 @@ __device__ __forceinline__ double wave_force(PosPtr pos, int n, int i0, double i
     return accL + acc;   // ddy[i] += output_i
 }
 
+// SRKN stage update of one (body, component) behind its force evaluation   symplectic.rs:90-97
+__device__ __forceinline__ void kick_drift_one(const KickDrift &kd, size_t o, int body, int comp, double a) {
+    const double vn = kd.v[o] + a * kd.hb;            // *dy = *dy + *ddy * (h * C::B[s])
+    kd.v[o] = vn;
+    const double yn = kd.y[o] + vn * kd.ha;           // *y = *y + *dy * (h * C::A[s])
+    kd.y[o] = yn;
+    reinterpret_cast<double *>(kd.pos_out + body)[comp] = yn;   // mu is already in both packed buffers
+}
 // ------------------------------------------------------------------------------------------------------
 // k_accel: a = init + sum, SoA [3][npad] output. One wave per block, BPW bodies per wave.
 // ------------------------------------------------------------------------------------------------------
 template <int BPW>
 __global__ void __launch_bounds__(64) k_accel(int n, int npad, const Body4 *__restrict__ pos,
                                               const double *__restrict__ acc_init, double *__restrict__ acc_out,
-                                              int lo, int hi) {
+                                              int lo, int hi, KickDrift kd) {
     __shared__ __attribute__((aligned(16))) double C[2 * 3 * BPW * kRow];   // double buffered contribution tile
     const int lane = threadIdx.x;
     const int i0 = lo + blockIdx.x * BPW;          // targets [lo, hi): the whole system, or this rank's shard
@@ -408,7 +416,10 @@ __global__ void __launch_bounds__(64) k_accel(int n, int npad, const Body4 *__re
     const bool owner = lane < 3 * BPW && my_i < hi;
     const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
     const double a = wave_force<BPW>(pos, n, i0, init, C, lane);
-    if (owner) acc_out[cc * npad + my_i] = a;
+    if (owner) {
+        acc_out[cc * npad + my_i] = a;
+        if (kd.v) kick_drift_one(kd, (size_t)cc * npad + my_i, my_i, cc, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -806,7 +817,8 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
 template <int LAYOUT>
 __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
                                                          const double *__restrict__ acc_init,
-                                                         double *__restrict__ acc_out, int dbg, int lo, int hi) {
+                                                         double *__restrict__ acc_out, int dbg, int lo, int hi,
+                                                         KickDrift kd) {
     __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
     const int i0 = lo + blockIdx.x * kWgBodies;
@@ -814,7 +826,10 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad
     const bool owner = (tid >> 6) == kWgPairWaves && lane < kWgRows && my_i < hi;
     const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
     const double a = wg_force<LAYOUT>(pos, n, i0, init, C, tid, dbg);
-    if (owner) acc_out[cc * npad + my_i] = a;
+    if (owner) {
+        acc_out[cc * npad + my_i] = a;
+        if (kd.v) kick_drift_one(kd, (size_t)cc * npad + my_i, my_i, cc, a);
+    }
 }
 
 // One launch per integrator step, workgroup-specialised force (see k_lm_step for the step structure).
@@ -1530,32 +1545,33 @@ int force_kernel_kind(int n, int requested) {
 }
 
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind,
-                 int lo, int hi) {
+                 int lo, int hi, const KickDrift *kdp) {
     if (hi < 0) hi = n;
+    const KickDrift kd = kdp ? *kdp : KickDrift{nullptr, nullptr, 0.0, 0.0, nullptr};
     const int nt = hi - lo;                            // targets of this launch; the kernel choice follows them
     if (n <= 0 || nt <= 0) return EPH_OK;
     if (force_kernel_kind(nt, kind) == 2) {
         const int dbg = wg_debug_flags();
         const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
         if (wg_layout() == 4)
-            hipLaunchKernelGGL(k_accel_wg<4>, grid, dim3(wg_threads(4)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+            hipLaunchKernelGGL(k_accel_wg<4>, grid, dim3(wg_threads(4)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         else if (wg_layout() == 3)
-            hipLaunchKernelGGL(k_accel_wg<3>, grid, dim3(wg_threads(3)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+            hipLaunchKernelGGL(k_accel_wg<3>, grid, dim3(wg_threads(3)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         else if (wg_layout() == 2)
-            hipLaunchKernelGGL(k_accel_wg<2>, grid, dim3(wg_threads(2)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+            hipLaunchKernelGGL(k_accel_wg<2>, grid, dim3(wg_threads(2)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         else if (wg_layout() == 1)
-            hipLaunchKernelGGL(k_accel_wg<1>, grid, dim3(wg_threads(1)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+            hipLaunchKernelGGL(k_accel_wg<1>, grid, dim3(wg_threads(1)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         else
-            hipLaunchKernelGGL(k_accel_wg<0>, grid, dim3(wg_threads(0)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi);
+            hipLaunchKernelGGL(k_accel_wg<0>, grid, dim3(wg_threads(0)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         return done("k_accel_wg");
     }
     const int bpw = lm_bodies_per_wave(nt);
     const dim3 grid((nt + bpw - 1) / bpw), block(64);
     switch (bpw) {
-        case 1: hipLaunchKernelGGL(k_accel<1>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
-        case 2: hipLaunchKernelGGL(k_accel<2>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
-        case 4: hipLaunchKernelGGL(k_accel<4>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
-        default: hipLaunchKernelGGL(k_accel<8>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi); break;
+        case 1: hipLaunchKernelGGL(k_accel<1>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi, kd); break;
+        case 2: hipLaunchKernelGGL(k_accel<2>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi, kd); break;
+        case 4: hipLaunchKernelGGL(k_accel<4>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi, kd); break;
+        default: hipLaunchKernelGGL(k_accel<8>, grid, block, 0, s, n, npad, pos, acc_init, acc_out, lo, hi, kd); break;
     }
     return done("k_accel");
 }

@@ -159,15 +159,15 @@ int NBodyIntegration::srkn_step(double h, double *y_slot) {
     if (time_ + h == time_) return EPH_STEP_SIZE_UNDERFLOW;
     int st;
     for (int s = 0; s < rk_.stages; ++s) {
-        if (!rk_.fsal || s > 0 || starter_i_ == 0) {
-            // problem.ode.eval(t_stage, &problem.state.y, self.ddy.zero())
-            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind(), lo_, hi_))) return st;
-            evals_++;
-        }
         // *dy = *dy + *ddy * (h * C::B[s]);  *y = *y + *dy * (h * C::A[s])
-        if ((st = launch_kick_drift(stream_, n_, npad_, ASR_.p, V_.p, y_slot, h * rk_.B[s], h * rk_.A[s], mu_.p,
-                                    P_[pp_ ^ 1].p)))
-            return st;
+        const KickDrift kd{V_.p, y_slot, h * rk_.B[s], h * rk_.A[s], P_[pp_ ^ 1].p};
+        if (!rk_.fsal || s > 0 || starter_i_ == 0) {
+            // problem.ode.eval(t_stage, &problem.state.y, self.ddy.zero()) and the stage update behind it, one launch
+            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind(), lo_, hi_, &kd))) return st;
+            evals_++;
+        } else if ((st = launch_kick_drift(stream_, n_, npad_, ASR_.p, V_.p, y_slot, kd.hb, kd.ha, mu_.p, P_[pp_ ^ 1].p))) {
+            return st;                                 // FSAL first stage: the acceleration is the previous step's last
+        }
         if ((st = gather_packed(P_[pp_ ^ 1].p))) return st;
         pp_ ^= 1;
     }
