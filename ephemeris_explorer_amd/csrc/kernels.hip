@@ -539,7 +539,8 @@ constexpr int kWgDefaultLayout = 3;   // measured at N = 4096 (us per step): lay
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
 constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave
-__device__ long long g_wg_cycles[8];                 // debug (EPH_DEBUG_WG=3): block 0 cycle accounting
+__device__ long long g_wg_cycles[8];                 // debug (EPH_DEBUG_WG=4): cycle accounting of workgroup 7
+__device__ long long g_wg_span[2][1024];             // debug: per workgroup entry / force-done ticks of the step kernel
 
 // pair wave: NB bodies (local indices b0..) against the 64 sources in pj -> rows of `tile`
 template <int NB>
@@ -642,9 +643,14 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
         tile_b[(3 * b0 + q) * kRow + lane] = c[3 * NB + q];
     }
 }
-// Layout 3 barrier schedule (every wave executes TB + 1 barriers, TB = ceil(tiles / 2) "big" tiles of two 64-source
-// tiles): B_0 after tiles 0..3 are in LDS; iteration T: pair waves produce tiles 2T+4, 2T+5 into buffers (2T+4)%6,
-// (2T+5)%6 while the chain wave sums tiles 2T, 2T+1; barrier.
+// Layout 3 barrier schedule. The 64-source tiles are grouped into "big" tiles, one barrier each: big tiles 0 and 1 are
+// single tiles (so the chain wave starts after two tiles, not four: its wait for the first barrier was 2.7 us of a
+// 42 us launch), every later one is two tiles. Every wave executes TB + 1 barriers: B_0 after big tiles 0 and 1 are
+// in LDS; iteration K: pair waves produce big tile K + 2 while the chain wave sums big tile K (and prefetches the head
+// of K + 1, complete since the previous barrier); barrier. Tile t lives in LDS buffer t % 6; the tiles alive at any time
+// span at most six consecutive indices.
+__device__ __forceinline__ int big_start(int K) { return K < 2 ? K : 2 * K - 2; }
+__device__ __forceinline__ int big_count(int tiles) { return tiles <= 2 ? tiles : 2 + (tiles - 2 + 1) / 2; }
 template <int NB, typename PosPtr>
 __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag) {
     double xi[NB], yi[NB], zi[NB];
@@ -659,22 +665,22 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
         const int j = min(t, tiles - 1) * kTile + lane;
         return pos[j < n ? j : n - 1];
     };
-    auto produce = [&](int t, const Body4 &pa, const Body4 &pb) {          // tiles t, t + 1 (t even)
+    auto produce = [&](int K, const Body4 &pa, const Body4 &pb) {          // big tile K
+        const int t = big_start(K);
         if (t >= tiles) return;
         double *ta = C + (t % 6) * kWgBuf, *tb = C + ((t + 1) % 6) * kWgBuf;
-        if (t + 1 < tiles) wg_pair_tile2<NB>(xi, yi, zi, pa, pb, tdiag == t || tdiag == t + 1, ta, tb, b0, lane);
+        if (K >= 2 && t + 1 < tiles) wg_pair_tile2<NB>(xi, yi, zi, pa, pb, tdiag == t || tdiag == t + 1, ta, tb, b0, lane);
         else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
     };
-    const int TB = (tiles + 1) / 2;
+    const int TB = big_count(tiles);
     Body4 pa = load_src(0), pb = load_src(1), na = load_src(2), nb = load_src(3);
-    produce(0, pa, pb);
-    pa = na; pb = nb; na = load_src(4); nb = load_src(5);
-    produce(2, pa, pb);
+    produce(0, pa, pa);
+    produce(1, pb, pb);
     __syncthreads();
-    for (int T = 0; T < TB; ++T) {
+    for (int K = 0; K < TB; ++K) {
         pa = na; pb = nb;
-        na = load_src(2 * T + 6); nb = load_src(2 * T + 7);
-        produce(2 * T + 4, pa, pb);
+        na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
+        produce(K + 2, pa, pb);
         __syncthreads();
     }
 }
@@ -705,7 +711,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // under the denser f64 stream and the step gets slower.)
     if constexpr (LAYOUT == 4) {
         switch (wave) {
-            case 0: for (int T = 0; T <= (tiles + 1) / 2; ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
+            case 0: for (int T = 0; T <= big_count(tiles); ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
             case 1: wg_pair_wave_big<3>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
             case 2: wg_pair_wave_big<3>(pos, n, i0, 3, C, lane, tiles, tdiag); return 0.0;
             case 3: wg_pair_wave_big<3>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
@@ -770,12 +776,13 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     load_chunk(row, 0, q[0]);
     load_chunk(row, 1, q[1]);
     if constexpr (wg_big(LAYOUT)) {
-        const int TB = (tiles + 1) / 2;
+        const int TB = big_count(tiles);
+        if ((dbg & 4) && blockIdx.x == 7 && lane == 0) g_wg_cycles[4] = __builtin_readcyclecounter() - c_start;   // wait for B_0
         for (int T = 0; T < TB; ++T) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int t = 2 * T + hf;
-                if (t >= tiles) break;
+                const int t = big_start(T) + hf;
+                if (t >= tiles || (T < 2 && hf)) break;
                 const double *r = row + (t % 6) * kWgBuf;
                 const double *rn = row + ((t + 1) % 6) * kWgBuf;   // complete since the previous barrier
                 const int cnt = min(kTile, n - t * kTile);
@@ -789,6 +796,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
             }
             __syncthreads();                          // big tile T consumed, big tile T + 2 ready
         }
+        if ((dbg & 4) && blockIdx.x == 7 && lane == 0) { g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
         return accL + acc;
     }
     for (int t = 0; t < tiles; ++t) {
@@ -854,7 +862,13 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
             av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
         }
     }
+    const long long t_entry = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
     const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
+    const long long t_force = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
+    if ((a.wg_flags & 4) && chain_wave && lane == 0) {       // tuning: where a launch spends its time (EPH_DEBUG_WG=4)
+        if (blockIdx.x == 7) { g_wg_cycles[0] = t_force - t_entry; }
+        if (blockIdx.x < 1024) { g_wg_span[0][blockIdx.x] = t_entry; g_wg_span[1][blockIdx.x] = t_force; }
+    }
     if (!owner) return;
 
     a.A[(size_t)a.cur * lvl + off] = anew;
@@ -1594,7 +1608,7 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
     if (force_kernel_kind(a.hi - a.lo, a.kind) == 2) {
         const dim3 grid((a.hi - a.lo + kWgBodies - 1) / kWgBodies);
         LmArgs b = a;
-        b.wg_flags = wg_debug_flags() & 8;             // only the priority knob; the cycle accounting is k_accel_wg's
+        b.wg_flags = wg_debug_flags() & 12;            // priority knob + launch-level accounting (the per-tile one is k_accel_wg's)
         const int lay = wg_layout();
         if (a.L == 12 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<12, 4>), grid, dim3(wg_threads(4)), 0, s, b);
         else if (a.L == 13 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<13, 4>), grid, dim3(wg_threads(4)), 0, s, b);
@@ -1698,6 +1712,17 @@ int launch_soa_to_aos(hipStream_t s, int n, int npad, const double *soa, double 
 int debug_wg_cycles(long long *out) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_cycles), sizeof(long long) * 8);
     if (e != hipSuccess) { set_last_error("hipMemcpyFromSymbol", e); return EPH_ERR_HIP; }
+    // step kernel: out[2] = earliest workgroup entry, out[3] = latest force completion over the grid (s_memtime ticks)
+    static long long span[2][1024];
+    e = hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wg_span), sizeof(span));
+    if (e != hipSuccess) { set_last_error("hipMemcpyFromSymbol", e); return EPH_ERR_HIP; }
+    long long lo = 0, hi = 0;
+    for (int b = 0; b < 1024; ++b) {
+        if (span[0][b] == 0) continue;
+        if (lo == 0 || span[0][b] < lo) lo = span[0][b];
+        if (span[1][b] > hi) hi = span[1][b];
+    }
+    if (lo) { out[2] = lo; out[3] = hi; }
     return EPH_OK;
 }
 int launch_debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee) {
