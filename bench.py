@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--horizon", type=int, default=100000,
                     help="parity horizon: max |dpos| vs the oracle's committed positions at every 10^k-th step up to this "
                          "many steps (tests/golden/plummer4096_horizon.npz; 0 = skip)")
+    ap.add_argument("--prewarm", type=float, default=1.0,
+                    help="seconds of untimed load on a scratch clone before the warm-up steps, so the timed region runs at the "
+                         "steady shader clock instead of the ramp from idle (0 = off)")
     ap.add_argument("--craft", type=int, default=262144)
     ap.add_argument("--craft-days", type=float, default=0.25)
     args = ap.parse_args()
@@ -310,6 +313,18 @@ def main():
         from ephemeris_explorer_amd.parallel import shard_nbody
         shard_nbody(g, dist, transport=args.transport, device="cuda")
     g.advance(12)                       # multistep start-up, reported separately in DESIGN.md
+    if args.prewarm > 0:
+        # The board idles at 100 MHz / 250 W and takes ~0.6 s of load to reach its 2.4 GHz shader clock
+        # (profiles/r02_step_kernel_evidence.md section 1): a short timed region entered straight from idle measures the ramp,
+        # not the kernel. Load the device first with a SCRATCH clone of the system (the measured handle's own history
+        # stays exactly start-up + W + K steps); untimed, like the W warm-up steps that follow.
+        scratch = g.clone()
+        chunk = max(1, int(2000 * (N_BODIES / n) ** 2))            # ~0.1 s of work per chunk at any size
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm:
+            scratch.advance(chunk)
+            scratch.sync()
+        del scratch
     g.advance(args.warmup)
     g.enable_timing(True)
 
