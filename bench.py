@@ -155,7 +155,10 @@ def craft_main(args):
         return b
 
     from ephemeris_explorer_amd.parallel import gather_craft_states
+    t_pre = time.perf_counter()
     for _ in range(args.warmup if args.warmup < 3 else 2):
+        sweep()
+    while time.perf_counter() - t_pre < args.prewarm:   # untimed: bring the board from idle to its steady clock (see main())
         sweep()
 
     def barrier():

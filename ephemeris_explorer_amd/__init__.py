@@ -24,6 +24,8 @@ import os as _os
 # of the (unpinned) point-mass term -- csrc/device_math.h. Default: the product library.
 _PV = int(_os.environ.get("EPH_AMD_PAIR_VARIANT", "0") or 0)
 LIB_PATH = _HERE / ("libephemeris_amd.so" if _PV == 0 else f"libephemeris_amd_pv{_PV}.so")
+if _os.environ.get("EPH_AMD_LIBRARY"):            # tuning builds (scripts/): another build of the same sources
+    LIB_PATH = Path(_os.environ["EPH_AMD_LIBRARY"])
 
 FORWARD, BACKWARD = 1, -1
 PATH_FAST = 4

@@ -8,7 +8,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libephemeris_amd.so"
 SOURCES = ["kernels.hip", "craft.hip", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
-HEADERS = ["eph_internal.h", "host.h", "device_math.h", "coeff_tables.inc", "cr_pow_tables.inc", "../../include/ephemeris_amd.h"]
+HEADERS = ["eph_internal.h", "host.h", "device_math.h", "coeff_tables.inc", "cr_pow_tables.inc", "chain_tile.inc", "../../include/ephemeris_amd.h"]
 # -ffp-contract=off is REQUIRED for parity (HIP's default is fast contraction): the reference never fuses a*b+c.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

@@ -699,6 +699,18 @@ __device__ __forceinline__ double chain_full_pf(const double *row, const double 
     return add_chunk(q[3], acc);
 }
 
+// The same ordered sum of a full tile with the instruction order pinned (tools/gen_chain_tile.py): 16 reads kept in
+// flight ahead of the dependent adds. Self-contained (no registers carried between tiles). EXPERIMENT (-DEPH_CHAIN_ASM=1):
+// alone on a CU it beats the compiler's chunked schedule (724 vs 930 ticks per tile, scripts/ubench/chain2.hip).
+#ifndef EPH_CHAIN_ASM
+#define EPH_CHAIN_ASM 0
+#endif
+__device__ __forceinline__ double chain_full_asm(const double *row, double acc) {
+    const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)row;   // LDS byte address
+#include "chain_tile.inc"
+    return acc;
+}
+
 // Returns on chain-wave lane ch < 48: component ch%3 of body i0 + ch/3. All 320 threads must call it.
 template <int LAYOUT, typename PosPtr>
 __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg = 0) {
@@ -772,9 +784,11 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     double2 q[4][8];
     long long t_work = 0, t_bar = 0;
     const long long c_start = __builtin_readcyclecounter();
-    __syncthreads();                                  // B_0: tiles 0 and 1 ready (layout 3: 0..3)
-    load_chunk(row, 0, q[0]);
-    load_chunk(row, 1, q[1]);
+    __syncthreads();                                  // B_0: tiles 0 and 1 ready
+    if constexpr (!(EPH_CHAIN_ASM && wg_big(LAYOUT))) {
+        load_chunk(row, 0, q[0]);
+        load_chunk(row, 1, q[1]);
+    }
     if constexpr (wg_big(LAYOUT)) {
         const int TB = big_count(tiles);
         if ((dbg & 4) && blockIdx.x == 7 && lane == 0) g_wg_cycles[4] = __builtin_readcyclecounter() - c_start;   // wait for B_0
@@ -787,11 +801,14 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
                 const double *rn = row + ((t + 1) % 6) * kWgBuf;   // complete since the previous barrier
                 const int cnt = min(kTile, n - t * kTile);
                 if (t != tdiag && cnt == kTile) {
-                    acc = chain_full_pf(r, rn, q, acc);
+                    if constexpr (EPH_CHAIN_ASM) acc = chain_full_asm(r, acc);   // experimental build: pinned order
+                    else acc = chain_full_pf(r, rn, q, acc);
                 } else {
                     chain_masked<kWgBodies>(r, cnt, t == tdiag ? gself : -1, li, acc, accL);
-                    load_chunk(rn, 0, q[0]);
-                    load_chunk(rn, 1, q[1]);
+                    if constexpr (!EPH_CHAIN_ASM) {
+                        load_chunk(rn, 0, q[0]);
+                        load_chunk(rn, 1, q[1]);
+                    }
                 }
             }
             __syncthreads();                          // big tile T consumed, big tile T + 2 ready
