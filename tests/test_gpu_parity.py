@@ -298,3 +298,39 @@ def test_degenerate_sizes(gpu):
         for b in range(n):
             assert sol.info(b) == osol.info(b)
             assert np.array_equal(sol.coeffs(b)[0], osol.coeffs(b)[0])
+
+
+def test_workgroup_kernel_at_every_tile_count(gpu):
+    """The role-specialised workgroup kernel is chosen for 2048 <= n < 8192 (32+ source tiles); its barrier schedule (single
+    tiles first, then pairs of tiles, six LDS buffers) is exercised here at the tile counts it never sees by default -- 2, 3,
+    4, 5, 7, 17 tiles, ragged last tiles -- by forcing it (EPH_FORCE=wg, read once per process: hence the subprocess),
+    for every role layout, accelerations and a few fused steps against the oracle."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import ephemeris_explorer_amd as ea
+from ephemeris_explorer_amd.workloads import plummer
+from oracle import orc
+same = lambda a, b: np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+rng = np.random.default_rng(5)
+for n in (65, 128, 129, 200, 256, 300, 448, 1030):
+    pos, mu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
+    assert same(ea.accel_eval(pos, mu), orc.gravity(pos, mu)), ("accel", n)
+for n in (130, 300, 1030):
+    pos, vel, mu = plummer(n)
+    g = ea.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
+    o = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0, native=True)
+    g.advance(12 + 7)
+    assert o.advance(12 + 7) == 0
+    assert same(g.state()[0], o.state()[0]) and same(g.state()[1], o.state()[1]), ("steps", n)
+print("ok")
+'''
+    for layout in ("0", "1", "2", "3", "4"):
+        env = dict(os.environ, EPH_FORCE="wg", EPH_WG_LAYOUT=layout)
+        r = subprocess.run([sys.executable, "-c", script, str(ROOT)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (layout, r.stdout[-1000:], r.stderr[-3000:])

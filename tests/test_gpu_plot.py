@@ -135,6 +135,7 @@ def test_plot_points_argument_errors(gpu, scene):
                                  ot.ctypes.data_as(C.POINTER(C.c_double)), ox.ctypes.data_as(C.POINTER(C.c_float)),
                                  cnt.ctypes.data_as(C.POINTER(C.c_int64)), stt.ctypes.data_as(C.POINTER(C.c_int32)),
                                  fail.ctypes.data_as(C.POINTER(C.c_double)))
+    assert gpu.plot_points(eph, {"camera_position": (1.0, 2.0, 3.0), "current": s.epoch}, []) == []      # no plots: nothing to do
     assert call(gpu.PlotRequest(3, -1, 0, 0, s.epoch, s.epoch + 1.0, 0, 1, 1e-4, 100), 10) == gpu.ERR_BAD_ARGUMENT
     assert call(gpu.PlotRequest(s.n, -1, 0, 0, s.epoch, s.epoch + 1.0, 0, 1, 1e-4, 10), 10) == gpu.ERR_BAD_ARGUMENT
     assert call(gpu.PlotRequest(-1, -1, 0, 5, s.epoch, s.epoch + 1.0, 0, 1, 1e-4, 10), 10) == gpu.ERR_BAD_ARGUMENT   # no knots given
