@@ -66,7 +66,7 @@ def run(system_dir, years=2.0, backward=True):
     for th in threads:
         th.join()
     if "f" not in sols or (r.bwd_prop is not None and "b" not in sols):
-        raise SystemExit("ephemeris propagation failed")
+        raise RuntimeError("ephemeris propagation failed")
     r.forward, r.backward = sols["f"], sols.get("b")
     r.ephemeris_seconds = time.time() - t0
 

@@ -7,7 +7,7 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int MODE>
-__global__ void __launch_bounds__(64) k(double *out, long long *cyc, int tiles) {
+__global__ void __launch_bounds__(64) k(double *out, long long *cyc, int tiles, const double *gbuf) {
     __shared__ __attribute__((aligned(16))) double C[3][48 * 66];
     const int lane = threadIdx.x;
     for (int i = lane; i < 3 * 48 * 66; i += 64) (&C[0][0])[i] = 1e-3 * i;
@@ -29,8 +29,16 @@ __global__ void __launch_bounds__(64) k(double *out, long long *cyc, int tiles) 
 #include "chain2_adds.inc"
         } else if (MODE == 5) {
 #include "chain2_reads.inc"
-        } else {
+        } else if (MODE == 6) {
 #include "chain2_b64.inc"
+        } else {
+            // the same rows in global memory (27 KB per CU: L1 / L2 resident), address = this lane's row of tile t % 3
+            const double *addr = gbuf + ((size_t)blockIdx.x * 3 + t % 3) * 48 * 66 + ch * 66;
+            if (MODE == 7) {
+#include "chain2_g16.inc"
+            } else {
+#include "chain2_greads.inc"
+            }
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -45,10 +53,13 @@ int run(const char *name) {
     const int tiles = 20000;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    k<MODE><<<256, 64>>>(out, cyc, 10);
+    double *gbuf;
+    CHECK(hipMalloc(&gbuf, sizeof(double) * 256 * 3 * 48 * 66));
+    CHECK(hipMemset(gbuf, 0, sizeof(double) * 256 * 3 * 48 * 66));
+    k<MODE><<<256, 64>>>(out, cyc, 10, gbuf);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k<MODE><<<256, 64>>>(out, cyc, tiles);
+    k<MODE><<<256, 64>>>(out, cyc, tiles, gbuf);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -65,5 +76,7 @@ int main() {
     run<2>("asm: add, add, read; ring of 16");
     run<3>("asm: add, read, add (hi half copied out); ring of 8");
     run<6>("asm: 64 ds_read_b64, add, read; ring of 16");
+    run<8>("32 global_load_dwordx4 only (L1/L2 resident rows)");
+    run<7>("asm: add, add, global_load; ring of 16");
     return 0;
 }

@@ -55,3 +55,20 @@ write("b64", *b64(16))
 write("adds", ["v_add_f64 %0, %0, v[20:21]"] * 64, [20, 21])
 write("reads", [f"ds_read_b128 v[{BASE + 4 * (k % 8)}:{BASE + 4 * (k % 8) + 3}], %1 offset:{16 * k}" for k in range(32)] +
       ["s_waitcnt lgkmcnt(0)"], range(BASE, BASE + 32))
+
+
+def global_ring(R):             # the same ring fed by global_load_dwordx4 (vmcnt) instead of ds_read_b128: do VMEM returns overlap the adds?
+    lines = ["s_waitcnt vmcnt(0)"] + [f"global_load_dwordx4 v[{BASE + 4 * k}:{BASE + 4 * k + 3}], %1, off offset:{16 * k}" for k in range(R)]
+    for k in range(32):
+        q = BASE + 4 * (k % R)
+        lines.append(f"s_waitcnt vmcnt({R - 1 if k + R <= 32 else 32 - k - 1})")
+        lines.append(f"v_add_f64 %0, %0, v[{q}:{q + 1}]")
+        lines.append(f"v_add_f64 %0, %0, v[{q + 2}:{q + 3}]")
+        if k + R < 32:
+            lines.append(f"global_load_dwordx4 v[{q}:{q + 3}], %1, off offset:{16 * (k + R)}")
+    return lines, range(BASE, BASE + 4 * R)
+
+
+write("g16", *global_ring(16))
+write("greads", ["s_waitcnt vmcnt(0)"] + [f"global_load_dwordx4 v[{BASE + 4 * (k % 8)}:{BASE + 4 * (k % 8) + 3}], %1, off offset:{16 * k}" for k in range(32)] +
+      ["s_waitcnt vmcnt(0)"], range(BASE, BASE + 32))
