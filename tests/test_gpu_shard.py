@@ -110,7 +110,7 @@ def _worker(rank, world, port, n, method, steps, out):
     (1024, 2, "QuinlanTremaine12", 12 + 40),          # wave kernel, start-up and steady state sharded
     (1000, 2, "QuinlanTremaine12", 12 + 9),           # ragged: the last rank owns 488 bodies
     (512, 4, "BlanesMoan6B", 5),                      # SRKN only
-    (8192, 2, "QuinlanTremaine12", 12 + 4),           # 4096 targets per rank: the workgroup kernel at an offset
+    (4096, 2, "QuinlanTremaine12", 12 + 4),           # 2048 targets per rank: the workgroup kernel at a target offset
 ])
 def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps):
     import torch.multiprocessing as mp
