@@ -71,3 +71,25 @@ def test_product_never_imports_the_oracle():
     for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.cpp")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
         text = p.read_text()
         assert "import orc" not in text and "eph_oracle" not in text and "pyoracle" not in text, p
+
+
+def test_header_is_plain_c_and_the_c_example_links(product_lib, tmp_path):
+    """include/ephemeris_amd.h is the boundary a cgo / Rust-FFI / C caller binds: it must compile as C99 (pedantic) and as
+    C++11, and examples/propagate.c -- the propagator seam driven from plain C -- must build and link against the library.
+    Without a device the example stops at its first compute call with EPH_ERR_NO_DEVICE (exit 77): no CPU fallback."""
+    import subprocess
+    from conftest import ROOT
+    hdr = ROOT / "include" / "ephemeris_amd.h"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", str(hdr)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", str(hdr)])
+    exe = tmp_path / "propagate"
+    libdir = ROOT / "ephemeris_explorer_amd"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}",
+                           str(ROOT / "examples" / "propagate.c"), f"-L{libdir}", "-lephemeris_amd",
+                           f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    import ephemeris_explorer_amd as ea
+    if ea.device_count() < 1:
+        assert r.returncode == 77 and "no HIP device" in r.stderr.lower() or "-2" in r.stderr, (r.returncode, r.stderr)
+    else:
+        assert r.returncode == 0 and "inside=1" in r.stdout, (r.stdout, r.stderr)

@@ -87,3 +87,25 @@ def test_cli_fine45_ship(gpu, tmp_path):
     kt, kp, kv = batch.knots(0)
     ot, op, ov = c.knots()
     assert np.array_equal(bits(kt), bits(ot)) and np.array_equal(bits(kp), bits(op))
+
+
+def test_c_example_runs_on_the_device(gpu, tmp_path):
+    """examples/propagate.c: the propagator seam from plain C (what a cgo / Rust-FFI binding does), on the device; its
+    printed Earth position at day 10 equals the oracle's (to the printed millimetre)."""
+    import re
+    import subprocess
+    from conftest import ROOT, load_system
+    exe = tmp_path / "propagate"
+    libdir = ROOT / "ephemeris_explorer_amd"
+    subprocess.check_call(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "propagate.c"), f"-L{libdir}",
+                           "-lephemeris_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    m = re.search(r"r\(day 10\) = \(([-0-9.]+), ([-0-9.]+), ([-0-9.]+)\) km inside=1", r.stdout)
+    assert m, r.stdout
+    s = load_system("sun_earth_moon_2433282.5")
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert o.step_to(s.epoch + 30 * 86400.0) == 0
+    want = o.take_solution().eval(1, s.epoch + 10 * 86400.0)[0]
+    got = np.array([float(x) for x in m.groups()])
+    assert np.abs(got - want).max() < 1e-3 + 1e-12 * np.abs(want).max()
