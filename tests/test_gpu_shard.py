@@ -110,7 +110,6 @@ def _worker(rank, world, port, n, method, steps, out):
     (1024, 2, "QuinlanTremaine12", 12 + 40),          # wave kernel, start-up and steady state sharded
     (1000, 2, "QuinlanTremaine12", 12 + 9),           # ragged: the last rank owns 488 bodies
     (512, 4, "BlanesMoan6B", 5),                      # SRKN only
-    (4096, 2, "QuinlanTremaine12", 12 + 4),           # 2048 targets per rank: the workgroup kernel at a target offset
 ])
 def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps):
     import torch.multiprocessing as mp
@@ -171,3 +170,60 @@ def test_sharded_propagator_builds_the_same_ephemeris(gpu):
         for (info, (co, nc)), (winfo, (wco, wnc)) in zip(rows, want):
             assert info == winfo and info[2] > 0
             assert np.array_equal(nc, wnc) and np.array_equal(co, wco)
+
+
+def test_two_ranks_in_one_process_workgroup_kernel_at_an_offset(gpu):
+    """2048 and 4096 targets per rank of 4096- and 8192-body systems: the role-specialised workgroup kernel (default layout: 152 KB of
+    LDS per workgroup) evaluating a target range that does not start at body 0. Two ranks as two THREADS of this process, each
+    with its own handle and stream; the exchange callback is a device-to-device copy of the peer's slice between two thread
+    barriers. (Two PROCESSES sharing one GPU thrash on this kernel -- every alternation swaps 152 KB of LDS per CU -- which
+    says nothing about one process per GPU.)"""
+    import ctypes
+    import threading
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    for n, steps in ((4096, 12 + 5), (8192, 12 + 2)):
+        pos, vel, mu = plummer(n)
+        world = 2
+        bar = threading.Barrier(world)
+        bufs = [None] * world
+        results = [None] * world
+        errors = []
+
+        def exchange_for(rank):
+            def exchange(dev_ptr, slice_bytes, r, w, stream):
+                if hip.hipStreamSynchronize(stream):
+                    return 2
+                bufs[rank] = dev_ptr
+                bar.wait()                                   # both slices written, both buffer addresses known
+                peer = 1 - rank
+                if hip.hipMemcpy(dev_ptr + peer * slice_bytes, bufs[peer] + peer * slice_bytes, slice_bytes, 3):   # D2D
+                    return 3
+                bar.wait()                                   # nobody overwrites its slice before the peer has copied it
+                return 0
+            return exchange
+
+        def worker(rank):
+            try:
+                nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H).shard(rank, world, exchange=exchange_for(rank))
+                nb.advance(steps)
+                results[rank] = (nb.state(), nb.acc(), nb.shard_info())
+            except Exception as e:                           # noqa: BLE001
+                errors.append(e)
+                bar.abort()
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        (p0, v0, t0, sc0), a0 = _single(n, "QuinlanTremaine12", steps)
+        for r in range(world):
+            (p, v, t, sc), a, (lo, hi, gathers) = results[r]
+            assert (lo, hi) == (r * n // 2, (r + 1) * n // 2) and gathers > 0
+            assert t == t0 and sc == sc0
+            assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(a, a0), (n, r)
