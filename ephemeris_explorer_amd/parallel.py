@@ -68,10 +68,8 @@ def gather_craft_states(state, n_total, dist=None, device="cpu"):
 
 
 def _hip():
-    lib = C.CDLL("libamdhip64.so")
-    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    lib.hipStreamSynchronize.argtypes = [C.c_void_p]
-    return lib
+    from . import hip_runtime
+    return hip_runtime()          # the runtime the library itself uses (a torch process carries a second one)
 
 
 def host_staged_exchange(dist, group=None):

@@ -178,13 +178,10 @@ def test_two_ranks_in_one_process_workgroup_kernel_at_an_offset(gpu):
     with its own handle and stream; the exchange callback is a device-to-device copy of the peer's slice between two thread
     barriers. (Two PROCESSES sharing one GPU thrash on this kernel -- every alternation swaps 152 KB of LDS per CU -- which
     says nothing about one process per GPU.)"""
-    import ctypes
     import threading
     import ephemeris_explorer_amd as ea
     from ephemeris_explorer_amd.workloads import plummer
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip = ea.hip_runtime()        # the library's own HIP runtime (earlier tests of this module import torch, which has another)
     for n, steps in ((4096, 12 + 5), (8192, 12 + 2)):
         pos, vel, mu = plummer(n)
         world = 2
