@@ -307,22 +307,16 @@ def _shard_call(fn, name, handle, rank, world, unique_id, exchange):
 
 
 def hip_runtime():
-    """ctypes handle of THE HIP runtime libephemeris_amd.so is linked against (by the path `ldd` resolves), not whatever
-    "libamdhip64.so" happens to resolve to: a process that also imported PyTorch carries torch's bundled runtime too, and
-    device pointers / streams of one runtime mean nothing to the other. For host programs (and tests) that touch the
-    library's device buffers themselves, e.g. inside an eph_exchange_fn."""
-    import subprocess
-    path = None
-    try:
-        for line in subprocess.check_output(["ldd", str(LIB_PATH)], text=True).splitlines():
-            if "libamdhip64" in line and "=>" in line:
-                path = line.split("=>")[1].split("(")[0].strip()
-                break
-    except (OSError, subprocess.CalledProcessError):
-        pass
-    lib = C.CDLL(path or "libamdhip64.so")
+    """The HIP runtime libephemeris_amd.so is bound to IN THIS PROCESS, as a ctypes object with hipMemcpy and
+    hipStreamSynchronize: symbols looked up through the library's own handle (dlsym searches its dependencies), not through
+    whatever "libamdhip64.so" resolves to -- a process that also imported PyTorch may carry a second, bundled runtime, and
+    device pointers / streams of one mean nothing to the other. For host programs (and tests) that touch the library's device
+    buffers themselves, e.g. inside an eph_exchange_fn."""
+    lib = _lib()
     lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipMemcpy.restype = C.c_int
     lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+    lib.hipStreamSynchronize.restype = C.c_int
     return lib
 
 
