@@ -168,7 +168,11 @@ struct Polynomial {
 struct UniformSpline {
     double start = 0, interval = 0;
     std::deque<Polynomial> polynomials;
-    double span() const { return interval * (double)polynomials.size(); }   // interval.scaled(len)
+    // polynomials already pushed as far as the bounds are concerned but still resident on the device (only inside an
+    // NBodyPropagator between fits and take_solution; 0 in every Solution handed out)
+    uint64_t ghost = 0;
+    uint64_t len() const { return (uint64_t)polynomials.size() + ghost; }
+    double span() const { return interval * (double)len(); }   // interval.scaled(len)
     double end() const { return start + span(); }
     void push_back(const Polynomial &p) { polynomials.push_back(p); }
     void push_front(const Polynomial &p) {
@@ -272,6 +276,15 @@ private:
     DevBuf<uint32_t> d_src_, d_cnt_;
     int failed_ = EPH_OK;
     int fit_and_push(int64_t done, hipStream_t s);
+    // Fitted polynomials stay on the device until somebody takes the solution: a batch appends its windows (body-major)
+    // to pend_co_ / pend_nc_ and only the bounds (UniformSpline::start, ::ghost) move on the host, with the reference's
+    // own f64 operations. materialize() downloads them and performs the push_back / push_front of every window.
+    DevBuf<double> pend_co_;                  // [pend_cap_][kDiv][3]
+    DevBuf<int32_t> pend_nc_;
+    size_t pend_count_ = 0, pend_cap_ = 0;
+    std::vector<std::vector<uint32_t>> pend_batches_;   // per batch: windows per body
+    int reserve_pending(size_t extra, hipStream_t s);
+    int materialize();
 };
 
 }  // namespace eph

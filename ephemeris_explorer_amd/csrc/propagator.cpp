@@ -125,7 +125,63 @@ int NBodyPropagator::clone(std::unique_ptr<NBodyPropagator> *out) {
         return st;
     EPH_HIP(hipMemcpy(p->log_.p, log_.p, sizeof(double) * log_.count, hipMemcpyDeviceToDevice));
     EPH_HIP(hipMemcpy(p->d_period_.p, d_period_.p, sizeof(uint32_t) * d_period_.count, hipMemcpyDeviceToDevice));
+    if (pend_count_) {                                // device-resident polynomials travel with the clone
+        if ((st = p->pend_co_.alloc(pend_count_ * kDiv * 3)) || (st = p->pend_nc_.alloc(pend_count_))) return st;
+        EPH_HIP(hipStreamSynchronize(integ_->stream()));
+        EPH_HIP(hipMemcpy(p->pend_co_.p, pend_co_.p, sizeof(double) * pend_count_ * kDiv * 3, hipMemcpyDeviceToDevice));
+        EPH_HIP(hipMemcpy(p->pend_nc_.p, pend_nc_.p, sizeof(int32_t) * pend_count_, hipMemcpyDeviceToDevice));
+        p->pend_count_ = p->pend_cap_ = pend_count_;
+        p->pend_batches_ = pend_batches_;
+    }
     *out = std::move(p);
+    return EPH_OK;
+}
+
+// room for `extra` more windows behind the pending ones (grow-only; contents kept)
+int NBodyPropagator::reserve_pending(size_t extra, hipStream_t s) {
+    const size_t need = pend_count_ + extra;
+    if (need <= pend_cap_) return EPH_OK;
+    const size_t cap = std::max(need + need / 2, (size_t)4096);
+    DevBuf<double> co;
+    DevBuf<int32_t> nc;
+    int st;
+    if ((st = co.alloc(cap * kDiv * 3)) || (st = nc.alloc(cap))) return st;
+    if (pend_count_) {
+        EPH_HIP(hipMemcpyAsync(co.p, pend_co_.p, sizeof(double) * pend_count_ * kDiv * 3, hipMemcpyDeviceToDevice, s));
+        EPH_HIP(hipMemcpyAsync(nc.p, pend_nc_.p, sizeof(int32_t) * pend_count_, hipMemcpyDeviceToDevice, s));
+        EPH_HIP(hipStreamSynchronize(s));
+    }
+    std::swap(pend_co_.p, co.p); std::swap(pend_co_.count, co.count);
+    std::swap(pend_nc_.p, nc.p); std::swap(pend_nc_.count, nc.count);
+    pend_cap_ = cap;
+    return EPH_OK;
+}
+
+// download the device-resident polynomials and perform the pushes the bounds already account for
+int NBodyPropagator::materialize() {
+    if (pend_count_ == 0) return EPH_OK;
+    hipStream_t s = integ_->stream();
+    EPH_HIP(hipSetDevice(integ_->device()));
+    std::vector<double> co(pend_count_ * kDiv * 3);
+    std::vector<int32_t> nc(pend_count_);
+    EPH_HIP(hipMemcpyAsync(co.data(), pend_co_.p, sizeof(double) * co.size(), hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipMemcpyAsync(nc.data(), pend_nc_.p, sizeof(int32_t) * nc.size(), hipMemcpyDeviceToHost, s));
+    EPH_HIP(hipStreamSynchronize(s));
+    size_t q = 0;
+    for (const std::vector<uint32_t> &nwin : pend_batches_)
+        for (size_t b = 0; b < nwin.size(); ++b) {
+            UniformSpline &traj = solution_.splines[b];
+            for (uint32_t w = 0; w < nwin[b]; ++w, ++q) {
+                Polynomial poly;
+                poly.ncoef = nc[q];
+                std::copy(co.begin() + q * kDiv * 3, co.begin() + (q + 1) * kDiv * 3, &poly.c[0][0]);
+                // push_at_bound: the start of a backward spline already moved when the window was fitted
+                if (direction_ > 0) traj.polynomials.push_back(poly); else traj.polynomials.push_front(poly);
+                traj.ghost -= 1;
+            }
+        }
+    pend_count_ = 0;
+    pend_batches_.clear();
     return EPH_OK;
 }
 
@@ -207,6 +263,32 @@ int NBodyPropagator::fit_and_push(int64_t done, hipStream_t s) {
     int64_t wmax = 0;
     for (int r = 0; r < world && sharded; ++r) wmax = std::max(wmax, qstart[body_lo(r + 1)] - qstart[body_lo(r)]);
     int st;
+    if (!sharded) {
+        // Unsharded: fit straight into the device-resident pending list; only the bounds move on the host
+        // (UniformSpline::push_front's `start -= interval`, one f64 subtraction per window like the reference).
+        if ((st = d_first_.reserve(W)) || (st = d_deg_.reserve(W)) || (st = d_src_.reserve(n)) || (st = d_cnt_.reserve(n)) ||
+            (st = d_region_.reserve(n)) || (st = reserve_pending((size_t)W, s)))
+            return st;
+        EPH_HIP(hipMemcpyAsync(d_first_.p, first.data(), sizeof(uint64_t) * W, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_deg_.p, deg.data(), sizeof(uint8_t) * W, hipMemcpyHostToDevice, s));
+        if ((st = launch_lsq_fit(s, W, d_first_.p, d_deg_.p, direction_ < 0, log_.p, pend_co_.p + pend_count_ * kDiv * 3,
+                                 pend_nc_.p + pend_count_)))
+            return st;
+        EPH_HIP(hipMemcpyAsync(d_src_.p, carry_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_cnt_.p, carry_cnt.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        EPH_HIP(hipMemcpyAsync(d_region_.p, log_off_.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice, s));
+        if ((st = launch_carry(s, n, d_region_.p, d_src_.p, d_cnt_.p, log_.p))) return st;
+        EPH_HIP(hipStreamSynchronize(s));            // the host vectors above go out of scope
+        for (int b = 0; b < n; ++b) {
+            UniformSpline &traj = solution_.splines[b];
+            traj.ghost += nwin[b];
+            if (direction_ < 0)
+                for (uint32_t w = 0; w < nwin[b]; ++w) traj.start -= traj.interval;
+        }
+        pend_count_ += (size_t)W;
+        pend_batches_.push_back(std::move(nwin));
+        return EPH_OK;
+    }
     // scratch is grow-only and lives with the propagator: a steady run allocates nothing per batch
     if ((st = d_first_.reserve(W)) || (st = d_deg_.reserve(W)) || (st = d_co_.reserve((size_t)W * kDiv * 3)) ||
         (st = d_nc_.reserve(W)) || (st = d_src_.reserve(n)) || (st = d_cnt_.reserve(n)) || (st = d_region_.reserve(n)))
@@ -299,7 +381,7 @@ int64_t NBodyPropagator::steps_until_reached(double t, int64_t cap) const {
         UniformSpline s;   // bound arithmetic only
         s.start = solution_.splines[b].start;
         s.interval = solution_.splines[b].interval;
-        uint64_t npoly = solution_.splines[b].polynomials.size();
+        uint64_t npoly = solution_.splines[b].len();
         uint64_t extra = 0;
         auto bound = [&]() {
             return direction_ > 0 ? s.start + s.interval * (double)npoly : s.start;
@@ -332,6 +414,8 @@ int NBodyPropagator::step_to(double t) {   // IncrementalPropagator::step_to  ep
 
 int NBodyPropagator::take_solution(std::unique_ptr<Solution> *out) {   // nbody.rs:182-189
     if (failed_) return failed_;
+    const int stm = materialize();
+    if (stm) return failed_ = stm;
     std::unique_ptr<Solution> old(new Solution(std::move(solution_)));
     solution_ = new_solution();
     *out = std::move(old);
