@@ -7,9 +7,14 @@
  *
  * PARITY PINNING: the reference cannot be built here (no Rust toolchain) and its innermost arithmetic
  * (`particular::gravity::newtonian`, git rev d490707a, Cargo.lock:4277-4285) is not on disk, so the pair
- * formula is "parity unpinned" (see DESIGN.md). Everything else is pinned by: the coefficient tables
- * (tests/golden/coeff_tables.json, generated from the reference's constants), the doc-test known answers
- * (integration/src/lib.rs:32-56,60-93), an independent Python restatement (oracle/pyoracle.py) and the
+ * formula is "parity unpinned" (orc_set_pair_variant carries the plausible alternatives, the product
+ * carries the same four behind -DEPH_PAIR_VARIANT). Everything else is pinned by: the reference's own discrete,
+ * integrator-sensitive known answers -- ephemeris/tests/solar_system_convergence.rs:346-357 asserts the converged
+ * step of QuinlanTremaine12 / Stormer13 / BlanesMoan14A on its compensated Double<DVec3> state, restated in
+ * convergence_double.inc and reproduced (10 / 5 / 10 minutes) by tests/test_convergence_pin.py --, the coefficient
+ * tables (tests/golden/coeff_tables.json, generated from the reference's constants), the doc-test known answers
+ * (integration/src/lib.rs:32-56,60-93), the spacecraft scenario's assertions
+ * (ephemeris/tests/spacecraft_propagation.rs:476-480), an independent Python restatement (oracle/pyoracle.py) and the
  * committed systems fixtures (tests/golden/systems).
  */
 #ifndef EPH_ORACLE_H
