@@ -253,7 +253,12 @@ int32_t eph_prop_create(int32_t n, const double *pos, const double *vel, const d
     return EPH_OK;
     EPH_GUARD_END
 }
-int32_t eph_prop_step(eph_prop *p) { return eph_prop_step_n(p, 1); }
+int32_t eph_prop_step(eph_prop *p) {      // lazily: queued, run as one device batch when data is needed (host.h)
+    EPH_GUARD_BEGIN
+    if (!p) return EPH_ERR_BAD_ARGUMENT;
+    return p->p->step_deferred();
+    EPH_GUARD_END
+}
 int32_t eph_prop_step_n(eph_prop *p, int64_t n) {
     EPH_GUARD_BEGIN
     if (!p || n < 0) return EPH_ERR_BAD_ARGUMENT;
@@ -278,12 +283,16 @@ int32_t eph_prop_has_reached(eph_prop *p, double t, int32_t *flag) {
 }
 int32_t eph_prop_integrator_time(eph_prop *p, double *t) {
     if (!p || !t) return EPH_ERR_BAD_ARGUMENT;
+    const int st = p->p->flush();             // queued steps run first
+    if (st) return st;
     *t = p->p->integration()->time();
     return EPH_OK;
 }
 int32_t eph_prop_get_state(eph_prop *p, double *pos, double *vel, double *t, uint32_t *sc) {
     EPH_GUARD_BEGIN
     if (!p) return EPH_ERR_BAD_ARGUMENT;
+    const int st = p->p->flush();             // queued steps run first
+    if (st) return st;
     return p->p->integration()->get_state(pos, vel, t, sc);
     EPH_GUARD_END
 }
@@ -317,7 +326,11 @@ int32_t eph_prop_clone(eph_prop *p, eph_prop **out) {
     EPH_GUARD_END
 }
 void eph_prop_destroy(eph_prop *p) { delete p; }
-eph_nbody *eph_prop_integrator(eph_prop *p) { return p ? &p->view : nullptr; }
+eph_nbody *eph_prop_integrator(eph_prop *p) {
+    if (!p) return nullptr;
+    (void)p->p->flush();                      // the view reads the integration directly: queued steps run first
+    return &p->view;
+}
 
 // ---- eph_solution -----------------------------------------------------------------------------------
 int32_t eph_solution_bodies(const eph_solution *s, int32_t *n) {

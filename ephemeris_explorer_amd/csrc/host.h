@@ -244,10 +244,18 @@ public:
     int clone(std::unique_ptr<NBodyPropagator> *out);
     int step_n(int64_t k);                    // k x IncrementalPropagator::step
     int step_to(double t);
+    // ONE IncrementalPropagator::step, executed lazily: the reference's callers step in a loop and look at time() /
+    // has_reached() after every step (ephemeris_explorer/src/prediction.rs:422-443). Everything those two return is a
+    // function of the number of steps taken (sampling counters and spline bounds), not of the numerical state, so a
+    // steady-state step only advances that bookkeeping on the host and is queued; the queue runs as one device batch when
+    // somebody needs data (take_solution, clone, state, step_n / step_to) or it reaches kDeferMax steps.
+    int step_deferred();
+    int flush();
     double time() const;                      // DirectionalSolout::solution_time
     bool has_reached(double t) const;
     int take_solution(std::unique_ptr<Solution> *out);
     NBodyIntegration *integration() { return integ_.get(); }
+    int64_t deferred() const { return deferred_; }
 
 private:
     NBodyPropagator() = default;
@@ -279,6 +287,18 @@ private:
     // Fitted polynomials stay on the device until somebody takes the solution: a batch appends its windows (body-major)
     // to pend_co_ / pend_nc_ and only the bounds (UniformSpline::start, ::ghost) move on the host, with the reference's
     // own f64 operations. materialize() downloads them and performs the push_back / push_front of every window.
+    // deferred steps (step_deferred): how many, and the bookkeeping as it will be once they have run
+    static constexpr int64_t kDeferMax = 8192;
+    int64_t deferred_ = 0;
+    double sh_time_ = 0;                                  // integrator time
+    std::vector<uint32_t> sh_phase_, sh_len_;             // SplineInterpolator counters
+    std::vector<double> sh_start_;                        // spline starts
+    std::vector<uint64_t> sh_npoly_;                      // spline lengths
+    double bound_at(size_t b) const {                     // bound of spline b, deferred steps included
+        const UniformSpline &s = solution_.splines[b];
+        if (deferred_ == 0) return bound_of(s);
+        return direction_ > 0 ? sh_start_[b] + s.interval * (double)sh_npoly_[b] : sh_start_[b];
+    }
     DevBuf<double> pend_co_;                  // [pend_cap_][kDiv][3]
     DevBuf<int32_t> pend_nc_;
     size_t pend_count_ = 0, pend_cap_ = 0;

@@ -109,6 +109,7 @@ int NBodyPropagator::create(int n, const double *pos, const double *vel, const d
 
 int NBodyPropagator::clone(std::unique_ptr<NBodyPropagator> *out) {
     if (failed_) return failed_;
+    if (deferred_) { const int stf = flush(); if (stf) return stf; }
     std::unique_ptr<NBodyPropagator> p(new NBodyPropagator());
     int st = integ_->clone(&p->integ_);
     if (st) return st;
@@ -345,7 +346,63 @@ int NBodyPropagator::fit_and_push(int64_t done, hipStream_t s) {
     return EPH_OK;
 }
 
+// IncrementalPropagator::step, lazily (see host.h). Returns exactly what the step will return.
+int NBodyPropagator::step_deferred() {
+    if (failed_) return failed_;
+    NBodyIntegration &ig = *integ_;
+    if (!ig.started() || ig.sharded()) return step_n(1);          // start-up and sharded runs execute at once
+    const size_t n = interp_.size();
+    if (deferred_ == 0) {                                            // open the queue: shadows = the current bookkeeping
+        sh_time_ = ig.time();
+        sh_phase_.resize(n); sh_len_.resize(n); sh_start_.resize(n); sh_npoly_.resize(n);
+        for (size_t b = 0; b < n; ++b) {
+            sh_phase_[b] = interp_[b].phase;
+            sh_len_[b] = interp_[b].len;
+            sh_start_[b] = solution_.splines[b].start;
+            sh_npoly_[b] = solution_.splines[b].len();
+        }
+    }
+    // LinearMultistepIntegrator::advance's checks (multistep/mod.rs:201-207) with the time the queued steps lead to: a
+    // step that would fail is not queued -- the queue runs and the step executes, returning the StepError itself
+    if (sh_time_ >= ig.bound() || sh_time_ + ig.step_size() == sh_time_) {
+        const int st = flush();
+        return st ? st : step_n(1);
+    }
+    sh_time_ = sh_time_ + ig.step_size();
+    for (size_t b = 0; b < n; ++b) {                                 // SplineInterpolators::solout_with, one step  nbody.rs:371-400
+        const uint32_t m = interp_[b].period_steps;
+        if (m == 0) continue;                                        // (last_sample_time is rebuilt when the queue runs)
+        if (++sh_phase_[b] < m) continue;
+        sh_phase_[b] = 0;                                            // a sample
+        if (++sh_len_[b] <= (uint32_t)kDiv) continue;
+        sh_len_[b] = 1;                                              // ninth sample: the window is fitted and pushed
+        sh_npoly_[b] += 1;
+        if (direction_ < 0) sh_start_[b] -= solution_.splines[b].interval;   // push_front
+    }
+    if (++deferred_ >= kDeferMax) return flush();
+    return EPH_OK;
+}
+
+int NBodyPropagator::flush() {
+    if (failed_) return failed_;
+    if (deferred_ == 0) return EPH_OK;
+    const int64_t k = deferred_;
+    deferred_ = 0;
+    const int st = step_n(k);                                        // none of these steps can return a StepError (checked when queued)
+    if (st) return failed_ = st;
+#ifndef NDEBUG
+    for (size_t b = 0; b < interp_.size(); ++b)
+        if (interp_[b].period_steps && (interp_[b].phase != sh_phase_[b] || interp_[b].len != sh_len_[b] ||
+                                        solution_.splines[b].len() != sh_npoly_[b] || solution_.splines[b].start != sh_start_[b])) {
+            set_last_error_text("deferred-step bookkeeping diverged from the executed batch");
+            return failed_ = EPH_ERR_HIP;
+        }
+#endif
+    return EPH_OK;
+}
+
 int NBodyPropagator::step_n(int64_t k) {
+    if (deferred_) { const int st = flush(); if (st) return st; }
     while (k > 0) {
         // start-up steps of the multistep method go one at a time (each is many small launches anyway)
         const int64_t chunk = integ_->started() ? std::min<int64_t>(k, kmax_) : 1;
@@ -359,17 +416,17 @@ int NBodyPropagator::step_n(int64_t k) {
 double NBodyPropagator::time() const {   // DirectionalSolout::solution_time  nbody.rs:501-508
     const auto &sp = solution_.splines;
     if (sp.empty()) return dir_offset(direction_, 0.0, -std::numeric_limits<double>::max());
-    double best = bound_of(sp[0]);
+    double best = bound_at(0);
     for (size_t b = 1; b < sp.size(); ++b) {
-        const double x = bound_of(sp[b]);
+        const double x = bound_at(b);
         if (0.0 < dir_distance(direction_, x, best)) best = x;   // min_by(D::cmp), first minimum wins
     }
     return best;
 }
 
 bool NBodyPropagator::has_reached(double t) const {   // nbody.rs:510-516
-    for (const UniformSpline &s : solution_.splines)
-        if (0.0 < dir_distance(direction_, bound_of(s), t)) return false;   // !D::cmp(&bound, &time).is_ge()
+    for (size_t b = 0; b < solution_.splines.size(); ++b)
+        if (0.0 < dir_distance(direction_, bound_at(b), t)) return false;   // !D::cmp(&bound, &time).is_ge()
     return true;
 }
 
@@ -403,6 +460,7 @@ int64_t NBodyPropagator::steps_until_reached(double t, int64_t cap) const {
 
 int NBodyPropagator::step_to(double t) {   // IncrementalPropagator::step_to  ephemeris/src/lib.rs:49-60
     if (failed_) return failed_;
+    if (deferred_) { const int st = flush(); if (st) return st; }
     for (;;) {
         if (has_reached(t)) return EPH_OK;
         int64_t k = integ_->started() ? steps_until_reached(t, kmax_) : 1;
@@ -414,6 +472,7 @@ int NBodyPropagator::step_to(double t) {   // IncrementalPropagator::step_to  ep
 
 int NBodyPropagator::take_solution(std::unique_ptr<Solution> *out) {   // nbody.rs:182-189
     if (failed_) return failed_;
+    if (deferred_) { const int st = flush(); if (st) return st; }
     const int stm = materialize();
     if (stm) return failed_ = stm;
     std::unique_ptr<Solution> old(new Solution(std::move(solution_)));

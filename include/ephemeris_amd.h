@@ -153,7 +153,12 @@ int32_t eph_prop_create(int32_t n, const double *pos_xyz, const double *vel_xyz,
  * propagator. eph_prop_step* / step_to / propagate / clone become collective calls. */
 int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
                        void *ctx);
-int32_t eph_prop_step(eph_prop *p);                  /* IncrementalPropagator::step  nbody.rs:200-207 */
+/* IncrementalPropagator::step  nbody.rs:200-207. Executed lazily: the reference's callers step in a loop and read
+ * time() / has_reached() after every step (ephemeris_explorer/src/prediction.rs:422-443); both are functions of the number
+ * of steps taken, so a steady-state step only advances that bookkeeping on the host (and returns the StepError the step
+ * would return) and the queued steps run as ONE device batch when data is needed -- take_solution, clone, get_state,
+ * step_n / step_to -- or after 8192 of them. Results are identical to executing every step at once. */
+int32_t eph_prop_step(eph_prop *p);
 int32_t eph_prop_step_n(eph_prop *p, int64_t n);     /* n x step(), batched on the device */
 int32_t eph_prop_step_to(eph_prop *p, double t);     /* IncrementalPropagator::step_to  lib.rs:49-60 */
 int32_t eph_prop_time(eph_prop *p, double *t);       /* DirectionalPropagator::time  nbody.rs:225-227,502-508 */

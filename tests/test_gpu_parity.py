@@ -334,3 +334,45 @@ print("ok")
         env = dict(os.environ, EPH_FORCE="wg", EPH_WG_LAYOUT=layout)
         r = subprocess.run([sys.executable, "-c", script, str(ROOT)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (layout, r.stdout[-1000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("name", ["sun_earth_moon_2433282.5", "full_solar_system_2433282.5"])
+@pytest.mark.parametrize("direction", [1, -1])
+def test_single_steps_are_deferred_but_indistinguishable(gpu, name, direction):
+    """The app's calling pattern (ephemeris_explorer/src/prediction.rs:422-443): `step()` in a loop, `has_reached()` and
+    `time()` after EVERY step, now and then a snapshot (take_solution + clone). eph_prop_step queues steady-state steps and
+    answers time() / has_reached() from host bookkeeping; everything observable must equal the oracle stepping one at a time."""
+    s = load_system(name)
+    g = gpu.NBodyPropagator.from_system(s, direction)
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, direction, s.count, s.degree)
+    target = s.epoch + direction * 400 * s.dt
+    reached_at = None
+    twin = None
+    for k in range(1, 12 + 900 + 1):
+        g.step()
+        assert o.step() == 0
+        assert g.time() == o.time(), k
+        assert g.has_reached(target) == o.has_reached(target), k
+        if reached_at is None and g.has_reached(target):
+            reached_at = k
+        if k in (5, 40, 137, 500):                    # a snapshot: inside the start-up, then with steps queued
+            sg, so = g.take_solution(), o.take_solution()
+            for b in range(s.n):
+                assert sg.info(b) == so.info(b), (k, b)
+                assert np.array_equal(sg.coeffs(b)[1], so.coeffs(b)[1])
+                assert_same_bits(sg.coeffs(b)[0], so.coeffs(b)[0], f"step {k} body {b}")
+            assert g.time() == o.time()
+        if k == 300:
+            twin = g.clone()                          # Clone with steps queued: the clone resumes identically
+    assert reached_at is not None and reached_at > 300
+    for _ in range(100):
+        twin.step()
+    g_state, o_state = g.state(), o.state()
+    assert g_state[2:] == o_state[2:]
+    assert_same_bits(g_state[0], o_state[0], "positions")
+    assert_same_bits(g_state[1], o_state[1], "velocities")
+    assert twin.state()[3] == 300 + 100
+    sg, so = g.take_solution(), o.take_solution()
+    for b in range(s.n):
+        assert sg.info(b) == so.info(b)
+        assert_same_bits(sg.coeffs(b)[0], so.coeffs(b)[0], f"final body {b}")
