@@ -1244,12 +1244,14 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
         constexpr int Rn = (R + L - 1) % L;            // slot of the oldest level = slot of the level being built
         __syncthreads();   // positions of the new level visible
         // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
-        if (pi0 >= 0) pair(pi0, pj0);
-        if (pi1 >= 0) pair(pi1, pj1);
+        if (!(a.wg_flags & 1)) {                       // (wg_flags: tuning switches, EPH_DEBUG_SMALL; 0 in normal runs)
+            if (pi0 >= 0) pair(pi0, pj0);
+            if (pi1 >= 0) pair(pi1, pj1);
+        }
         __syncthreads();   // contributions visible
         // ---- ordered chains: plain in-order sums over the rows (zeros outside each chain's range)
         double acc = 0.0;
-        if (chain_thread) {
+        if (chain_thread && !(a.wg_flags & 2)) {
             const double *row = half ? &U[chain][0] : &Lw[chain][0];
             for (int c = 0; c < nrow; c += 16) {
                 double2 r[8];
@@ -1681,6 +1683,13 @@ template <int L>
 static int launch_lm_persistent_L(hipStream_t s, const LmArgs &a, int64_t nsteps) {
     static const int old_design = [] { const char *e = getenv("EPH_SMALL"); return e && e[0] == '1'; }();
     if (!old_design && a.n <= kSmallMaxN) {
+        static const int dbg = [] { const char *e = getenv("EPH_DEBUG_SMALL"); return e ? atoi(e) : 0; }();
+        LmArgs b = a;
+        b.wg_flags = dbg;                              // 1: no pair stage, 2: no chain stage (timing breakdown only)
+        hipLaunchKernelGGL(k_lm_small<L>, dim3(1), dim3(512), 0, s, b, (long long)nsteps);
+        return done("k_lm_small");
+    }
+    if (false) {
         hipLaunchKernelGGL(k_lm_small<L>, dim3(1), dim3(512), 0, s, a, (long long)nsteps);
         return done("k_lm_small");
     }
