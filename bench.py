@@ -357,7 +357,7 @@ def main():
         # as MI355X_MICROARCH.md prescribes) of this same command, committed under profiles/ -- not measurable live
         traffic, traffic_src, valu_insts = None, None, None
         tj = ROOT / "profiles" / "traffic.json"
-        if tj.exists() and n == N_BODIES:
+        if tj.exists() and n == N_BODIES and not fast and not sharded:      # the committed PMC passes are of the default path
             tinfo = json.loads(tj.read_text())
             traffic, traffic_src = tinfo.get("traffic_bytes_per_launch"), tinfo.get("source")
             valu_insts = tinfo.get("valu_wave_insts_per_launch")
