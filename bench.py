@@ -356,8 +356,8 @@ def main():
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected and corrected
         # as MI355X_MICROARCH.md prescribes) of this same command, committed under profiles/ -- not measurable live
         traffic, traffic_src, valu_insts = None, None, None
-        tj = ROOT / "profiles" / "traffic.json"
-        if tj.exists() and n == N_BODIES and not fast and not sharded:      # the committed PMC passes are of the default path
+        tj = ROOT / "profiles" / ("traffic_fast.json" if fast else "traffic.json")
+        if tj.exists() and n == N_BODIES and not sharded:                   # the committed PMC passes of this path
             tinfo = json.loads(tj.read_text())
             traffic, traffic_src = tinfo.get("traffic_bytes_per_launch"), tinfo.get("source")
             valu_insts = tinfo.get("valu_wave_insts_per_launch")

@@ -49,7 +49,18 @@ for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
             pmc.setdefault(k, {}).update(v)
 if (src / "fast_pmc_sq_counter_collection.csv").exists():
     fast = {k: v for k, v in per_dispatch("fast_pmc_sq").items() if "k_fast" in k}
+    for extra in ("fast_pmc_fetch", "fast_pmc_write"):
+        if (src / f"{extra}_counter_collection.csv").exists():
+            for k, v in per_dispatch(extra).items():
+                if "k_fast" in k:
+                    fast.setdefault(k, {}).update(v)
     (dst / f"{tag}_fast_pmc.json").write_text(json.dumps(fast, indent=1) + "\n")
+    if all("FETCH_SIZE" in v for v in fast.values()) and fast:
+        # one step of the fast path = one k_fast_partial + one k_fast_finish launch
+        total = sum((2.0 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024.0 for v in fast.values())
+        (dst / "traffic_fast.json").write_text(json.dumps({
+            "source": f"profiles/{tag}_fast_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; sum of the step's two launches)",
+            "traffic_bytes_per_launch": total}, indent=1) + "\n")
 stats = {r["Name"]: r for r in csv.DictReader(open(src / "stats_kernel_stats.csv"))}
 out = {"note": "per-dispatch averages; SQ_* counters are summed over the chip; FETCH_SIZE/WRITE_SIZE in KiB. "
                "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read, so "
