@@ -254,7 +254,7 @@ def main():
                          "spacecraft) | nbody-sharded: ONE system of --bodies (default 65536, configs[4] in f64) "
                          "partitioned by target body over the ranks, one RCCL all-gather per step (strong scaling)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl", help="nbody-sharded exchange")
-    ap.add_argument("--path", choices=["exact", "fast"], default="exact",
+    ap.add_argument("--path", choices=["exact", "fast", "fast-rsq"], default="exact",
                     help="exact (default): the reference's summation order, bit-identical to the CPU path | fast: the "
                          "opt-in slice-parallel sums (EPH_PATH_FAST) -- a second, separately labelled line "
                          "(config.workload ..._fast) with its measured divergence from the reference order")
@@ -306,12 +306,13 @@ def main():
     # rank r integrates its own replica (seed + r): independent systems, no exchange -- or, sharded, every rank
     # builds the SAME system and owns n/world target bodies of it
     pos, vel, mu = plummer(n, seed=20260926 + (0 if sharded else rank))
-    fast = args.path == "fast"
+    fast = args.path in ("fast", "fast-rsq")
+    fast_path = {"fast": ea.PATH_FAST, "fast-rsq": ea.PATH_FAST_RSQ}.get(args.path)
     if fast and sharded:
         raise SystemExit("--path fast is not sharded")
     g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
     if fast:
-        g.set_path(ea.PATH_FAST)
+        g.set_path(fast_path)
     if sharded:
         from ephemeris_explorer_amd.parallel import shard_nbody
         shard_nbody(g, dist, transport=args.transport, device="cuda")
@@ -372,7 +373,7 @@ def main():
                         "bodies_per_gpu": nt, "method": "QuinlanTremaine12",
                         "parallelism": f"target-partition x{world}, 1 all-gather of {32 * n} B per step "
                                        f"({args.transport})"} if sharded else
-                       {"workload": f"plummer_{n}_f64_qt12{'_fast' if fast else ''} (BASELINE.json configs[2]; h=1/1024, "
+                       {"workload": f"plummer_{n}_f64_qt12{'_' + args.path.replace('-', '_') if fast else ''} (BASELINE.json configs[2]; h=1/1024, "
                                     "seed 20260926+rank)" + ("; OPT-IN fast path: slice-parallel partial sums, NOT the "
                                                              "reference's summation order" if fast else ""),
                         "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}",
@@ -402,7 +403,7 @@ def main():
             # parity beside the number: a fresh GPU run of the same steps vs the oracle
             c = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
             if fast:
-                c.set_path(ea.PATH_FAST)
+                c.set_path(fast_path)
             nsteps = o.state()[3]                            # the oracle went on for the all-cores sample
             c.advance(nsteps)
             dp = np.abs(c.state()[0] - o.state()[0]).max()
@@ -416,7 +417,7 @@ def main():
             ref = np.load(fx)
             c = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
             if fast:
-                c.set_path(ea.PATH_FAST)
+                c.set_path(fast_path)
             done, hz = 0, {}
             for k in (int(x) for x in ref["checkpoints"]):
                 if k > args.horizon:

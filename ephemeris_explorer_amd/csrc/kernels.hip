@@ -924,7 +924,20 @@ constexpr int kFastWaves = 4;                          // waves (= slices) per w
 constexpr int kFastUnrollMax = 8;                      // sources per range check / loop trip: 4 or 8 (EPH_FAST_UNROLL)
 constexpr int kFastMaxSlices = 64;
 
-template <bool DIAG, int kFastUnroll>
+// 1 / r^3 WITHOUT the IEEE square root and division (EPH_PATH_FAST_RSQ): y = v_rsq_f64(n2) refined by two Newton steps
+// (relative error ~1e-16, not correctly rounded), then y * y * y. 15 VALU operations instead of 22 and one
+// transcendental instead of two. n2 = 0 (the body itself) gives NaN here too; the caller masks that source.
+__device__ __forceinline__ double inv_r3_approx(double n2) {
+    double y = __builtin_amdgcn_rsq(n2);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double a = n2 * y;
+        const double r = __builtin_fma(-a, 0.5 * y, 0.5);      // 0.5 * (1 - n2 * y^2)
+        y = __builtin_fma(y, r, y);
+    }
+    return y * y * y;
+}
+template <bool DIAG, int kFastUnroll, bool APPROX>
 __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4))) Body4 *src, int j0, int j1, int i,
                                            double xi, double yi, double zi, double &ax, double &ay, double &az) {
     auto fetch = [&](int j, Body4 (&p)[kFastUnroll]) {
@@ -946,7 +959,13 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
             worst = max(worst, range_key(pre[u].n2));
         }
         double c[3 * kFastUnroll];
-        if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
+        if (APPROX) {
+#pragma unroll
+            for (int u = 0; u < kFastUnroll; ++u) {
+                const double sc = pj[u].mu * inv_r3_approx(pre[u].n2);
+                c[3 * u] = pre[u].dx * sc; c[3 * u + 1] = pre[u].dy * sc; c[3 * u + 2] = pre[u].dz * sc;
+            }
+        } else if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
 #pragma unroll
             for (int u = 0; u < kFastUnroll; ++u) pair_finish<true>(pre[u], pj[u].mu, c[3 * u], c[3 * u + 1], c[3 * u + 2]);
         } else {
@@ -967,7 +986,7 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
 // slice sums and their combination. (First version: one launch with a per-block arrival ticket, the last workgroup
 // of a block combining -- measured 66 / 96 / 166 us per step at 16 / 32 / 64 slices, N = 4096: the agent-scope
 // fence each workgroup needs before its ticket costs ~0.13 us and they serialise; gpurun_out r02a.)
-template <int UNROLL>
+template <int UNROLL, bool APPROX>
 __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npad, const Body4 *__restrict__ pos,
                                                                   int S, int slice_len, double *__restrict__ partial) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -982,8 +1001,8 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
     const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (j0 < j1) {
-        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
-        else fast_slice<false, UNROLL>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL, APPROX>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        else fast_slice<false, UNROLL, APPROX>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
     }
     double *pp = partial + (size_t)slice * 3 * npad + i;
     pp[0] = ax;
@@ -1653,18 +1672,21 @@ int fast_slices(int npad) {
     S = std::max(kFastWaves, std::min(kFastMaxSlices, S));
     return (S + kFastWaves - 1) / kFastWaves * kFastWaves;
 }
-int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial) {
+int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, bool approx) {
     if (a.n <= 0) return EPH_OK;
     if (a.lo != 0 || a.hi != a.n) return EPH_ERR_UNSUPPORTED;          // the fast path is not sharded
     static const int unroll = [] { const char *e = getenv("EPH_FAST_UNROLL"); return e && atoi(e) == 8 ? 8 : 4; }();
     const int S = fast_slices(a.npad);
     int slice_len = (a.npad + S - 1) / S;
-    slice_len = (slice_len + unroll - 1) / unroll * unroll;
+    const int un = approx ? 4 : unroll;
+    slice_len = (slice_len + un - 1) / un * un;
     const dim3 pgrid((unsigned)(a.npad / 64 * (S / kFastWaves))), pblock(64 * kFastWaves);
-    if (unroll == 8 && a.npad % 8 == 0)
-        hipLaunchKernelGGL(k_fast_partial<8>, pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
+    if (approx)
+        hipLaunchKernelGGL((k_fast_partial<4, true>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
+    else if (unroll == 8 && a.npad % 8 == 0)
+        hipLaunchKernelGGL((k_fast_partial<8, false>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     else
-        hipLaunchKernelGGL(k_fast_partial<4>, pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
+        hipLaunchKernelGGL((k_fast_partial<4, false>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     const dim3 grid((3 * a.npad + 255) / 256), block(256);
     if (a.L == 12) hipLaunchKernelGGL(k_fast_finish<12>, grid, block, 0, s, a, S, partial);
     else if (a.L == 13) hipLaunchKernelGGL(k_fast_finish<13>, grid, block, 0, s, a, S, partial);

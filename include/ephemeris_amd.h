@@ -106,6 +106,9 @@ int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count);
  * the reference in the last bits of every acceleration (deterministic run to run). Unsharded systems of more than
  * 64 bodies; start-up steps and SRKN methods keep the ordered kernels. DESIGN.md "what bit-exactness costs". */
 #define EPH_PATH_FAST 4
+/* 5 = EPH_PATH_FAST_RSQ, OPT-IN: the fast path with 1/r^3 from v_rsq_f64 + two Newton steps instead of the IEEE square
+ * root and division (SURVEY 7 stage 3 "fast mode"): the pair terms themselves differ from the reference's in the last bit. */
+#define EPH_PATH_FAST_RSQ 5
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path);
 /* device time of the steady-state kernels launched by this handle so far, measured with HIP events on the
  * handle's stream: total milliseconds and launch count (used by bench.py for the roofline figure) */

@@ -39,6 +39,25 @@ def test_fast_path_is_deterministic_and_close_to_the_ordered_path(gpu, n):
     assert np.abs(v0 - ve).max() < 1e-6
 
 
+def test_fast_rsq_path(gpu):
+    """EPH_PATH_FAST_RSQ: the fast path with 1/r^3 from v_rsq_f64 + two Newton steps (no IEEE sqrt / divide): deterministic,
+    accelerations within a few ulp of the ordered path's pair terms summed in slice order."""
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(1000)
+    runs = []
+    for path in (0, 4, 5, 5):
+        g = gpu.NBodyIntegration(pos, vel, mu, 0.0, H)
+        g.set_path(path)
+        g.advance(12 + 1)                    # one steady step: the accelerations of the same positions
+        runs.append(g.acc())
+    exact, fast, rsq, rsq2 = runs
+    assert np.array_equal(rsq, rsq2)
+    scale = np.abs(exact).max()
+    assert 0.0 < np.abs(rsq - exact).max() < 1e-13 * scale and not np.array_equal(rsq, fast)
+    with pytest.raises(gpu.EphemerisError):
+        gpu.NBodyIntegration(pos, vel, mu, 0.0, H).set_path(6)
+
+
 def test_fast_path_refuses_what_it_does_not_cover(gpu):
     from conftest import load_system
     s = load_system("full_solar_system_2433282.5")
@@ -48,7 +67,7 @@ def test_fast_path_refuses_what_it_does_not_cover(gpu):
     with pytest.raises(gpu.EphemerisError):                   # 32 bodies: one workgroup, nothing to slice
         g.advance(1)
     with pytest.raises(gpu.EphemerisError):
-        g.set_path(5)
+        g.set_path(6)
 
 
 def test_fast_path_with_solout_sampling(gpu):
