@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MI
 # the other bench lines of the round (fast path, massless sweep, one large sharded system) + their kernel stats
 cd $GRAFT_REPO_ROOT
 python bench.py --path fast > $OUT/bench_fast.json 2> $OUT/bench_fast.err
+python bench.py --path fast-rsq > $OUT/bench_fast_rsq.json 2> $OUT/bench_fast_rsq.err
 python bench.py --workload craft --steps 3 > $OUT/bench_craft.json 2> $OUT/bench_craft.err
 python bench.py --workload nbody-sharded --steps 20 --warmup 3 > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
 cd /tmp

@@ -21,7 +21,7 @@ bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
 (dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1) + "\n")
 
 
-for extra in ("bench_fast", "bench_craft", "bench_sharded"):                      # the round's other bench lines
+for extra in ("bench_fast", "bench_fast_rsq", "bench_craft", "bench_sharded"):                      # the round's other bench lines
     f = src / f"{extra}.json"
     if f.exists() and f.read_text().strip():
         (dst / f"{tag}_{extra}.json").write_text(json.dumps(json.loads(f.read_text().strip().splitlines()[-1]), indent=1) + "\n")
