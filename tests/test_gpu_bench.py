@@ -1,0 +1,69 @@
+"""-m gpu: bench.py's contract and its N > 1 flow on a one-GPU box. The driver launches N ranks with
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`; here two ranks share the GPU
+(EPH_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device) for the three workloads: per-rank replicas, the sharded
+massless sweep with its result all-gather, and one system partitioned by target body (host-staged exchange)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+NEED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"]
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(args, ranks):
+    env = dict(os.environ, EPH_BENCH_BACKEND="gloo")
+    if ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_port()), str(ROOT / "bench.py"), "--gpus", str(ranks)] + args
+    else:
+        cmd = [sys.executable, str(ROOT / "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert not [k for k in NEED if k not in d], d.keys()
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    return d
+
+
+def test_default_line_single_gpu():
+    d = _run(["--steps", "10", "--warmup", "3", "--cpu-steps", "3", "--horizon", "100", "--prewarm", "0.2"], 1)
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["metric"] == "body-steps/s" and d["dtype"] == "f64"
+    assert d["value"] > 1e6                                        # the north star's floor
+    assert d["parity"]["max_abs_dpos"] == 0.0 and set(d["parity"]["horizon_max_abs_dpos"].values()) == {0.0}
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"]
+    assert "plummer_4096_f64_qt12" in d["config"]["workload"]
+
+
+def test_two_ranks_replicas():
+    d = _run(["--steps", "10", "--warmup", "3", "--prewarm", "0"], 2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e6
+
+
+def test_two_ranks_craft_sweep_with_result_gather():
+    d = _run(["--workload", "craft", "--craft", "4001", "--craft-days", "0.05", "--steps", "1", "--prewarm", "0"], 2)
+    assert d["n_gpus"] == 2 and d["metric"] == "craft-steps/s" and "all-gather" in d["config"]["exchange"]
+
+
+def test_two_ranks_one_sharded_system():
+    d = _run(["--workload", "nbody-sharded", "--bodies", "1024", "--transport", "host", "--steps", "5", "--warmup", "2",
+              "--prewarm", "0"], 2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_per_gpu"] == 512
