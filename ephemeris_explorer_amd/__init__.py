@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
-    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div",
 ]
 
 
@@ -204,6 +204,9 @@ def _lib():
     L.eph_plot_points.argtypes = [vp, C.POINTER(PlotView), i64, C.POINTER(PlotRequest), i64, _dp, _dp, _dp, i64, _dp,
                                   C.POINTER(C.c_float), _i64p, _i32p, _dp]
     L.eph_hermite_join.argtypes = [i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, i64, _dp, _dp, _dp, _i64p]
+    L.eph_transitions_join.argtypes = [i64, _dp, _i32p, i64, _dp, _i32p, f64, i64, _dp, _i32p, _i64p]
+    L.eph_apsides_join.argtypes = [i64, _dp, _dp, _i32p, _i32p, i64, _dp, _dp, _i32p, _i32p, f64, i64, _dp, _dp, _i32p,
+                                   _i32p, _i64p]
     L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
     L.eph_debug_div.argtypes = [i64, _dp, _dp, _dp, _dp]
     if L.eph_abi_version() != 1:
@@ -797,6 +800,38 @@ def hermite_join(lhs, rhs):
     _check(_lib().eph_hermite_join(len(lt), _p(lt), _p(lp), _p(lv), len(rt), _p(rt), _p(rp), _p(rv), cap, _p(t), _p(p),
                                    _p(v), C.byref(n)), "eph_hermite_join")
     return t[:n.value].copy(), p[:n.value].copy(), v[:n.value].copy()
+
+
+def transitions_join(lhs, rhs, at):
+    """item.transitions.clear_after(at); item.transitions.extend(rhs) -- the SoiTransitions half of
+    PredictionTarget::merge (ephemeris_explorer/src/dynamics/spacecraft.rs:838-839). lhs / rhs are (time, body) arrays;
+    `at` is the merged solution's trajectory.start(). Host only."""
+    lt, lb = _f64(lhs[0]).ravel(), np.ascontiguousarray(lhs[1], dtype=np.int32).ravel()
+    rt, rb = _f64(rhs[0]).ravel(), np.ascontiguousarray(rhs[1], dtype=np.int32).ravel()
+    cap = len(lt) + len(rt)
+    t, b = np.zeros(max(cap, 1)), np.zeros(max(cap, 1), dtype=np.int32)
+    n = C.c_int64()
+    _check(_lib().eph_transitions_join(len(lt), _p(lt), _p(lb, _i32p), len(rt), _p(rt), _p(rb, _i32p), float(at), cap, _p(t),
+                                       _p(b, _i32p), C.byref(n)), "eph_transitions_join")
+    return t[:n.value].copy(), b[:n.value].copy()
+
+
+def apsides_join(lhs, rhs, at):
+    """item.apsides.clear_after(at); item.apsides.extend(rhs) (ephemeris_explorer/src/dynamics/spacecraft.rs:836-837).
+    lhs / rhs are (time, distance, kind, body) arrays. Host only."""
+    def parts(x):
+        return (_f64(x[0]).ravel(), _f64(x[1]).ravel(), np.ascontiguousarray(x[2], dtype=np.int32).ravel(),
+                np.ascontiguousarray(x[3], dtype=np.int32).ravel())
+    lt, ld, lk, lb = parts(lhs)
+    rt, rd, rk, rb = parts(rhs)
+    cap = len(lt) + len(rt)
+    m = max(cap, 1)
+    t, d, k, b = np.zeros(m), np.zeros(m), np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
+    n = C.c_int64()
+    _check(_lib().eph_apsides_join(len(lt), _p(lt), _p(ld), _p(lk, _i32p), _p(lb, _i32p), len(rt), _p(rt), _p(rd), _p(rk, _i32p),
+                                   _p(rb, _i32p), float(at), cap, _p(t), _p(d), _p(k, _i32p), _p(b, _i32p), C.byref(n)),
+           "eph_apsides_join")
+    return t[:n.value].copy(), d[:n.value].copy(), k[:n.value].copy(), b[:n.value].copy()
 
 
 def debug_div(a, b):

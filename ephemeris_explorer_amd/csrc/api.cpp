@@ -498,4 +498,53 @@ int32_t eph_hermite_join(int64_t n_lhs, const double *t_lhs, const double *pos_l
     return EPH_OK;
 }
 
+// SoiTransitions::clear_after(at) then ::extend(rhs)   (app dynamics/spacecraft.rs:341-346, 356-361, 331-337): the
+// event half of PredictionTarget::merge (:836-839). Times inside one list are unique (insert replaces), so the
+// binary search is a partition point.
+int32_t eph_transitions_join(int64_t n_lhs, const double *t_lhs, const int32_t *body_lhs, int64_t n_rhs, const double *t_rhs,
+                             const int32_t *body_rhs, double at, int64_t capacity, double *t_out, int32_t *body_out,
+                             int64_t *n_out) {
+    if (n_lhs < 0 || n_rhs < 0 || capacity < 0 || !n_out || (n_lhs > 0 && (!t_lhs || !body_lhs)) ||
+        (n_rhs > 0 && (!t_rhs || !body_rhs)) || capacity < n_lhs + n_rhs || (capacity > 0 && (!t_out || !body_out)))
+        return EPH_ERR_BAD_ARGUMENT;
+    int64_t n = 0;
+    for (int64_t k = 0; k < n_lhs && t_lhs[k] <= at; ++k, ++n) {              // Ok(i) => truncate(i + 1), Err(i) => truncate(i)
+        t_out[n] = t_lhs[k];
+        body_out[n] = body_lhs[k];
+    }
+    for (int64_t r = 0; r < n_rhs; ++r) {                                     // for (time, entity) in other.0 { self.insert(..) }
+        int64_t i = 0;
+        while (i < n && t_out[i] < t_rhs[r]) ++i;
+        if (i < n && t_out[i] == t_rhs[r]) { body_out[i] = body_rhs[r]; continue; }          // Ok(i) => self.0[i] = ..
+        if (i > 0 && body_out[i - 1] == body_rhs[r]) continue;                               // same sphere as before: no entry
+        for (int64_t k = n; k > i; --k) { t_out[k] = t_out[k - 1]; body_out[k] = body_out[k - 1]; }
+        t_out[i] = t_rhs[r];
+        body_out[i] = body_rhs[r];
+        ++n;
+    }
+    *n_out = n;
+    return EPH_OK;
+}
+
+// Apsides::clear_after(at) then ::extend(rhs)   (app dynamics/spacecraft.rs:431-436, 426-428): extend is a plain
+// append here (no sorted insert, unlike the transitions).
+int32_t eph_apsides_join(int64_t n_lhs, const double *t_lhs, const double *distance_lhs, const int32_t *kind_lhs,
+                         const int32_t *body_lhs, int64_t n_rhs, const double *t_rhs, const double *distance_rhs,
+                         const int32_t *kind_rhs, const int32_t *body_rhs, double at, int64_t capacity, double *t_out,
+                         double *distance_out, int32_t *kind_out, int32_t *body_out, int64_t *n_out) {
+    if (n_lhs < 0 || n_rhs < 0 || capacity < 0 || !n_out || (n_lhs > 0 && (!t_lhs || !distance_lhs || !kind_lhs || !body_lhs)) ||
+        (n_rhs > 0 && (!t_rhs || !distance_rhs || !kind_rhs || !body_rhs)) || capacity < n_lhs + n_rhs ||
+        (capacity > 0 && (!t_out || !distance_out || !kind_out || !body_out)))
+        return EPH_ERR_BAD_ARGUMENT;
+    int64_t n = 0;
+    for (int64_t k = 0; k < n_lhs && t_lhs[k] <= at; ++k, ++n) {
+        t_out[n] = t_lhs[k]; distance_out[n] = distance_lhs[k]; kind_out[n] = kind_lhs[k]; body_out[n] = body_lhs[k];
+    }
+    for (int64_t r = 0; r < n_rhs; ++r, ++n) {
+        t_out[n] = t_rhs[r]; distance_out[n] = distance_rhs[r]; kind_out[n] = kind_rhs[r]; body_out[n] = body_rhs[r];
+    }
+    *n_out = n;
+    return EPH_OK;
+}
+
 }  // extern "C"

@@ -357,6 +357,24 @@ int32_t eph_hermite_join(int64_t n_lhs, const double *t_lhs, const double *pos_l
                          int64_t n_rhs, const double *t_rhs, const double *pos_rhs, const double *vel_rhs,
                          int64_t capacity, double *t_out, double *pos_out, double *vel_out, int64_t *n_out);
 
+/* The event half of PredictionTarget::merge (ephemeris_explorer/src/dynamics/spacecraft.rs:836-839), host only:
+ *   item.transitions.clear_after(solution.trajectory.start()); item.transitions.extend(solution.transitions);
+ *   item.apsides.clear_after(solution.trajectory.start());     item.apsides.extend(solution.apsides);
+ * `at` is solution.trajectory.start() (the first knot of the slab being merged). clear_after keeps the entries with
+ * t <= at (:341-346, :431-436: Ok(i) => truncate(i + 1), Err(i) => truncate(i); with several apsides at exactly `at`
+ * Rust's binary search may stop at any of them -- this keeps them all). SoiTransitions::extend inserts every entry
+ * in time order, replaces an entry with the same time and drops one whose predecessor is the same body (:331-337,
+ * :356-361); Apsides::extend appends (:426-428). lhs and rhs are the parallel arrays eph_craft_batch_events fills
+ * (kind: 0 = Periapsis, 1 = Apoapsis); the outputs hold capacity >= n_lhs + n_rhs entries and may be the lhs
+ * arrays themselves (never the rhs ones: the sorted insert moves entries); *n_out is the joined length. */
+int32_t eph_transitions_join(int64_t n_lhs, const double *t_lhs, const int32_t *body_lhs, int64_t n_rhs, const double *t_rhs,
+                             const int32_t *body_rhs, double at, int64_t capacity, double *t_out, int32_t *body_out,
+                             int64_t *n_out);
+int32_t eph_apsides_join(int64_t n_lhs, const double *t_lhs, const double *distance_lhs, const int32_t *kind_lhs,
+                         const int32_t *body_lhs, int64_t n_rhs, const double *t_rhs, const double *distance_rhs,
+                         const int32_t *kind_rhs, const int32_t *body_rhs, double at, int64_t capacity, double *t_out,
+                         double *distance_out, int32_t *kind_out, int32_t *body_out, int64_t *n_out);
+
 /* Test hook: the step-size controller's correctly rounded pow(x[i], y) on the device */
 int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out);
 /* test hook: a[i] / b[i] through the shared-reciprocal division of k_craft_wave and through the compiler's IEEE

@@ -849,6 +849,45 @@ def hermite_join(lhs, rhs):
     return [k for k in lhs if at > k[0]] + list(rhs)
 
 
+def _rust_binary_search(times, t):
+    """slice::binary_search_by on a sorted list: ("ok", i) when times[i] == t, else ("err", insertion index)."""
+    import bisect
+    i = bisect.bisect_left(times, t)
+    return ("ok", i) if i < len(times) and times[i] == t else ("err", i)
+
+
+def transitions_clear_after(tr, at):
+    """SoiTransitions::clear_after (ephemeris_explorer/src/dynamics/spacecraft.rs:341-346). tr: list of (time, body)."""
+    kind, i = _rust_binary_search([t for t, _ in tr], at)
+    return tr[:i + 1] if kind == "ok" else tr[:i]
+
+
+def transitions_insert(tr, time, body):
+    """SoiTransitions::insert (:331-337): replace at an equal time; no entry when the previous one is the same body."""
+    kind, i = _rust_binary_search([t for t, _ in tr], time)
+    if kind == "ok":
+        tr[i] = (time, body)
+    elif i > 0 and tr[i - 1][1] == body:
+        pass
+    else:
+        tr.insert(i, (time, body))
+
+
+def transitions_join(lhs, rhs, at):
+    """item.transitions.clear_after(at); item.transitions.extend(rhs)   (:838-839, extend = insert each, :356-361)"""
+    out = transitions_clear_after(list(lhs), at)
+    for time, body in rhs:
+        transitions_insert(out, time, body)
+    return out
+
+
+def apsides_join(lhs, rhs, at):
+    """item.apsides.clear_after(at); item.apsides.extend(rhs)   (:836-837; clear_after :431-436, extend appends :426-428).
+    Entries are (time, distance, kind, body); times distinct at the cut."""
+    kind, i = _rust_binary_search([a[0] for a in lhs], at)
+    return list(lhs[:i + 1] if kind == "ok" else lhs[:i]) + list(rhs)
+
+
 # ---- adaptive plot sampling (ephemeris_explorer/src/ui/world/plot.rs:93-149,318-374,429-436) ---------------------------
 def _f32(x):
     import struct

@@ -186,3 +186,44 @@ def test_hermite_join_matches_restatement(ea):
                               rt.ctypes.data_as(dp), z.ctypes.data_as(dp), z.ctypes.data_as(dp), 2,
                               out_t.ctypes.data_as(dp), out_p.ctypes.data_as(dp), out_p.ctypes.data_as(dp), ctypes.byref(n))
     assert st == -1 and n.value == 4 and (out_t == -1.0).all()
+
+
+def test_event_joins_match_restatement(ea):
+    """eph_transitions_join / eph_apsides_join = the event half of PredictionTarget::merge
+    (ephemeris_explorer/src/dynamics/spacecraft.rs:836-839), host logic, against the restated list operations."""
+    rng = np.random.default_rng(33)
+    grid = np.arange(0.0, 400.0, 10.0)
+    for case in range(300):
+        nl, nr = int(rng.integers(0, 10)), int(rng.integers(0, 8))
+        lt = np.sort(rng.choice(grid, nl, replace=False))
+        lb = rng.integers(0, 4, nl).astype(np.int32)
+        # the new list overlaps the old one: same times, new times, repeated spheres
+        rt = np.sort(rng.choice(np.concatenate([grid, grid + 5.0]), nr, replace=False))
+        rb = rng.integers(0, 4, nr).astype(np.int32)
+        at = float(rng.choice(list(lt) + [-5.0, 155.0, 1e9]))
+        want = po.transitions_join(list(zip(lt.tolist(), lb.tolist())), list(zip(rt.tolist(), rb.tolist())), at)
+        t, b = ea.transitions_join((lt, lb), (rt, rb), at)
+        assert list(zip(t.tolist(), b.tolist())) == want, case
+        assert (np.diff(t) > 0).all()                        # stays sorted with unique times
+
+        ld, lk = rng.uniform(1e6, 1e9, nl), rng.integers(0, 2, nl).astype(np.int32)
+        rt2 = np.sort(rng.uniform(max(at, 0.0), max(at, 0.0) + 100.0, nr))    # a solution's apsides come after its start
+        rd, rk = rng.uniform(1e6, 1e9, nr), rng.integers(0, 2, nr).astype(np.int32)
+        want = po.apsides_join(list(zip(lt.tolist(), ld.tolist(), lk.tolist(), lb.tolist())),
+                               list(zip(rt2.tolist(), rd.tolist(), rk.tolist(), rb.tolist())), at)
+        got = ea.apsides_join((lt, ld, lk, lb), (rt2, rd, rk, rb), at)
+        assert list(zip(*(g.tolist() for g in got))) == want, case
+    # in place on the lhs arrays, and the argument checks
+    import ctypes
+    lib = ea._lib()
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    t = np.array([0.0, 10.0, 20.0, 0.0, 0.0]); b = np.array([0, 1, 2, 0, 0], dtype=np.int32)
+    rt = np.array([12.0, 15.0]); rb = np.array([1, 3], dtype=np.int32)
+    n = ctypes.c_int64()
+    st = lib.eph_transitions_join(3, t.ctypes.data_as(dp), b.ctypes.data_as(ip), 2, rt.ctypes.data_as(dp),
+                                  rb.ctypes.data_as(ip), 10.0, 5, t.ctypes.data_as(dp), b.ctypes.data_as(ip), ctypes.byref(n))
+    # 20 s is cut; (12, body 1) follows an entry of body 1 and is dropped; (15, body 3) is kept
+    assert st == 0 and n.value == 3 and t[:3].tolist() == [0.0, 10.0, 15.0] and b[:3].tolist() == [0, 1, 3]
+    st = lib.eph_transitions_join(3, t.ctypes.data_as(dp), b.ctypes.data_as(ip), 2, rt.ctypes.data_as(dp),
+                                  rb.ctypes.data_as(ip), 10.0, 4, t.ctypes.data_as(dp), b.ctypes.data_as(ip), ctypes.byref(n))
+    assert st == -1
