@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
-    "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_wg_cycles",
+    "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_inv_r3_sweep", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
@@ -175,6 +175,7 @@ def _lib():
     L.eph_solution_destroy.restype = None
     L.eph_least_squares_fit.argtypes = [i32, i32, i64, _dp, _dp, _i32p]
     L.eph_debug_inv_r3.argtypes = [i64, _dp, _dp, _dp]
+    L.eph_debug_inv_r3_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.eph_ephemeris_create.argtypes = [vp, _dp, C.POINTER(vp)]
     L.eph_ephemeris_interpolation_errors.argtypes = [vp, vp, i64, _dp, C.POINTER(i64)]
     L.eph_ephemeris_destroy.argtypes = [vp]
@@ -288,6 +289,14 @@ def debug_inv_r3(n2):
     fast, ieee = np.zeros_like(n2), np.zeros_like(n2)
     _check(_lib().eph_debug_inv_r3(n2.size, _p(n2), _p(fast), _p(ieee)), "eph_debug_inv_r3")
     return fast, ieee
+
+
+def debug_inv_r3_sweep(seed, n):
+    """(mismatches, bits of one mismatching operand) of the in-range 1/(x*sqrt(x)) sequence against the IEEE expansion
+    over n device-generated operands."""
+    bad, ex = C.c_uint64(), C.c_uint64()
+    _check(_lib().eph_debug_inv_r3_sweep(int(seed), int(n), C.byref(bad), C.byref(ex)), "eph_debug_inv_r3_sweep")
+    return bad.value, ex.value
 
 
 def _shard_call(fn, name, handle, rank, world, unique_id, exchange):

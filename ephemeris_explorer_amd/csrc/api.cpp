@@ -465,6 +465,23 @@ int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee
     EPH_GUARD_END
 }
 
+int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, uint64_t *example_bits) {
+    EPH_GUARD_BEGIN
+    if (n < 0 || !mismatches || !example_bits) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    DevBuf<unsigned long long> out;
+    if ((st = out.alloc(2))) return st;
+    EPH_HIP(hipMemset(out.p, 0, 2 * sizeof(unsigned long long)));
+    if ((st = launch_debug_inv_r3_sweep(nullptr, seed, n, out.p))) return st;
+    unsigned long long h[2];
+    EPH_HIP(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+    *mismatches = h[0];
+    *example_bits = h[1];
+    return EPH_OK;
+    EPH_GUARD_END
+}
+
 int32_t eph_debug_wg_cycles(int64_t *out8) {
     if (!out8) return EPH_ERR_BAD_ARGUMENT;
     return debug_wg_cycles((long long *)out8);

@@ -61,7 +61,35 @@ constexpr int kPairVariant = EPH_PAIR_VARIANT;
 // in_range(n2) keeps every intermediate of every variant inside the exponent range where the stripped sequences
 // equal the compiler's IEEE expansions: n2 in [2^-300, 2^300) => sqrt in [2^-150, 2^150), products and reciprocals
 // within [2^-450, 2^450].
+// Variant 0 with the reciprocal's seed taken from the square root's own refinement instead of a second quarter-rate
+// v_rcp_f64: after the coupled step h = 0.5 / sqrt(x) to ~2^-45 or better, so 8 h^3 = 1 / (x sqrt(x)) to ~2^-43 -- far
+// tighter than the hardware seed (~2^-26), which makes the first of rcp_inrange's two Newton steps redundant. One
+// Newton step leaves r within half an ulp (+2^-80) of 1 / p, the same faithful value the compiler's sequence reaches,
+// and the closing residual step rounds it correctly: bit-identical to 1.0 / (x * sqrt(x)) (same tests as rcp_inrange,
+// plus scripts/sweep_inv_r3.py over 2^32 operands). Saves a transcendental and one fma per interaction.
+#ifndef EPH_RCP_SEED_FROM_RSQ
+#define EPH_RCP_SEED_FROM_RSQ 1
+#endif
+__device__ __forceinline__ double inv_r3_seeded(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);                         // sqrt(x), correctly rounded (sqrt_inrange)
+    const double p = x * g;
+    double q = (h * h) * h * 8.0;                       // ~ 1 / p
+    double e = __builtin_fma(-p, q, 1.0);
+    q = __builtin_fma(q, e, q);
+    e = __builtin_fma(-p, q, 1.0);
+    return __builtin_fma(e, q, q);
+}
 __device__ __forceinline__ double inv_r3_inrange(double n2) {
+    if constexpr (kPairVariant == 0 && EPH_RCP_SEED_FROM_RSQ) return inv_r3_seeded(n2);
     if constexpr (kPairVariant == 1) { const double r = sqrt_inrange(n2); return rcp_inrange(r * r * r); }
     else if constexpr (kPairVariant == 2) { const double s = rcp_inrange(sqrt_inrange(n2)); return s * s * s; }
     else if constexpr (kPairVariant == 3) return rcp_inrange(n2) * rcp_inrange(sqrt_inrange(n2));

@@ -116,6 +116,7 @@ int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const Sam
 int launch_carry(hipStream_t s, int n, const uint64_t *region, const uint32_t *src, const uint32_t *cnt, double *log);
 // test hook: 1/(x*sqrt(x)) through the in-range fast sequences and through the compiler's IEEE expansions
 int launch_debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee);
+int launch_debug_inv_r3_sweep(hipStream_t s, uint64_t seed, int64_t n, unsigned long long *out2);   // rounds n up to 2^20
 int debug_wg_cycles(long long *out);   // EPH_DEBUG_WG=3 cycle accounting of the workgroup force kernel
 // AoS <-> SoA staging
 int launch_aos_to_soa(hipStream_t s, int n, int npad, const double *aos, double *soa);

@@ -60,6 +60,30 @@ __global__ void k_debug_inv_r3(long long n, const double *__restrict__ n2, doubl
     ieee[i] = inv_r3_ieee(x);
 }
 
+// Sweep of the in-range sequence against the compiler's IEEE expansion over counter-generated operands (splitmix64 of
+// seed + index: 52 random mantissa bits, biased exponent uniform over the guarded range [723, 1323)). out[0] = number of
+// operands whose two results differ in any bit, out[1] = the bits of one such operand.
+__global__ void k_debug_inv_r3_sweep(unsigned long long seed, int per_thread, unsigned long long *out) {
+    unsigned long long idx = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * (unsigned long long)per_thread;
+    unsigned bad = 0;
+    unsigned long long bad_x = 0;
+    for (int k = 0; k < per_thread; ++k, ++idx) {
+        unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const unsigned long long expo = 723ull + (z >> 52) % 600ull;
+        const unsigned long long bits = (expo << 52) | (z & 0xFFFFFFFFFFFFFull);
+        const double x = __longlong_as_double((long long)bits);
+        const double f = inv_r3_inrange(x), g = inv_r3_ieee(x);
+        if (__double_as_longlong(f) != __double_as_longlong(g)) { ++bad; bad_x = bits; }
+    }
+    if (bad) {
+        atomicAdd(&out[0], (unsigned long long)bad);
+        atomicExch(&out[1], bad_x);
+    }
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     // same-wave LDS hand-off (lane-per-source writes -> lane-per-chain reads): DS ops of one wave execute in
     // order; this only stops the compiler from moving them across.
@@ -169,6 +193,11 @@ __device__ __forceinline__ double &pair_stage(TileCtx<BPW> &w) {
     else if constexpr (S == 8) { w.d[B] = __builtin_fma(-w.g[B], w.g[B], x); return w.d[B]; }
     else if constexpr (S == 9) { w.g[B] = __builtin_fma(w.d[B], w.h[B], w.g[B]); return w.g[B]; }       // sqrt(n2)
     else if constexpr (S == 10) { w.p[B] = x * w.g[B]; return w.p[B]; }                                 // n2*sqrt(n2)
+    // S11-13: the reciprocal's seed, 8 h^3 from the square root's refined h (inv_r3_seeded, device_math.h) or the
+    // hardware seed plus one Newton step (rcp_inrange); the remaining steps are common
+    else if constexpr (S == 11 && EPH_RCP_SEED_FROM_RSQ) { w.r[B] = w.h[B] * w.h[B]; return w.r[B]; }
+    else if constexpr (S == 12 && EPH_RCP_SEED_FROM_RSQ) { w.r[B] = w.r[B] * w.h[B]; return w.r[B]; }
+    else if constexpr (S == 13 && EPH_RCP_SEED_FROM_RSQ) { w.r[B] = w.r[B] * 8.0; return w.r[B]; }
     else if constexpr (S == 11) { w.r[B] = __builtin_amdgcn_rcp(w.p[B]); return w.r[B]; }
     else if constexpr (S == 12) { w.d[B] = __builtin_fma(-w.p[B], w.r[B], 1.0); return w.d[B]; }
     else if constexpr (S == 13) { w.r[B] = __builtin_fma(w.r[B], w.d[B], w.r[B]); return w.r[B]; }
@@ -521,6 +550,9 @@ __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
 // 64-source tile. The chain wave shares its SIMD with pair wave 0 (waves of a workgroup go to SIMDs round-robin),
 // which therefore gets fewer bodies; the hardware interleaves the two and the adds' bubbles get filled.
 // ------------------------------------------------------------------------------------------------------
+#ifndef EPH_PAIR_LOOP
+#define EPH_PAIR_LOOP 0
+#endif
 constexpr int kWgBodies = 16;
 constexpr int kWgPairWaves = 4;                      // index of the chain wave (wave 4: lands on the SIMD of wave 0)
 // Role layouts (waves of a workgroup go to the four SIMDs round-robin: wave k -> SIMD k % 4):
@@ -532,10 +564,24 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 //   3: layout 1's roles with ONE barrier per 128 sources (two 64-source tiles, six LDS buffers): half the barriers,
 //                  and every pair wave carries twice as many independent interactions between them
 //   4: layout 3's barrier schedule with layout 2's roles (chain wave alone on SIMD 0, pair waves 3/3/3 + 3/2/2)
-constexpr int wg_threads(int layout) { return layout >= 1 ? 64 * 8 : 64 * 5; }
-constexpr bool wg_big(int layout) { return layout == 3 || layout == 4; }
+//   5: TWELVE waves (three per SIMD, <= 168 VGPRs each), layout 3's barrier schedule: SIMD 0 = one-body pair wave + chain
+//                  wave + an idle wave, SIMDs 1-3 = pair waves of 2/2/1 bodies -- a third wave per SIMD to fill the f64
+//                  issue gaps two leave (the fast path's pair arithmetic: 253 cycles per interaction at two waves per
+//                  SIMD, 196 at four). The step kernel loads its history AFTER the force here (registers).
+//   6: layout 5 with the idle wave given a body (SIMD 0: 1 + chain + 1; SIMDs 1-3: 2/2/1, 2/2/1, 2/1/1)
+// In layout 5 the step kernel's history / Cowell / predictor work moves from the chain wave to the idle wave 8 (the "tail
+// wave"): it loads the 2 L history values while the others work and receives the new acceleration through LDS. (Giving
+// that work to a pair wave stalls the whole workgroup at the first barrier: a wave's loads return in order, so its first
+// source tile queues behind 24 history loads -- 40.3-40.7 us. Layout 6 has no idle wave: its chain wave loads the history
+// AFTER the force, the 168-register budget having no room to carry it through the loop.)
+// Measured and dropped: sixteen waves (four per SIMD, <= 128 VGPRs, chain read ring of two chunks) 41.0-42.9 us.
+constexpr int wg_threads(int layout) { return layout >= 5 ? 64 * 12 : layout >= 1 ? 64 * 8 : 64 * 5; }
+constexpr int wg_tail_wave(int layout) { return layout == 5 ? 8 : 4; }   // 4 = the chain wave itself
+constexpr bool wg_big(int layout) { return layout >= 3; }
 constexpr int wg_bufs(int layout) { return wg_big(layout) ? 6 : 3; }
-constexpr int kWgDefaultLayout = 3;   // measured at N = 4096 (us per step): layout 0 47.8, 1 44.6, 2 48.9, 3 41.6 (gpurun_out r02c, r02d)
+// measured at N = 4096 (us per step): layout 0 47.8, 1 44.6, 2 48.9, 3 41.6 (gpurun_out r02c, r02d); with the seeded
+// reciprocal 3: 40.2, 5: 37.0, 6: 39.0 (r02q)
+constexpr int kWgDefaultLayout = 5;
 constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
 constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave
@@ -548,6 +594,8 @@ __device__ __forceinline__ void wg_pair_tile(const double (&xi)[NB], const doubl
                                              const Body4 &pj, bool ieee, double *tile, int b0, int lane) {
     // (forcing a stage-major interleave of the NB interactions with scheduling anchors was measured: no gain
     // over the compiler's own schedule here, 1380 vs 1400 cycles per 5-body tile)
+    // (the workgroup's own tile goes to the IEEE form as a whole -- n2 = 0 on the self lanes; giving those lanes a
+    // harmless in-range operand instead, since the chain wave never reads them, was measured: no gain, 40.1 vs 40.0 us)
     PairPre pre[NB];
     unsigned worst = ieee ? kRangeSpan : 0u;           // max of the range keys: one add + one max per body
 #pragma unroll
@@ -661,9 +709,22 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
         yi[b] = pos[ii].y;
         zi[b] = pos[ii].z;
     }
+    // EPH_PAIR_LOOP (tuning; -DEPH_PAIR_LOOP=k, scripts/build_exp.sh): bit 0 = source rows addressed as SGPR tile base +
+    // loop-invariant VGPR byte offset (only the last tile of a ragged n clamps it); bit 1 = two iterations per trip with
+    // the (a, b) and (na, nb) register sets trading places instead of being copied. Both remove VALU bookkeeping (about 20
+    // of the ~260 instructions of an iteration) and both measured SLOWER at N = 4096: 0: 39.78, 1: 40.32, 2: 40.05,
+    // 3: 40.27 us per step (gpurun_out r02m) -- the pair waves are bound by f64 issue, not by their integer overhead.
+    const unsigned off_full = (unsigned)lane * (unsigned)sizeof(Body4);
+    const unsigned off_last = (unsigned)min(lane, n - 1 - (tiles - 1) * kTile) * (unsigned)sizeof(Body4);
     auto load_src = [&](int t) -> Body4 {
-        const int j = min(t, tiles - 1) * kTile + lane;
-        return pos[j < n ? j : n - 1];
+        if constexpr (EPH_PAIR_LOOP & 1) {
+            const int tt = min(t, tiles - 1);
+            const char *tp = (const char *)&pos[(size_t)tt * kTile];
+            return *(const Body4 *)(tp + (tt == tiles - 1 ? off_last : off_full));
+        } else {
+            const int j = min(t, tiles - 1) * kTile + lane;
+            return pos[j < n ? j : n - 1];
+        }
     };
     auto produce = [&](int K, const Body4 &pa, const Body4 &pb) {          // big tile K
         const int t = big_start(K);
@@ -677,11 +738,23 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
     produce(0, pa, pa);
     produce(1, pb, pb);
     __syncthreads();
-    for (int K = 0; K < TB; ++K) {
-        pa = na; pb = nb;
-        na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
-        produce(K + 2, pa, pb);
-        __syncthreads();
+    if constexpr (EPH_PAIR_LOOP & 2) {
+        for (int K = 0; K < TB; K += 2) {
+            pa = load_src(big_start(K + 3)); pb = load_src(big_start(K + 3) + 1);
+            produce(K + 2, na, nb);
+            __syncthreads();
+            if (K + 1 >= TB) break;
+            na = load_src(big_start(K + 4)); nb = load_src(big_start(K + 4) + 1);
+            produce(K + 3, pa, pb);
+            __syncthreads();
+        }
+    } else {
+        for (int K = 0; K < TB; ++K) {
+            pa = na; pb = nb;
+            na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
+            produce(K + 2, pa, pb);
+            __syncthreads();
+        }
     }
 }
 
@@ -721,7 +794,37 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
     // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
     // under the denser f64 stream and the step gets slower.)
-    if constexpr (LAYOUT == 4) {
+    if constexpr (LAYOUT == 5) {
+        switch (wave) {
+            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
+            case 8: for (int T = 0; T <= big_count(tiles); ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
+            case 1: wg_pair_wave_big<2>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
+            case 5: wg_pair_wave_big<2>(pos, n, i0, 3, C, lane, tiles, tdiag); return 0.0;
+            case 9: wg_pair_wave_big<1>(pos, n, i0, 5, C, lane, tiles, tdiag); return 0.0;
+            case 2: wg_pair_wave_big<2>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 8, C, lane, tiles, tdiag); return 0.0;
+            case 10: wg_pair_wave_big<1>(pos, n, i0, 10, C, lane, tiles, tdiag); return 0.0;
+            case 3: wg_pair_wave_big<2>(pos, n, i0, 11, C, lane, tiles, tdiag); return 0.0;
+            case 7: wg_pair_wave_big<2>(pos, n, i0, 13, C, lane, tiles, tdiag); return 0.0;
+            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag); return 0.0;
+            default: break;
+        }
+    } else if constexpr (LAYOUT == 6) {
+        switch (wave) {
+            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
+            case 8: wg_pair_wave_big<1>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
+            case 1: wg_pair_wave_big<2>(pos, n, i0, 2, C, lane, tiles, tdiag); return 0.0;
+            case 5: wg_pair_wave_big<2>(pos, n, i0, 4, C, lane, tiles, tdiag); return 0.0;
+            case 9: wg_pair_wave_big<1>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
+            case 2: wg_pair_wave_big<2>(pos, n, i0, 7, C, lane, tiles, tdiag); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 9, C, lane, tiles, tdiag); return 0.0;
+            case 10: wg_pair_wave_big<1>(pos, n, i0, 11, C, lane, tiles, tdiag); return 0.0;
+            case 3: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag); return 0.0;
+            case 7: wg_pair_wave_big<1>(pos, n, i0, 14, C, lane, tiles, tdiag); return 0.0;
+            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag); return 0.0;
+            default: break;
+        }
+    } else if constexpr (LAYOUT == 4) {
         switch (wave) {
             case 0: for (int T = 0; T <= big_count(tiles); ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
             case 1: wg_pair_wave_big<3>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
@@ -815,7 +918,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
         }
         if ((dbg & 4) && blockIdx.x == 7 && lane == 0) { g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
         return accL + acc;
-    }
+    } else {
     for (int t = 0; t < tiles; ++t) {
         const long long c0 = __builtin_readcyclecounter();
         const double *r = row + (t % kWgBufs) * kWgBuf;
@@ -837,6 +940,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     }
     if ((dbg & 4) && blockIdx.x == 7 && lane == 0) { g_wg_cycles[4] = t_work; g_wg_cycles[5] = t_bar; g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
     return accL + acc;
+    }
 }
 
 template <int LAYOUT>
@@ -863,46 +967,71 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
     __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool chain_wave = (tid >> 6) == kWgPairWaves;
+    // the wave that does the integrator's work around the force; wave-uniform by construction, and told so (a scalar
+    // branch keeps the history registers out of the other roles' live ranges)
+    const bool tail_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == wg_tail_wave(LAYOUT);
     const int i0 = a.lo + blockIdx.x * kWgBodies;
     const int cb = lane / 3, cc = lane % 3;
     const int my_i = i0 + cb;
-    const bool owner = chain_wave && lane < kWgRows && my_i < a.hi;
+    const bool owner = tail_wave && lane < kWgRows && my_i < a.hi;
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + (owner ? my_i : 0);
 
-    double yv[L], av[L];   // history of this lane's (body, component); loaded before the pair loop, used after it
-    if (chain_wave) {
+    // history of this lane's (body, component): loaded before the force loop and used after it (layout 6: loaded after)
+    auto load_history = [&](double (&yv)[L], double (&av)[L]) {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             const int slot = (a.cur + j) % L;
             yv[j] = a.Y[slot * lvl + off];
             av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
         }
-    }
-    const long long t_entry = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
-    const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
-    const long long t_force = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
-    if ((a.wg_flags & 4) && chain_wave && lane == 0) {       // tuning: where a launch spends its time (EPH_DEBUG_WG=4)
-        if (blockIdx.x == 7) { g_wg_cycles[0] = t_force - t_entry; }
-        if (blockIdx.x < 1024) { g_wg_span[0][blockIdx.x] = t_entry; g_wg_span[1][blockIdx.x] = t_force; }
-    }
-    if (!owner) return;
-
-    a.A[(size_t)a.cur * lvl + off] = anew;
-    {
-        double prev[L];
+    };
+    auto finish = [&](double (&yv)[L], double (&av)[L], double anew) {   // the step around the force, owner lanes only
+        a.A[(size_t)a.cur * lvl + off] = anew;
+        {
+            double prev[L];
 #pragma unroll
-        for (int j = 0; j < L - 1; ++j) prev[j] = av[j + 1];
-        prev[L - 1] = 0.0;
-        a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
-    }
-    maybe_sample(a.samp, my_i, cc, a.step, yv[0]);
-    if (a.do_predict) {
-        av[0] = anew;
-        const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
-        const int nslot = (a.cur + L - 1) % L;
-        a.Y[(size_t)nslot * lvl + off] = ynext;
-        reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
+            for (int j = 0; j < L - 1; ++j) prev[j] = av[j + 1];
+            prev[L - 1] = 0.0;
+            a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
+        }
+        maybe_sample(a.samp, my_i, cc, a.step, yv[0]);
+        if (a.do_predict) {
+            av[0] = anew;
+            const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
+            const int nslot = (a.cur + L - 1) % L;
+            a.Y[(size_t)nslot * lvl + off] = ynext;
+            reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
+        }
+    };
+    if constexpr (wg_tail_wave(LAYOUT) != kWgPairWaves) {
+        // the tail wave's whole life is this branch, so its history registers are live across this code only (through
+        // wg_force's role switch the allocator would keep them alive in every role and spill)
+        if (tail_wave) {
+            double yv[L], av[L];
+            load_history(yv, av);
+            const int tiles = (a.n + kTile - 1) / kTile;
+            for (int T = 0; T <= big_count(tiles); ++T) __syncthreads();   // the idle wave's role: TB + 1 barriers
+            __syncthreads();                              // the chain wave's result is in LDS
+            if (owner) finish(yv, av, C[lane]);
+        } else {
+            const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
+            if (chain_wave && lane < kWgRows) C[lane] = anew;    // every tile buffer is dead after the loop's last barrier
+            __syncthreads();
+        }
+    } else {
+        double yv[L], av[L];
+        if (tail_wave && LAYOUT != 6) load_history(yv, av);
+        const long long t_entry = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
+        const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
+        const long long t_force = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
+        if ((a.wg_flags & 4) && chain_wave && lane == 0) {       // tuning: where a launch spends its time (EPH_DEBUG_WG=4)
+            if (blockIdx.x == 7) { g_wg_cycles[0] = t_force - t_entry; }
+            if (blockIdx.x < 1024) { g_wg_span[0][blockIdx.x] = t_entry; g_wg_span[1][blockIdx.x] = t_force; }
+        }
+        if (!owner) return;
+        if constexpr (LAYOUT == 6) load_history(yv, av);
+        finish(yv, av, anew);
     }
 }
 
@@ -1576,7 +1705,7 @@ int lm_bodies_per_wave(int n) {
 // (1 no chain, 2 no pair work, 4 cycle accounting into g_wg_cycles, 8 chain wave at raised priority)
 static int wg_layout() {
     static const int v = [] { const char *e = getenv("EPH_WG_LAYOUT"); return e ? atoi(e) : kWgDefaultLayout; }();
-    return v >= 1 && v <= 4 ? v : 0;
+    return v >= 1 && v <= 6 ? v : 0;
 }
 static int wg_debug_flags() {
     static const int v = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
@@ -1591,9 +1720,11 @@ int force_kernel_kind(int n, int requested) {
         return e[1] == 'a' ? 1 : 2;
     }();
     if (forced) return forced;
-    // measured on MI355X (us per step, QT12; wg = layout 3 | wave): n=1024 17 | 15 (r01), 2048 24.8 | 25.9, 3072 33.5 | 43.9,
-    // 4096 41.6 | 54, 8192 148 | 146, 16384 565 | 569 (gpurun_out r02e)
-    return (n >= 2048 && n < 8192) ? 2 : 1;
+    // measured on MI355X (us per step, QT12; wg = layout 5 | wave): n=512 10.2 | 9.0, 768 12.1 | 11.8, 1024 14.1 | 14.2,
+    // 1280 15.9 | 19.1, 2048 21.6 | 25.1, 4096 36.9 | 54, 8192 134 | 143, 12288 292 | 412, 16384 511 | 552, 32768 1995 | 2174,
+    // 65536 7864 | 8823 (gpurun_out r02s, r02t). (With round 2's first workgroup layout the wave form still won outside
+    // 2048 <= n < 8192.)
+    return n >= 1024 ? 2 : 1;
 }
 
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind,
@@ -1605,13 +1736,18 @@ int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double 
     if (force_kernel_kind(nt, kind) == 2) {
         const int dbg = wg_debug_flags();
         const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
-        if (wg_layout() == 4)
+        const int lay = wg_layout();
+        if (lay == 6)
+            hipLaunchKernelGGL(k_accel_wg<6>, grid, dim3(wg_threads(6)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
+        else if (lay == 5)
+            hipLaunchKernelGGL(k_accel_wg<5>, grid, dim3(wg_threads(5)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
+        else if (lay == 4)
             hipLaunchKernelGGL(k_accel_wg<4>, grid, dim3(wg_threads(4)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
-        else if (wg_layout() == 3)
+        else if (lay == 3)
             hipLaunchKernelGGL(k_accel_wg<3>, grid, dim3(wg_threads(3)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
-        else if (wg_layout() == 2)
+        else if (lay == 2)
             hipLaunchKernelGGL(k_accel_wg<2>, grid, dim3(wg_threads(2)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
-        else if (wg_layout() == 1)
+        else if (lay == 1)
             hipLaunchKernelGGL(k_accel_wg<1>, grid, dim3(wg_threads(1)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         else
             hipLaunchKernelGGL(k_accel_wg<0>, grid, dim3(wg_threads(0)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
@@ -1648,7 +1784,11 @@ int launch_lm_step(hipStream_t s, const LmArgs &a) {
         LmArgs b = a;
         b.wg_flags = wg_debug_flags() & 12;            // priority knob + launch-level accounting (the per-tile one is k_accel_wg's)
         const int lay = wg_layout();
-        if (a.L == 12 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<12, 4>), grid, dim3(wg_threads(4)), 0, s, b);
+        if (a.L == 12 && lay == 6) hipLaunchKernelGGL((k_lm_step_wg<12, 6>), grid, dim3(wg_threads(6)), 0, s, b);
+        else if (a.L == 13 && lay == 6) hipLaunchKernelGGL((k_lm_step_wg<13, 6>), grid, dim3(wg_threads(6)), 0, s, b);
+        else if (a.L == 12 && lay == 5) hipLaunchKernelGGL((k_lm_step_wg<12, 5>), grid, dim3(wg_threads(5)), 0, s, b);
+        else if (a.L == 13 && lay == 5) hipLaunchKernelGGL((k_lm_step_wg<13, 5>), grid, dim3(wg_threads(5)), 0, s, b);
+        else if (a.L == 12 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<12, 4>), grid, dim3(wg_threads(4)), 0, s, b);
         else if (a.L == 13 && lay == 4) hipLaunchKernelGGL((k_lm_step_wg<13, 4>), grid, dim3(wg_threads(4)), 0, s, b);
         else if (a.L == 12 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<12, 3>), grid, dim3(wg_threads(3)), 0, s, b);
         else if (a.L == 13 && lay == 3) hipLaunchKernelGGL((k_lm_step_wg<13, 3>), grid, dim3(wg_threads(3)), 0, s, b);
@@ -1777,6 +1917,14 @@ int launch_debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast
     if (n <= 0) return EPH_OK;
     hipLaunchKernelGGL(k_debug_inv_r3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (long long)n, n2, fast, ieee);
     return done("k_debug_inv_r3");
+}
+int launch_debug_inv_r3_sweep(hipStream_t s, uint64_t seed, int64_t n, unsigned long long *out2) {
+    const int per = 4096;
+    const int64_t threads = (n + per - 1) / per;
+    if (threads <= 0) return EPH_OK;
+    hipLaunchKernelGGL(k_debug_inv_r3_sweep, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                       (unsigned long long)seed, per, out2);
+    return done("k_debug_inv_r3_sweep");
 }
 int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step) {
     if (n <= 0 || !sa.period) return EPH_OK;

@@ -383,6 +383,10 @@ int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast,
 /* Test hook: 1/(x*sqrt(x)) for n inputs computed by the kernel's in-range fast sequences (NaN where the range
  * guard would send the tile to the IEEE form) and by the compiler's IEEE sqrt/divide expansions. */
 int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee);
+/* Test hook: the same comparison over n operands generated on the device (splitmix64(seed + index): random mantissa,
+ * exponent uniform over the guarded range; n is rounded up to a multiple of 2^20). *mismatches = operands whose two
+ * results differ in any bit; *example_bits = the IEEE bits of one of them (0 when none). */
+int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, uint64_t *example_bits);
 /* Tuning hook (EPH_DEBUG_WG=3): s_memtime accounting of one workgroup of the force kernel: {pair wave work,
  * barrier wait, pair wave 0 work, wait, chain wave work, wait, tiles, 0}. */
 int32_t eph_debug_wg_cycles(int64_t *out8);
