@@ -553,6 +553,18 @@ __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
 #ifndef EPH_PAIR_LOOP
 #define EPH_PAIR_LOOP 0
 #endif
+// tuning builds of the barrier-per-128-sources layouts (scripts/build_exp.sh): 1 = the chain wave skips its sums (pair
+// side alone), 2 = the pair waves skip their tiles (chain side alone); results are then meaningless. Compile-time on
+// purpose: the same two tests as RUN-time flags cost the default path 3.6 us per step (36.9 -> 40.5, gpurun_out r02v).
+#ifndef EPH_WG_SIDE
+#define EPH_WG_SIDE 0
+#endif
+// ablations for the same tuning builds (results meaningless): 1 = pair waves keep their contributions in registers (no
+// ds_write), 2 = no barrier inside the tile loops, 4 = pair waves reuse their first source tiles (no loads in the loop)
+#ifndef EPH_WG_ABLATE
+#define EPH_WG_ABLATE 0
+#endif
+#define WG_LOOP_BARRIER() do { if constexpr (!(EPH_WG_ABLATE & 2)) __syncthreads(); } while (0)
 constexpr int kWgBodies = 16;
 constexpr int kWgPairWaves = 4;                      // index of the chain wave (wave 4: lands on the SIMD of wave 0)
 // Role layouts (waves of a workgroup go to the four SIMDs round-robin: wave k -> SIMD k % 4):
@@ -612,7 +624,10 @@ __device__ __forceinline__ void wg_pair_tile(const double (&xi)[NB], const doubl
         for (int b = 0; b < NB; ++b) pair_finish<false>(pre[b], pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
     }
 #pragma unroll
-    for (int q = 0; q < 3 * NB; ++q) tile[(3 * b0 + q) * kRow + lane] = c[q];
+    for (int q = 0; q < 3 * NB; ++q) {
+        if constexpr (EPH_WG_ABLATE & 1) asm volatile("" ::"v"(c[q]));
+        else tile[(3 * b0 + q) * kRow + lane] = c[q];
+    }
 }
 
 // Barrier schedule (every wave executes tiles+1 barriers): B_0 after tiles 0 and 1 are in LDS; iteration t: pair
@@ -687,8 +702,12 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
     }
 #pragma unroll
     for (int q = 0; q < 3 * NB; ++q) {
-        tile_a[(3 * b0 + q) * kRow + lane] = c[q];
-        tile_b[(3 * b0 + q) * kRow + lane] = c[3 * NB + q];
+        if constexpr (EPH_WG_ABLATE & 1) {
+            asm volatile("" ::"v"(c[q]), "v"(c[3 * NB + q]));
+        } else {
+            tile_a[(3 * b0 + q) * kRow + lane] = c[q];
+            tile_b[(3 * b0 + q) * kRow + lane] = c[3 * NB + q];
+        }
     }
 }
 // Layout 3 barrier schedule. The 64-source tiles are grouped into "big" tiles, one barrier each: big tiles 0 and 1 are
@@ -700,7 +719,8 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
 __device__ __forceinline__ int big_start(int K) { return K < 2 ? K : 2 * K - 2; }
 __device__ __forceinline__ int big_count(int tiles) { return tiles <= 2 ? tiles : 2 + (tiles - 2 + 1) / 2; }
 template <int NB, typename PosPtr>
-__device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag) {
+__device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag,
+                                                 int dbg = 0) {
     double xi[NB], yi[NB], zi[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -728,7 +748,7 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
     };
     auto produce = [&](int K, const Body4 &pa, const Body4 &pb) {          // big tile K
         const int t = big_start(K);
-        if (t >= tiles) return;
+        if (t >= tiles || EPH_WG_SIDE == 2) return;    // -DEPH_WG_SIDE=2 (tuning): pair waves idle, the chain side alone
         double *ta = C + (t % 6) * kWgBuf, *tb = C + ((t + 1) % 6) * kWgBuf;
         if (K >= 2 && t + 1 < tiles) wg_pair_tile2<NB>(xi, yi, zi, pa, pb, tdiag == t || tdiag == t + 1, ta, tb, b0, lane);
         else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
@@ -751,9 +771,10 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
     } else {
         for (int K = 0; K < TB; ++K) {
             pa = na; pb = nb;
-            na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
+            if constexpr (!(EPH_WG_ABLATE & 4)) { na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1); }
+            else asm volatile("" : "+v"(na.x), "+v"(nb.x));   // opaque: nothing may be hoisted out of the loop
             produce(K + 2, pa, pb);
-            __syncthreads();
+            WG_LOOP_BARRIER();
         }
     }
 }
@@ -796,54 +817,54 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // under the denser f64 stream and the step gets slower.)
     if constexpr (LAYOUT == 5) {
         switch (wave) {
-            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
-            case 8: for (int T = 0; T <= big_count(tiles); ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
-            case 1: wg_pair_wave_big<2>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
-            case 5: wg_pair_wave_big<2>(pos, n, i0, 3, C, lane, tiles, tdiag); return 0.0;
-            case 9: wg_pair_wave_big<1>(pos, n, i0, 5, C, lane, tiles, tdiag); return 0.0;
-            case 2: wg_pair_wave_big<2>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
-            case 6: wg_pair_wave_big<2>(pos, n, i0, 8, C, lane, tiles, tdiag); return 0.0;
-            case 10: wg_pair_wave_big<1>(pos, n, i0, 10, C, lane, tiles, tdiag); return 0.0;
-            case 3: wg_pair_wave_big<2>(pos, n, i0, 11, C, lane, tiles, tdiag); return 0.0;
-            case 7: wg_pair_wave_big<2>(pos, n, i0, 13, C, lane, tiles, tdiag); return 0.0;
-            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag); return 0.0;
+            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 8: __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER(); return 0.0;   // TB + 1 barriers
+            case 1: wg_pair_wave_big<2>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 5: wg_pair_wave_big<2>(pos, n, i0, 3, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 9: wg_pair_wave_big<1>(pos, n, i0, 5, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave_big<2>(pos, n, i0, 6, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 8, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 10: wg_pair_wave_big<1>(pos, n, i0, 10, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave_big<2>(pos, n, i0, 11, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 7: wg_pair_wave_big<2>(pos, n, i0, 13, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag, dbg); return 0.0;
             default: break;
         }
     } else if constexpr (LAYOUT == 6) {
         switch (wave) {
-            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
-            case 8: wg_pair_wave_big<1>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
-            case 1: wg_pair_wave_big<2>(pos, n, i0, 2, C, lane, tiles, tdiag); return 0.0;
-            case 5: wg_pair_wave_big<2>(pos, n, i0, 4, C, lane, tiles, tdiag); return 0.0;
-            case 9: wg_pair_wave_big<1>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
-            case 2: wg_pair_wave_big<2>(pos, n, i0, 7, C, lane, tiles, tdiag); return 0.0;
-            case 6: wg_pair_wave_big<2>(pos, n, i0, 9, C, lane, tiles, tdiag); return 0.0;
-            case 10: wg_pair_wave_big<1>(pos, n, i0, 11, C, lane, tiles, tdiag); return 0.0;
-            case 3: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag); return 0.0;
-            case 7: wg_pair_wave_big<1>(pos, n, i0, 14, C, lane, tiles, tdiag); return 0.0;
-            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag); return 0.0;
+            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 8: wg_pair_wave_big<1>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 1: wg_pair_wave_big<2>(pos, n, i0, 2, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 5: wg_pair_wave_big<2>(pos, n, i0, 4, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 9: wg_pair_wave_big<1>(pos, n, i0, 6, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave_big<2>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 9, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 10: wg_pair_wave_big<1>(pos, n, i0, 11, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 7: wg_pair_wave_big<1>(pos, n, i0, 14, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag, dbg); return 0.0;
             default: break;
         }
     } else if constexpr (LAYOUT == 4) {
         switch (wave) {
-            case 0: for (int T = 0; T <= big_count(tiles); ++T) __syncthreads(); return 0.0;   // TB + 1 barriers
-            case 1: wg_pair_wave_big<3>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
-            case 2: wg_pair_wave_big<3>(pos, n, i0, 3, C, lane, tiles, tdiag); return 0.0;
-            case 3: wg_pair_wave_big<3>(pos, n, i0, 6, C, lane, tiles, tdiag); return 0.0;
-            case 5: wg_pair_wave_big<3>(pos, n, i0, 9, C, lane, tiles, tdiag); return 0.0;
-            case 6: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag); return 0.0;
-            case 7: wg_pair_wave_big<2>(pos, n, i0, 14, C, lane, tiles, tdiag); return 0.0;
+            case 0: __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER(); return 0.0;   // TB + 1 barriers
+            case 1: wg_pair_wave_big<3>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave_big<3>(pos, n, i0, 3, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave_big<3>(pos, n, i0, 6, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 5: wg_pair_wave_big<3>(pos, n, i0, 9, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 7: wg_pair_wave_big<2>(pos, n, i0, 14, C, lane, tiles, tdiag, dbg); return 0.0;
             default: break;
         }
     } else if constexpr (LAYOUT == 3) {
         switch (wave) {
-            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag); return 0.0;
-            case 1: wg_pair_wave_big<3>(pos, n, i0, 1, C, lane, tiles, tdiag); return 0.0;
-            case 2: wg_pair_wave_big<3>(pos, n, i0, 4, C, lane, tiles, tdiag); return 0.0;
-            case 3: wg_pair_wave_big<3>(pos, n, i0, 7, C, lane, tiles, tdiag); return 0.0;
-            case 5: wg_pair_wave_big<2>(pos, n, i0, 10, C, lane, tiles, tdiag); return 0.0;
-            case 6: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag); return 0.0;
-            case 7: wg_pair_wave_big<2>(pos, n, i0, 14, C, lane, tiles, tdiag); return 0.0;
+            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 1: wg_pair_wave_big<3>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 2: wg_pair_wave_big<3>(pos, n, i0, 4, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 3: wg_pair_wave_big<3>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 5: wg_pair_wave_big<2>(pos, n, i0, 10, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 6: wg_pair_wave_big<2>(pos, n, i0, 12, C, lane, tiles, tdiag, dbg); return 0.0;
+            case 7: wg_pair_wave_big<2>(pos, n, i0, 14, C, lane, tiles, tdiag, dbg); return 0.0;
             default: break;
         }
     } else if constexpr (LAYOUT == 2) {
@@ -903,7 +924,8 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
                 const double *r = row + (t % 6) * kWgBuf;
                 const double *rn = row + ((t + 1) % 6) * kWgBuf;   // complete since the previous barrier
                 const int cnt = min(kTile, n - t * kTile);
-                if (t != tdiag && cnt == kTile) {
+                if constexpr (EPH_WG_SIDE == 1) {      // tuning: chain wave idle, the pair side alone
+                } else if (t != tdiag && cnt == kTile) {
                     if constexpr (EPH_CHAIN_ASM) acc = chain_full_asm(r, acc);   // experimental build: pinned order
                     else acc = chain_full_pf(r, rn, q, acc);
                 } else {
@@ -914,7 +936,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
                     }
                 }
             }
-            __syncthreads();                          // big tile T consumed, big tile T + 2 ready
+            WG_LOOP_BARRIER();                          // big tile T consumed, big tile T + 2 ready
         }
         if ((dbg & 4) && blockIdx.x == 7 && lane == 0) { g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
         return accL + acc;
@@ -1011,7 +1033,7 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
             double yv[L], av[L];
             load_history(yv, av);
             const int tiles = (a.n + kTile - 1) / kTile;
-            for (int T = 0; T <= big_count(tiles); ++T) __syncthreads();   // the idle wave's role: TB + 1 barriers
+            __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER();   // the idle wave's role: TB + 1 barriers
             __syncthreads();                              // the chain wave's result is in LDS
             if (owner) finish(yv, av, C[lane]);
         } else {
