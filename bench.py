@@ -381,7 +381,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("k_fast_partial + k_fast_finish<12>" if fast else
-                                    "k_lm_step_wg<12,LAYOUT>" if 2048 < nt < 8192 else "k_lm_step<BPW,12>"),
+                                    "k_lm_step_wg<12,LAYOUT>" if nt >= 1024 else "k_lm_step<BPW,12>"),
                          "launch_us": launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * nt,
                          "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see fp64"

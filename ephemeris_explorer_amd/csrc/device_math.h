@@ -66,7 +66,8 @@ constexpr int kPairVariant = EPH_PAIR_VARIANT;
 // tighter than the hardware seed (~2^-26), which makes the first of rcp_inrange's two Newton steps redundant. One
 // Newton step leaves r within half an ulp (+2^-80) of 1 / p, the same faithful value the compiler's sequence reaches,
 // and the closing residual step rounds it correctly: bit-identical to 1.0 / (x * sqrt(x)) (same tests as rcp_inrange,
-// plus scripts/sweep_inv_r3.py over 2^32 operands). Saves a transcendental and one fma per interaction.
+// plus eph_debug_inv_r3_sweep: 2.7e11 device-generated operands without a mismatch, 2^33 of them in
+// tests/test_gpu_parity.py). Saves a transcendental and one fma per interaction.
 #ifndef EPH_RCP_SEED_FROM_RSQ
 #define EPH_RCP_SEED_FROM_RSQ 1
 #endif
