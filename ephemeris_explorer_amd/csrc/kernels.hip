@@ -688,6 +688,8 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
     }
     double c[6 * NB];
     if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
+        // (the same arithmetic written stage by stage across the 2 NB interactions, so that adjacent instructions are
+        // independent, was measured: 37.38 vs 37.04 us -- the three waves of a SIMD already fill each other's gaps)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             pair_finish<true>(pre[b], pa.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
