@@ -556,6 +556,9 @@ __global__ void __launch_bounds__(64) k_lm_step(const LmArgs a) {
 // tuning builds of the barrier-per-128-sources layouts (scripts/build_exp.sh): 1 = the chain wave skips its sums (pair
 // side alone), 2 = the pair waves skip their tiles (chain side alone); results are then meaningless. Compile-time on
 // purpose: the same two tests as RUN-time flags cost the default path 3.6 us per step (36.9 -> 40.5, gpurun_out r02v).
+#ifndef EPH_WG_ACCOUNT
+#define EPH_WG_ACCOUNT 0
+#endif
 #ifndef EPH_WG_SIDE
 #define EPH_WG_SIDE 0
 #endif
@@ -773,12 +776,20 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
             __syncthreads();
         }
     } else {
+        long long t_work = 0, t_bar = 0;               // -DEPH_WG_ACCOUNT=1 (tuning): s_memtime ticks producing / at the barrier
         for (int K = 0; K < TB; ++K) {
+            const long long c0 = EPH_WG_ACCOUNT ? __builtin_readcyclecounter() : 0;
             pa = na; pb = nb;
             if constexpr (!(EPH_WG_ABLATE & 4)) { na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1); }
             else asm volatile("" : "+v"(na.x), "+v"(nb.x));   // opaque: nothing may be hoisted out of the loop
             produce(K + 2, pa, pb);
+            const long long c1 = EPH_WG_ACCOUNT ? __builtin_readcyclecounter() : 0;
             WG_LOOP_BARRIER();
+            if constexpr (EPH_WG_ACCOUNT) { t_work += c1 - c0; t_bar += __builtin_readcyclecounter() - c1; }
+        }
+        if constexpr (EPH_WG_ACCOUNT) {                // layout 5: b0 = 1 is a two-body wave of SIMD 1, b0 = 5 its one-body wave
+            if (blockIdx.x == 7 && lane == 0 && b0 == 1) { g_wg_cycles[0] = t_work; g_wg_cycles[1] = t_bar; }
+            if (blockIdx.x == 7 && lane == 0 && b0 == 5) { g_wg_cycles[2] = t_work; g_wg_cycles[3] = t_bar; }
         }
     }
 }
@@ -921,6 +932,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
         const int TB = big_count(tiles);
         if ((dbg & 4) && blockIdx.x == 7 && lane == 0) g_wg_cycles[4] = __builtin_readcyclecounter() - c_start;   // wait for B_0
         for (int T = 0; T < TB; ++T) {
+            const long long c0 = EPH_WG_ACCOUNT ? __builtin_readcyclecounter() : 0;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int t = big_start(T) + hf;
@@ -940,7 +952,13 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
                     }
                 }
             }
+            const long long c1 = EPH_WG_ACCOUNT ? __builtin_readcyclecounter() : 0;
             WG_LOOP_BARRIER();                          // big tile T consumed, big tile T + 2 ready
+            if constexpr (EPH_WG_ACCOUNT) { t_work += c1 - c0; t_bar += __builtin_readcyclecounter() - c1; }
+        }
+        if constexpr (EPH_WG_ACCOUNT) {
+            if (blockIdx.x == 7 && lane == 0) { g_wg_cycles[4] = t_work; g_wg_cycles[5] = t_bar; g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
+            return accL + acc;
         }
         if ((dbg & 4) && blockIdx.x == 7 && lane == 0) { g_wg_cycles[6] = tiles; g_wg_cycles[7] = __builtin_readcyclecounter() - c_start; }
         return accL + acc;
