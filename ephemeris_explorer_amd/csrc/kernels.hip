@@ -589,7 +589,8 @@ constexpr int kWgPairWaves = 4;                      // index of the chain wave 
 // that work to a pair wave stalls the whole workgroup at the first barrier: a wave's loads return in order, so its first
 // source tile queues behind 24 history loads -- 40.3-40.7 us. Layout 6 has no idle wave: its chain wave loads the history
 // AFTER the force, the 168-register budget having no room to carry it through the loop.)
-// Measured and dropped: sixteen waves (four per SIMD, <= 128 VGPRs, chain read ring of two chunks) 41.0-42.9 us.
+// Measured and dropped: sixteen waves (four per SIMD, <= 128 VGPRs, chain read ring of two chunks) 41.0-42.9 us; layout 5
+// with the chain wave alone on SIMD 0 (pair waves 2/2/2, 2/2/1, 2/2/1) 41.2 us -- five bodies per pair SIMD is the balance.
 constexpr int wg_threads(int layout) { return layout >= 5 ? 64 * 12 : layout >= 1 ? 64 * 8 : 64 * 5; }
 constexpr int wg_tail_wave(int layout) { return layout == 5 ? 8 : 4; }   // 4 = the chain wave itself
 constexpr bool wg_big(int layout) { return layout >= 3; }
