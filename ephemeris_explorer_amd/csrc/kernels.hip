@@ -1095,7 +1095,6 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
 //   a_i = ((p_0 + p_1) + ... + p_{S-1}),  p_s = ((0 + c(i, j0)) + c(i, j0 + 1)) + ...   (j over slice s, j != i)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFastWaves = 4;                          // waves (= slices) per workgroup
-constexpr int kFastUnrollMax = 8;                      // sources per range check / loop trip: 4 or 8 (EPH_FAST_UNROLL)
 constexpr int kFastMaxSlices = 64;
 
 // 1 / r^3 WITHOUT the IEEE square root and division (EPH_PATH_FAST_RSQ): y = v_rsq_f64(n2) refined by two Newton steps
