@@ -728,7 +728,7 @@ __device__ __forceinline__ int big_start(int K) { return K < 2 ? K : 2 * K - 2; 
 __device__ __forceinline__ int big_count(int tiles) { return tiles <= 2 ? tiles : 2 + (tiles - 2 + 1) / 2; }
 template <int NB, typename PosPtr>
 __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag,
-                                                 int dbg = 0) {
+                                                 int dbg = 0, int wbuf = kWgBuf) {   // wbuf: doubles per LDS tile buffer
     double xi[NB], yi[NB], zi[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -757,7 +757,7 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
     auto produce = [&](int K, const Body4 &pa, const Body4 &pb) {          // big tile K
         const int t = big_start(K);
         if (t >= tiles || EPH_WG_SIDE == 2) return;    // -DEPH_WG_SIDE=2 (tuning): pair waves idle, the chain side alone
-        double *ta = C + (t % 6) * kWgBuf, *tb = C + ((t + 1) % 6) * kWgBuf;
+        double *ta = C + (t % 6) * wbuf, *tb = C + ((t + 1) % 6) * wbuf;
         if (K >= 2 && t + 1 < tiles) wg_pair_tile2<NB>(xi, yi, zi, pa, pb, tdiag == t || tdiag == t + 1, ta, tb, b0, lane);
         else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
     };
@@ -822,16 +822,40 @@ __device__ __forceinline__ double chain_full_asm(const double *row, double acc) 
 }
 
 // Returns on chain-wave lane ch < 48: component ch%3 of body i0 + ch/3. All 320 threads must call it.
-template <int LAYOUT, typename PosPtr>
+template <int LAYOUT, int WB = kWgBodies, typename PosPtr>
 __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg = 0) {
+    static_assert(WB == kWgBodies || LAYOUT == 5, "8- and 4-body workgroups exist in the default layout only");
+    constexpr int kRows = 3 * WB, kBuf = kRows * kRow;   // chains of the chain wave, doubles per LDS tile buffer
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = (n + kTile - 1) / kTile;
     const int tdiag = i0 / kTile;
-    // Waves of a workgroup are placed on the four SIMDs round-robin, so the chain wave (4) shares a SIMD with pair
-    // wave 0, which therefore takes only 2 of the 16 bodies. (Measured alternative: 8 pair waves, two per SIMD --
-    // fewer idle issue slots, 15% fewer cycles per tile, but the chip then clocks down from ~2.15 to ~1.57 GHz
-    // under the denser f64 stream and the step gets slower.)
-    if constexpr (LAYOUT == 5) {
+    // Workgroups of 8 / 4 bodies for target counts that would leave CUs without a 16-body workgroup (<= 2048 / <= 1024
+    // targets): the chain wave's cost per tile does not depend on how many of its lanes carry a chain, so with one
+    // workgroup per CU the step takes the chain wave's time; one body per pair wave, SIMD 0 left to the chain wave.
+    if constexpr (WB == 8) {
+        switch (wave) {
+            case 1: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 2: wg_pair_wave_big<1>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 3: wg_pair_wave_big<1>(pos, n, i0, 2, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 5: wg_pair_wave_big<1>(pos, n, i0, 3, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 6: wg_pair_wave_big<1>(pos, n, i0, 4, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 7: wg_pair_wave_big<1>(pos, n, i0, 5, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 9: wg_pair_wave_big<1>(pos, n, i0, 6, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 10: wg_pair_wave_big<1>(pos, n, i0, 7, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 0: case 8: case 11: __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER(); return 0.0;
+            default: break;
+        }
+    } else if constexpr (WB == 4) {
+        switch (wave) {
+            case 1: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 2: wg_pair_wave_big<1>(pos, n, i0, 1, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 3: wg_pair_wave_big<1>(pos, n, i0, 2, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 5: wg_pair_wave_big<1>(pos, n, i0, 3, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
+            case 4: break;
+            default: __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER(); return 0.0;
+        }
+    } else if constexpr (LAYOUT == 5) {
+        // (waves of a workgroup are placed on the four SIMDs round-robin: wave k on SIMD k % 4)
         switch (wave) {
             case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg); return 0.0;
             case 8: __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER(); return 0.0;   // TB + 1 barriers
@@ -916,9 +940,9 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     }
     if (dbg & 8) __builtin_amdgcn_s_setprio(3);        // tuning: chain wave ahead of the pair wave(s) on its SIMD
     // chain wave (raising its priority with s_setprio was measured in layout 0: 4-5 us slower per evaluation)
-    const int ch = lane < kWgRows ? lane : kWgRows - 1;
+    const int ch = lane < kRows ? lane : kRows - 1;
     const double *row = C + ch * kRow;
-    const int gself = (i0 % kTile) / kWgBodies;
+    const int gself = (i0 % kTile) / WB;
     const int li = (i0 % kTile) + ch / 3;
     double acc = init, accL = 0.0;
     double2 q[4][8];
@@ -938,15 +962,15 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
             for (int hf = 0; hf < 2; ++hf) {
                 const int t = big_start(T) + hf;
                 if (t >= tiles || (T < 2 && hf)) break;
-                const double *r = row + (t % 6) * kWgBuf;
-                const double *rn = row + ((t + 1) % 6) * kWgBuf;   // complete since the previous barrier
+                const double *r = row + (t % 6) * kBuf;
+                const double *rn = row + ((t + 1) % 6) * kBuf;   // complete since the previous barrier
                 const int cnt = min(kTile, n - t * kTile);
                 if constexpr (EPH_WG_SIDE == 1) {      // tuning: chain wave idle, the pair side alone
                 } else if (t != tdiag && cnt == kTile) {
                     if constexpr (EPH_CHAIN_ASM) acc = chain_full_asm(r, acc);   // experimental build: pinned order
                     else acc = chain_full_pf(r, rn, q, acc);
                 } else {
-                    chain_masked<kWgBodies>(r, cnt, t == tdiag ? gself : -1, li, acc, accL);
+                    chain_masked<WB>(r, cnt, t == tdiag ? gself : -1, li, acc, accL);
                     if constexpr (!EPH_CHAIN_ASM) {
                         load_chunk(rn, 0, q[0]);
                         load_chunk(rn, 1, q[1]);
@@ -988,18 +1012,18 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     }
 }
 
-template <int LAYOUT>
+template <int LAYOUT, int WB = kWgBodies>
 __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
                                                          const double *__restrict__ acc_init,
                                                          double *__restrict__ acc_out, int dbg, int lo, int hi,
                                                          KickDrift kd) {
-    __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgBuf];
+    __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * 3 * WB * kRow];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i0 = lo + blockIdx.x * kWgBodies;
+    const int i0 = lo + blockIdx.x * WB;
     const int my_i = i0 + lane / 3, cc = lane % 3;
-    const bool owner = (tid >> 6) == kWgPairWaves && lane < kWgRows && my_i < hi;
+    const bool owner = (tid >> 6) == kWgPairWaves && lane < 3 * WB && my_i < hi;
     const double init = (owner && acc_init) ? acc_init[cc * npad + my_i] : 0.0;
-    const double a = wg_force<LAYOUT>(pos, n, i0, init, C, tid, dbg);
+    const double a = wg_force<LAYOUT, WB>(pos, n, i0, init, C, tid, dbg);
     if (owner) {
         acc_out[cc * npad + my_i] = a;
         if (kd.v) kick_drift_one(kd, (size_t)cc * npad + my_i, my_i, cc, a);
@@ -1007,15 +1031,16 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_accel_wg(int n, int npad
 }
 
 // One launch per integrator step, workgroup-specialised force (see k_lm_step for the step structure).
-template <int L, int LAYOUT>
+template <int L, int LAYOUT, int WB = kWgBodies>
 __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs a) {
-    __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgBuf];
+    constexpr int kWgRows = 3 * WB;                    // (shadows the 16-body constant)
+    __shared__ __attribute__((aligned(16))) double C[wg_bufs(LAYOUT) * kWgRows * kRow];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool chain_wave = (tid >> 6) == kWgPairWaves;
     // the wave that does the integrator's work around the force; wave-uniform by construction, and told so (a scalar
     // branch keeps the history registers out of the other roles' live ranges)
     const bool tail_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == wg_tail_wave(LAYOUT);
-    const int i0 = a.lo + blockIdx.x * kWgBodies;
+    const int i0 = a.lo + blockIdx.x * WB;
     const int cb = lane / 3, cc = lane % 3;
     const int my_i = i0 + cb;
     const bool owner = tail_wave && lane < kWgRows && my_i < a.hi;
@@ -1060,7 +1085,7 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
             __syncthreads();                              // the chain wave's result is in LDS
             if (owner) finish(yv, av, C[lane]);
         } else {
-            const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
+            const double anew = wg_force<LAYOUT, WB>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
             if (chain_wave && lane < kWgRows) C[lane] = anew;    // every tile buffer is dead after the loop's last barrier
             __syncthreads();
         }
@@ -1068,7 +1093,7 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
         double yv[L], av[L];
         if (tail_wave && LAYOUT != 6) load_history(yv, av);
         const long long t_entry = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
-        const double anew = wg_force<LAYOUT>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
+        const double anew = wg_force<LAYOUT, WB>(a.pos_cur, a.n, i0, 0.0, C, tid, a.wg_flags);
         const long long t_force = (a.wg_flags & 4) ? __builtin_readcyclecounter() : 0;
         if ((a.wg_flags & 4) && chain_wave && lane == 0) {       // tuning: where a launch spends its time (EPH_DEBUG_WG=4)
             if (blockIdx.x == 7) { g_wg_cycles[0] = t_force - t_entry; }
@@ -1751,6 +1776,14 @@ static int wg_layout() {
     static const int v = [] { const char *e = getenv("EPH_WG_LAYOUT"); return e ? atoi(e) : kWgDefaultLayout; }();
     return v >= 1 && v <= 6 ? v : 0;
 }
+// bodies per workgroup of the default layout: 16, or 8 / 4 when 16-body workgroups would leave CUs idle (one workgroup
+// per CU either way, and the chain wave's time per tile does not depend on how many chains it carries)
+static int wg_bodies(int nt) {
+    static const int forced = [] { const char *e = getenv("EPH_WG_BODIES"); return e ? atoi(e) : 0; }();
+    if (wg_layout() != 5) return kWgBodies;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
+    return nt <= 1024 ? 4 : nt <= 2048 ? 8 : kWgBodies;
+}
 static int wg_debug_flags() {
     static const int v = [] { const char *e = getenv("EPH_DEBUG_WG"); return e ? atoi(e) : 0; }();
     return v;
@@ -1764,11 +1797,11 @@ int force_kernel_kind(int n, int requested) {
         return e[1] == 'a' ? 1 : 2;
     }();
     if (forced) return forced;
-    // measured on MI355X (us per step, QT12; wg = layout 5 | wave): n=512 10.2 | 9.0, 768 12.1 | 11.8, 1024 14.1 | 14.2,
-    // 1280 15.9 | 19.1, 2048 21.6 | 25.1, 4096 36.9 | 54, 8192 134 | 143, 12288 292 | 412, 16384 511 | 552, 32768 1995 | 2174,
-    // 65536 7864 | 8823 (gpurun_out r02s, r02t). (With round 2's first workgroup layout the wave form still won outside
-    // 2048 <= n < 8192.)
-    return n >= 1024 ? 2 : 1;
+    // measured on MI355X (us per step, QT12; wg = layout 5 with 4 / 8 / 16 bodies per workgroup | wave): n=512 9.0 | 9.05,
+    // 640 9.7 | 10.7, 768 10.5 | 11.7, 896 11.2 | 12.9, 1024 11.9 | 14.2, 1536 15.4 | 22.2, 2048 18.3 | 25.1, 4096 36.9 | 54, 8192 134 | 143, 12288 292 | 412,
+    // 16384 511 | 552, 32768 1995 | 2174, 65536 7864 | 8823 (gpurun_out r02s, r02t, r02ab). (With round 2's first
+    // workgroup layout the wave form still won outside 2048 <= n < 8192.)
+    return n > 512 ? 2 : 1;
 }
 
 int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out, int kind,
@@ -1779,9 +1812,14 @@ int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double 
     if (n <= 0 || nt <= 0) return EPH_OK;
     if (force_kernel_kind(nt, kind) == 2) {
         const int dbg = wg_debug_flags();
-        const dim3 grid((nt + kWgBodies - 1) / kWgBodies);
+        const int wb = wg_bodies(nt);
+        const dim3 grid((nt + wb - 1) / wb);
         const int lay = wg_layout();
-        if (lay == 6)
+        if (wb == 8)
+            hipLaunchKernelGGL((k_accel_wg<5, 8>), grid, dim3(wg_threads(5)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
+        else if (wb == 4)
+            hipLaunchKernelGGL((k_accel_wg<5, 4>), grid, dim3(wg_threads(5)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
+        else if (lay == 6)
             hipLaunchKernelGGL(k_accel_wg<6>, grid, dim3(wg_threads(6)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
         else if (lay == 5)
             hipLaunchKernelGGL(k_accel_wg<5>, grid, dim3(wg_threads(5)), 0, s, n, npad, pos, acc_init, acc_out, dbg, lo, hi, kd);
@@ -1824,11 +1862,16 @@ static int launch_lm_step_L(hipStream_t s, const LmArgs &a) {
 int launch_lm_step(hipStream_t s, const LmArgs &a) {
     if (a.n <= 0 || a.hi <= a.lo) return EPH_OK;
     if (force_kernel_kind(a.hi - a.lo, a.kind) == 2) {
-        const dim3 grid((a.hi - a.lo + kWgBodies - 1) / kWgBodies);
+        const int wb = wg_bodies(a.hi - a.lo);
+        const dim3 grid((a.hi - a.lo + wb - 1) / wb);
         LmArgs b = a;
         b.wg_flags = wg_debug_flags() & 12;            // priority knob + launch-level accounting (the per-tile one is k_accel_wg's)
         const int lay = wg_layout();
-        if (a.L == 12 && lay == 6) hipLaunchKernelGGL((k_lm_step_wg<12, 6>), grid, dim3(wg_threads(6)), 0, s, b);
+        if (a.L == 12 && wb == 8) hipLaunchKernelGGL((k_lm_step_wg<12, 5, 8>), grid, dim3(wg_threads(5)), 0, s, b);
+        else if (a.L == 13 && wb == 8) hipLaunchKernelGGL((k_lm_step_wg<13, 5, 8>), grid, dim3(wg_threads(5)), 0, s, b);
+        else if (a.L == 12 && wb == 4) hipLaunchKernelGGL((k_lm_step_wg<12, 5, 4>), grid, dim3(wg_threads(5)), 0, s, b);
+        else if (a.L == 13 && wb == 4) hipLaunchKernelGGL((k_lm_step_wg<13, 5, 4>), grid, dim3(wg_threads(5)), 0, s, b);
+        else if (a.L == 12 && lay == 6) hipLaunchKernelGGL((k_lm_step_wg<12, 6>), grid, dim3(wg_threads(6)), 0, s, b);
         else if (a.L == 13 && lay == 6) hipLaunchKernelGGL((k_lm_step_wg<13, 6>), grid, dim3(wg_threads(6)), 0, s, b);
         else if (a.L == 12 && lay == 5) hipLaunchKernelGGL((k_lm_step_wg<12, 5>), grid, dim3(wg_threads(5)), 0, s, b);
         else if (a.L == 13 && lay == 5) hipLaunchKernelGGL((k_lm_step_wg<13, 5>), grid, dim3(wg_threads(5)), 0, s, b);

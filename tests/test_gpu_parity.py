@@ -310,7 +310,8 @@ def test_degenerate_sizes(gpu):
 
 
 def test_workgroup_kernel_at_every_tile_count(gpu):
-    """The role-specialised workgroup kernel is chosen for n >= 1024 (16+ source tiles); its barrier schedule (single
+    """The role-specialised workgroup kernel is chosen for n > 512 (9+ source tiles; workgroups of 4 bodies up to 1024
+    targets, 8 up to 2048, 16 above -- all three sizes occur below); its barrier schedule (single
     tiles first, then pairs of tiles, six LDS buffers) is exercised here at the tile counts it never sees by default -- 2, 3,
     4, 5, 7, 17 tiles, ragged last tiles -- by forcing it (EPH_FORCE=wg, read once per process: hence the subprocess),
     for every role layout, accelerations and a few fused steps against the oracle."""
@@ -327,10 +328,10 @@ from ephemeris_explorer_amd.workloads import plummer
 from oracle import orc
 same = lambda a, b: np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
 rng = np.random.default_rng(5)
-for n in (65, 128, 129, 200, 256, 300, 448, 1030):
+for n in (65, 128, 129, 200, 256, 300, 448, 1030, 2100):
     pos, mu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
     assert same(ea.accel_eval(pos, mu), orc.gravity(pos, mu)), ("accel", n)
-for n in (130, 300, 1030):
+for n in (130, 300, 1030, 2100):
     pos, vel, mu = plummer(n)
     g = ea.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
     o = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0, native=True)
@@ -339,10 +340,13 @@ for n in (130, 300, 1030):
     assert same(g.state()[0], o.state()[0]) and same(g.state()[1], o.state()[1]), ("steps", n)
 print("ok")
 '''
-    for layout in ("0", "1", "2", "3", "4", "5", "6"):
+    cases = [(layout, None) for layout in "0123456"] + [("5", "4"), ("5", "8"), ("5", "16")]   # the last three: one size at EVERY n
+    for layout, bodies in cases:
         env = dict(os.environ, EPH_FORCE="wg", EPH_WG_LAYOUT=layout)
+        if bodies:
+            env["EPH_WG_BODIES"] = bodies
         r = subprocess.run([sys.executable, "-c", script, str(ROOT)], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (layout, r.stdout[-1000:], r.stderr[-3000:])
+        assert r.returncode == 0 and "ok" in r.stdout, (layout, bodies, r.stdout[-1000:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("name", ["sun_earth_moon_2433282.5", "full_solar_system_2433282.5"])
