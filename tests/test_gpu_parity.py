@@ -349,6 +349,15 @@ print("ok")
         assert r.returncode == 0 and "ok" in r.stdout, (layout, bodies, r.stdout[-1000:], r.stderr[-3000:])
 
 
+def test_kernel_choice_boundaries(gpu):
+    """Accelerations at the sizes where the kernel choice changes: wave form up to 512 targets, then workgroups of 4 bodies
+    (up to 1024), 8 (up to 2048) and 16 -- one body either side of each boundary, plus ragged sizes in between."""
+    rng = np.random.default_rng(3)
+    for n in (511, 512, 513, 520, 576, 700, 1023, 1024, 1025, 1500, 2047, 2048, 2049):
+        pos, mu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
+        assert_same_bits(gpu.accel_eval(pos, mu), orc.gravity(pos, mu), f"accelerations, n = {n}")
+
+
 @pytest.mark.parametrize("name", ["sun_earth_moon_2433282.5", "full_solar_system_2433282.5"])
 @pytest.mark.parametrize("direction", [1, -1])
 def test_single_steps_are_deferred_but_indistinguishable(gpu, name, direction):
