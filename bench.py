@@ -240,6 +240,44 @@ def craft_cpu_baseline(s, ship, pos, vel, t_end, craft_days, sample=1000):
             "seconds": dt, "craft": n}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher environment: become the launcher -- one rank per GPU through
+    torch.distributed.run on 127.0.0.1 with a free port -- and pass rank 0's single JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if r.returncode or not lines:
+        sys.stderr.write(r.stdout[-4000:])
+        raise SystemExit(r.returncode or 1)
+
+
+def timed_blocks(run_block, barrier, agree, blocks=0, min_region_s=0.05, max_blocks=64):
+    """The K-step block, timed R times, each block bracketed by barrier + device sync on both sides. R = `blocks`, or
+    (0) chosen after the first block so that the timed region is at least `min_region_s` (a 20-step block of a 40 us
+    kernel is 0.8 ms: one scheduling hiccup moves it by percents), at least 3. `agree(t)` returns the max of t over the
+    ranks so that every rank times the same number of blocks. Returns the sorted block times [s]."""
+    times, want = [], blocks
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        run_block()
+        barrier()
+        times.append(time.perf_counter() - t0)
+        if want <= 0:
+            want = min(max_blocks, max(3, int(min_region_s / max(agree(times[0]), 1e-9)) + 1))
+        if len(times) >= want:
+            return sorted(times)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,7 +291,12 @@ def main():
                          "configs[3], sharded over the ranks (steps = sweeps of `--craft-days` days over `--craft` "
                          "spacecraft) | nbody-sharded: ONE system of --bodies (default 65536, configs[4] in f64) "
                          "partitioned by target body over the ranks, one RCCL all-gather per step (strong scaling)")
-    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl", help="nbody-sharded exchange")
+    ap.add_argument("--transport", choices=["rccl", "host", "peer"], default="rccl",
+                    help="nbody-sharded exchange: rccl (ncclAllGather) | peer (direct writes into IPC-mapped peer "
+                         "mailboxes, csrc/peer.hip) | host (staged through host memory; tests)")
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="how many times the K-step block is timed (0 = as many as make the timed region >= 50 ms, at "
+                         "least 3); ms_per_step is the MEDIAN block")
     ap.add_argument("--path", choices=["exact", "fast", "fast-rsq"], default="exact",
                     help="exact (default): the reference's summation order, bit-identical to the CPU path | fast: the "
                          "opt-in slice-parallel sums (EPH_PATH_FAST) -- a second, separately labelled line "
@@ -278,7 +321,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+            return self_launch(args.gpus)
         args.gpus = world
 
     import numpy as np
@@ -337,15 +380,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    g.advance(args.steps)               # EXACTLY K steps
-    g.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def block():
+        g.advance(args.steps)           # EXACTLY K steps
+        g.sync()
+
     from ephemeris_explorer_amd.parallel import reduce_timing
+    blocks = timed_blocks(block, barrier, lambda t: reduce_timing(t, 0, dist, device="cuda")[1], blocks=args.blocks)
+    elapsed = blocks[len(blocks) // 2]                   # the median block: K steps
     units_local = n * args.steps / world if sharded else n * args.steps
     units, elapsed = reduce_timing(elapsed, units_local, dist, device="cuda")       # sum of units, MAX of time
+    _, t_min = reduce_timing(blocks[0], 0, dist, device="cuda")
+    _, t_max = reduce_timing(blocks[-1], 0, dist, device="cuda")
     ms_kernel, launches = g.kernel_time()
 
     if rank == 0:
@@ -366,6 +411,9 @@ def main():
             "metric": "body-steps/s", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "blocks": len(blocks), "ms_per_step_min": t_min / args.steps * 1e3, "ms_per_step_max": t_max / args.steps * 1e3,
+            "timing": f"the {args.steps}-step block timed {len(blocks)} times (barrier + device sync around each); "
+                      "value and ms_per_step are the median block",
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": ({"workload": f"plummer_{n}_f64_qt12, one system partitioned by target body "

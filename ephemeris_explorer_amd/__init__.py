@@ -20,7 +20,7 @@ from . import systems  # noqa: F401  (state.json / ephemeris.json / ships reader
 _HERE = Path(__file__).resolve().parent
 import os as _os
 
-# EPH_AMD_PAIR_VARIANT=k (1..3) loads libephemeris_amd_pv<k>.so: the same library built with another evaluation order
+# EPH_AMD_PAIR_VARIANT=k (1..6) loads libephemeris_amd_pv<k>.so: the same library built with another evaluation order
 # of the (unpinned) point-mass term -- csrc/device_math.h. Default: the product library.
 _PV = int(_os.environ.get("EPH_AMD_PAIR_VARIANT", "0") or 0)
 LIB_PATH = _HERE / ("libephemeris_amd.so" if _PV == 0 else f"libephemeris_amd_pv{_PV}.so")

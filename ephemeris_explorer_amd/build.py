@@ -7,6 +7,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libephemeris_amd.so"
+N_PAIR_VARIANTS = 7      # csrc/device_math.h: 0 = the product, 1..6 = other orders of the unpinned point-mass term
 SOURCES = ["kernels.hip", "craft.hip", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
 HEADERS = ["eph_internal.h", "host.h", "device_math.h", "coeff_tables.inc", "cr_pow_tables.inc", "chain_tile.inc", "../../include/ephemeris_amd.h"]
 # -ffp-contract=off is REQUIRED for parity (HIP's default is fast contraction): the reference never fuses a*b+c.
@@ -35,7 +36,7 @@ def needs_build(pair_variant=0):
 
 
 def build(force=False, verbose=False, pair_variant=0):
-    """pair_variant 0 = the product library; 1..3 = the same sources with -DEPH_PAIR_VARIANT=k (another evaluation
+    """pair_variant 0 = the product library; 1..6 = the same sources with -DEPH_PAIR_VARIANT=k (another evaluation
     order of the point-mass term whose reference source is absent, csrc/device_math.h) -> libephemeris_amd_pv<k>.so."""
     LIB = lib_path(pair_variant)
     if not force and not needs_build(pair_variant):
@@ -63,10 +64,10 @@ def build(force=False, verbose=False, pair_variant=0):
 
 
 def build_all(force=False, verbose=False):
-    """The product library and the three pair-variant builds, compiled concurrently."""
+    """The product library and the six pair-variant builds, compiled concurrently."""
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(4) as ex:
-        return list(ex.map(lambda k: build(force, verbose, k), range(4)))
+        return list(ex.map(lambda k: build(force, verbose, k), range(N_PAIR_VARIANTS)))
 
 
 if __name__ == "__main__":

@@ -228,6 +228,14 @@ int32_t eph_nbody_shard(eph_nbody *h, int32_t rank, int32_t world, const void *r
 int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
                        void *ctx) {
     if (!p || !p->p) return EPH_ERR_BAD_ARGUMENT;
+    // Steps taken before sharding left their polynomials on the device (and maybe a queue of deferred steps); the
+    // sharded branch pushes its windows straight into the host splines, so everything older must be there first.
+    {
+        EPH_GUARD_BEGIN
+        const int st = p->p->settle();
+        if (st) return st;
+        EPH_GUARD_END
+    }
     return eph_nbody_shard(&p->view, rank, world, rccl_unique_id, fn, ctx);
 }
 int32_t eph_nbody_shard_info(eph_nbody *h, int32_t *lo, int32_t *hi, uint64_t *gathers) {

@@ -208,10 +208,9 @@ __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &b
     }
     const V3 d = sub(bp, pos);                        // acceleration_at::<false>: dir = body - at
     const double n2 = dot(d, d);
-    double inv;                                       // 1 / (n2 * sqrt(n2)), IEEE sqrt and divide (device_math.h)
-    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = inv_r3_inrange(n2);
-    else inv = inv_r3_ieee(n2);
-    term = scale(d, be.mu * inv);
+    // the point-mass term in the build's evaluation order, IEEE sqrt and divide (device_math.h)
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) pair_apply<true>(pair_den<true>(n2), d.x, d.y, d.z, be.mu, term.x, term.y, term.z);
+    else pair_apply<false>(pair_den<false>(n2), d.x, d.y, d.z, be.mu, term.x, term.y, term.z);
     return true;
 }
 // k_craft_wave: lane b always evaluates body b, so the body's table entry, the refined reciprocal of its spline
@@ -260,10 +259,8 @@ __device__ __forceinline__ bool body_term_cached(const CraftArgs &a, LaneBody &l
     }
     const V3 d = sub(bp, pos);
     const double n2 = dot(d, d);
-    double inv;
-    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = inv_r3_inrange(n2);
-    else inv = inv_r3_ieee(n2);
-    term = scale(d, b.mu * inv);
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) pair_apply<true>(pair_den<true>(n2), d.x, d.y, d.z, b.mu, term.x, term.y, term.z);
+    else pair_apply<false>(pair_den<false>(n2), d.x, d.y, d.z, b.mu, term.x, term.y, term.z);
     return true;
 }
 __global__ void k_debug_div(long long n, const double *__restrict__ a, const double *__restrict__ b,

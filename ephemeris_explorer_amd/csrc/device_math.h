@@ -11,14 +11,24 @@
 
 namespace eph {
 
+// Which evaluation order of the point-mass term this build carries (see the table further down).
+#ifndef EPH_PAIR_VARIANT
+#define EPH_PAIR_VARIANT 0
+#endif
+static_assert(EPH_PAIR_VARIANT >= 0 && EPH_PAIR_VARIANT <= 6, "EPH_PAIR_VARIANT must be 0..6");
+constexpr int kPairVariant = EPH_PAIR_VARIANT;
+// Guarded operand range of the wrapper-free sequences. Variants 0-3 (one reciprocal): n2 in [2^-300, 2^300), biased
+// exponent in [723, 1323). Variants 4-6 (true divisions by p = n2*sqrt(n2) through a shared refined reciprocal,
+// div_refined below) need p in [2^-200, 2^200): n2 in [2^-133, 2^133), biased exponent in [890, 1156).
+constexpr unsigned kRangeBase = kPairVariant >= 4 ? 0x37A00000u : 0x2D300000u;
+constexpr unsigned kRangeSpan = kPairVariant >= 4 ? 0x10A00000u : 0x25800000u;
 __device__ __forceinline__ bool in_range(double n2) {
-    // biased exponent in [723, 1323)  <=>  2^-300 <= n2 < 2^300  (n2 >= 0; NaN/inf/0/denormals are out)
-    return (unsigned)(__double2hiint(n2) - 0x2D300000) < 0x25800000u;
+    // n2 >= 0; NaN/inf/0/denormals are out
+    return (unsigned)(__double2hiint(n2) - kRangeBase) < kRangeSpan;
 }
 // the same test for several operands at once: in range iff max over the operands of range_key() < kRangeSpan
 // (one integer add and one max per operand instead of a compare and boolean plumbing)
-constexpr unsigned kRangeSpan = 0x25800000u;
-__device__ __forceinline__ unsigned range_key(double n2) { return (unsigned)(__double2hiint(n2) - 0x2D300000); }
+__device__ __forceinline__ unsigned range_key(double n2) { return (unsigned)(__double2hiint(n2) - kRangeBase); }
 __device__ __forceinline__ double sqrt_inrange(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
@@ -49,15 +59,16 @@ __device__ __forceinline__ double rcp_inrange(double p) {
 //     1                                         r = sqrt(n2) ; inv = 1 / (r * r * r)
 //     2                                         s = 1 / sqrt(n2) ; inv = s * s * s
 //     3                                         inv = (1 / n2) * (1 / sqrt(n2))
-// with IEEE sqrt / divide in every form (the CPU restatement the tests check against has the same four). `python -m ephemeris_explorer_amd.build --pair-variant k` builds
-// libephemeris_amd_pv<k>.so; tests/test_gpu_variants.py checks each against the oracle in the same variant.
+// each followed by a = d * (mu * inv), and the DIVISION forms with p = n2 * sqrt(n2) and three true divisions
+// (glam's DVec3 / f64 is component-wise):
+//     4   a = (d * mu) / p     Rust `dir * mu / (mag_2 * mag_2.sqrt())`, the published crate's documented scalar form
+//     5   a = d * (mu / p)
+//     6   a = (d / p) * mu     a paired routine sharing `dir / p` between the two masses
+// with IEEE sqrt / divide in every form (the CPU restatement the tests check against has the same seven). `python -m ephemeris_explorer_amd.build --pair-variant k` builds
+// libephemeris_amd_pv<k>.so; tests/test_gpu_variants.py checks each against the oracle in the same variant. Kernels reach
+// the term through pair_den / pair_apply at the end of this file.
 // Only variant 0 has the hand-interleaved tile pipeline of wave_force (kernels.hip pair_stage); the others run
 // the same kernels with the compiler's schedule.
-#ifndef EPH_PAIR_VARIANT
-#define EPH_PAIR_VARIANT 0
-#endif
-static_assert(EPH_PAIR_VARIANT >= 0 && EPH_PAIR_VARIANT <= 3, "EPH_PAIR_VARIANT must be 0..3");
-constexpr int kPairVariant = EPH_PAIR_VARIANT;
 // in_range(n2) keeps every intermediate of every variant inside the exponent range where the stripped sequences
 // equal the compiler's IEEE expansions: n2 in [2^-300, 2^300) => sqrt in [2^-150, 2^150), products and reciprocals
 // within [2^-450, 2^450].
@@ -127,6 +138,70 @@ __device__ __forceinline__ double div_refined(double a, double b, double r) {
 __device__ __forceinline__ double div_shared(double a, double b, double r, bool b_ok) {
     if (b_ok && (a == 0.0 || in_range_div(a))) return div_refined(a, b, r);
     return a / b;
+}
+
+// ---- the point-mass term behind one interface (every kernel family calls these two) ---------------------------
+// pair_den<FAST>(n2): what the two directions of a pair share -- variants 0-3: v = 1/r^3; variants 4-6: v = p =
+// n2*sqrt(n2) and, in the FAST form, r = rcp_refined(p). pair_apply<FAST>(den, d, mu): the acceleration d-wards of a
+// mass mu. FAST = the wrapper-free sequences (caller guarantees in_range(n2) for the whole wave); !FAST = the
+// compiler's IEEE sqrt / divide. Quotients in the FAST form go through div_refined when the numerator is in
+// in_range_div (a signed zero numerator returns itself: x/p = x for p > 0), through the compiler's division otherwise.
+struct PairDen { double v, r; };
+template <bool FAST>
+__device__ __forceinline__ PairDen pair_den(double n2) {
+    PairDen d;
+    if constexpr (kPairVariant <= 3) {
+        d.v = FAST ? inv_r3_inrange(n2) : inv_r3_ieee(n2);
+        d.r = 0.0;
+    } else if constexpr (FAST) {
+        d.v = n2 * sqrt_inrange(n2);
+        d.r = rcp_refined(d.v);
+    } else {
+        d.v = n2 * sqrt(n2);
+        d.r = 0.0;
+    }
+    return d;
+}
+// numerator a of a FAST quotient is usable by div_refined: a signed zero (handled by a select) or in in_range_div
+__device__ __forceinline__ bool quot_ok(double a) { return a == 0.0 || in_range_div(a); }
+// a / p through the shared reciprocal, branch-free: valid when quot_ok(a); a signed zero returns itself (x/p = x, p > 0)
+__device__ __forceinline__ double quot_fast(double a, const PairDen &d) {
+    const double q = div_refined(a, d.v, d.r);
+    return a == 0.0 ? a : q;
+}
+template <bool FAST>
+__device__ __forceinline__ void pair_apply(const PairDen &d, double dx, double dy, double dz, double mu, double &cx,
+                                           double &cy, double &cz) {
+    if constexpr (kPairVariant <= 3) {
+        const double s = mu * d.v;
+        cx = dx * s;
+        cy = dy * s;
+        cz = dz * s;
+    } else if constexpr (!FAST) {
+        if constexpr (kPairVariant == 4) { cx = (dx * mu) / d.v; cy = (dy * mu) / d.v; cz = (dz * mu) / d.v; }
+        else if constexpr (kPairVariant == 5) { const double s = mu / d.v; cx = dx * s; cy = dy * s; cz = dz * s; }
+        else { cx = (dx / d.v) * mu; cy = (dy / d.v) * mu; cz = (dz / d.v) * mu; }
+    } else {
+        // straight-line fast quotients for every lane; lanes whose numerator leaves the guarded range (denormal-scale
+        // products, |a| < 2^-200 or >= 2^200) redo theirs with the compiler's division behind ONE wave-uniform branch
+        // that a tile of ordinary operands never takes
+        if constexpr (kPairVariant == 4) {
+            const double nx = dx * mu, ny = dy * mu, nz = dz * mu;
+            cx = quot_fast(nx, d); cy = quot_fast(ny, d); cz = quot_fast(nz, d);
+            const bool bad = !(quot_ok(nx) && quot_ok(ny) && quot_ok(nz));
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && bad) { cx = nx / d.v; cy = ny / d.v; cz = nz / d.v; }
+        } else if constexpr (kPairVariant == 5) {
+            double s = quot_fast(mu, d);
+            const bool bad = !quot_ok(mu);
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && bad) s = mu / d.v;
+            cx = dx * s; cy = dy * s; cz = dz * s;
+        } else {
+            double qx = quot_fast(dx, d), qy = quot_fast(dy, d), qz = quot_fast(dz, d);
+            const bool bad = !(quot_ok(dx) && quot_ok(dy) && quot_ok(dz));
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && bad) { qx = dx / d.v; qy = dy / d.v; qz = dz / d.v; }
+            cx = qx * mu; cy = qy * mu; cz = qz * mu;
+        }
+    }
 }
 
 }  // namespace eph

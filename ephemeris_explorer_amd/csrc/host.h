@@ -251,6 +251,9 @@ public:
     // somebody needs data (take_solution, clone, state, step_n / step_to) or it reaches kDeferMax steps.
     int step_deferred();
     int flush();
+    // run the queued steps and bring the device-resident polynomials into the host splines: afterwards the host
+    // Solution is complete (eph_prop_shard needs that before the sharded branch starts pushing newer windows)
+    int settle() { const int st = flush(); return st ? st : materialize(); }
     double time() const;                      // DirectionalSolout::solution_time
     bool has_reached(double t) const;
     int take_solution(std::unique_ptr<Solution> *out);
@@ -302,6 +305,9 @@ private:
     DevBuf<double> pend_co_;                  // [pend_cap_][kDiv][3]
     DevBuf<int32_t> pend_nc_;
     size_t pend_count_ = 0, pend_cap_ = 0;
+    // device-side budget of the pending list (196 B per window): beyond it the list is spilled to the host splines
+    // (materialize) instead of growing; a failed device allocation does the same instead of failing the run
+    static constexpr size_t kPendMaxWindows = (size_t)1 << 23;   // 1.6 GB
     std::vector<std::vector<uint32_t>> pend_batches_;   // per batch: windows per body
     int reserve_pending(size_t extra, hipStream_t s);
     int materialize();

@@ -43,13 +43,8 @@ __device__ __forceinline__ PairPre pair_pre(double xi, double yi, double zi, con
 }
 template <bool FAST>
 __device__ __forceinline__ void pair_finish(const PairPre &p, double mu, double &cx, double &cy, double &cz) {
-    double inv;
-    if (FAST) inv = inv_r3_inrange(p.n2);
-    else inv = inv_r3_ieee(p.n2);   // IEEE correctly rounded f64 sqrt and divide
-    const double s = mu * inv;
-    cx = p.dx * s;
-    cy = p.dy * s;
-    cz = p.dz * s;
+    // IEEE correctly rounded f64 sqrt and divide in the build's evaluation order (device_math.h pair_den / pair_apply)
+    pair_apply<FAST>(pair_den<FAST>(p.n2), p.dx, p.dy, p.dz, mu, cx, cy, cz);
 }
 __global__ void k_debug_inv_r3(long long n, const double *__restrict__ n2, double *__restrict__ fast,
                                double *__restrict__ ieee) {
@@ -1138,7 +1133,7 @@ __device__ __forceinline__ double inv_r3_approx(double n2) {
     return y * y * y;
 }
 template <bool DIAG, int kFastUnroll, bool APPROX>
-__device__ __forceinline__ void fast_slice(const __attribute__((address_space(4))) Body4 *src, int j0, int j1, int i,
+__device__ __forceinline__ void fast_slice(const __attribute__((address_space(4))) Body4 *src, int j0, int j1, int n, int i,
                                            double xi, double yi, double zi, double &ax, double &ay, double &az) {
     auto fetch = [&](int j, Body4 (&p)[kFastUnroll]) {
 #pragma unroll
@@ -1146,7 +1141,7 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
     };
     Body4 nxt[kFastUnroll];
     fetch(j0, nxt);
-    for (int j = j0; j < j1; j += kFastUnroll) {       // j1 - j0 is a multiple of kFastUnroll (padded sources: mu = 0)
+    for (int j = j0; j < j1; j += kFastUnroll) {       // j1 - j0 is a multiple of kFastUnroll; sources >= n are padding
         Body4 pj[kFastUnroll];
 #pragma unroll
         for (int u = 0; u < kFastUnroll; ++u) pj[u] = nxt[u];
@@ -1175,6 +1170,9 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
 #pragma unroll
         for (int u = 0; u < kFastUnroll; ++u) {
             if (DIAG && j + u == i) continue;          // the body itself (n2 = 0 -> NaN): not a source
+            // padding rows are zeros at the ORIGIN with mu = 0: a real body sitting exactly there (the central body of a
+            // heliocentric system) would get n2 = 0 -> 0 * inf = NaN from them. Wave-uniform test, last slice only.
+            if (j + u >= n) continue;
             ax = ax + c[3 * u];
             ay = ay + c[3 * u + 1];
             az = az + c[3 * u + 2];
@@ -1201,8 +1199,8 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
     const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (j0 < j1) {
-        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL, APPROX>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
-        else fast_slice<false, UNROLL, APPROX>(src, j0, j1, i, xi, yi, zi, ax, ay, az);
+        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        else fast_slice<false, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
     }
     double *pp = partial + (size_t)slice * 3 * npad + i;
     pp[0] = ax;
@@ -1437,16 +1435,22 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
         const double dx = bj.x - bi.x, dy = bj.y - bi.y, dz = bj.z - bi.z;
         const double n2 = dx * dx + dy * dy + dz * dz;
         // IEEE sqrt and divide; the wrapper-free sequences when every lane's operand is in range (device_math.h)
-        double inv;
-        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) inv = inv_r3_inrange(n2);
-        else inv = inv_r3_ieee(n2);
-        const double si = bj.mu * inv, sj = bi.mu * inv;
-        U[i * 3 + 0][j] = dx * si;
-        U[i * 3 + 1][j] = dy * si;
-        U[i * 3 + 2][j] = dz * si;
-        Lw[j * 3 + 0][i] = -dx * sj;
-        Lw[j * 3 + 1][i] = -dy * sj;
-        Lw[j * 3 + 2][i] = -dz * sj;
+        double ax, ay, az, bx, by, bz;
+        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) {
+            const PairDen den = pair_den<true>(n2);
+            pair_apply<true>(den, dx, dy, dz, bj.mu, ax, ay, az);
+            pair_apply<true>(den, -dx, -dy, -dz, bi.mu, bx, by, bz);
+        } else {
+            const PairDen den = pair_den<false>(n2);
+            pair_apply<false>(den, dx, dy, dz, bj.mu, ax, ay, az);
+            pair_apply<false>(den, -dx, -dy, -dz, bi.mu, bx, by, bz);
+        }
+        U[i * 3 + 0][j] = ax;
+        U[i * 3 + 1][j] = ay;
+        U[i * 3 + 2][j] = az;
+        Lw[j * 3 + 0][i] = bx;
+        Lw[j * 3 + 1][i] = by;
+        Lw[j * 3 + 2][i] = bz;
     };
 
     // ---- predictor (ELM2::advance) of the first step, in the (body, comp) threads

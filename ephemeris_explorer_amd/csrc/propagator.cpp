@@ -138,24 +138,41 @@ int NBodyPropagator::clone(std::unique_ptr<NBodyPropagator> *out) {
     return EPH_OK;
 }
 
-// room for `extra` more windows behind the pending ones (grow-only; contents kept)
+// room for `extra` more windows behind the pending ones (grow-only; contents kept). Past kPendMaxWindows, or when
+// the device cannot hold a larger list, the pending windows go to the host splines first and the list starts over.
 int NBodyPropagator::reserve_pending(size_t extra, hipStream_t s) {
-    const size_t need = pend_count_ + extra;
-    if (need <= pend_cap_) return EPH_OK;
-    const size_t cap = std::max(need + need / 2, (size_t)4096);
-    DevBuf<double> co;
-    DevBuf<int32_t> nc;
-    int st;
-    if ((st = co.alloc(cap * kDiv * 3)) || (st = nc.alloc(cap))) return st;
-    if (pend_count_) {
-        EPH_HIP(hipMemcpyAsync(co.p, pend_co_.p, sizeof(double) * pend_count_ * kDiv * 3, hipMemcpyDeviceToDevice, s));
-        EPH_HIP(hipMemcpyAsync(nc.p, pend_nc_.p, sizeof(int32_t) * pend_count_, hipMemcpyDeviceToDevice, s));
-        EPH_HIP(hipStreamSynchronize(s));
+    if (pend_count_ + extra <= pend_cap_) return EPH_OK;
+    if (pend_count_ && pend_count_ + extra > kPendMaxWindows) {
+        const int st = materialize();
+        if (st) return st;
+        if (extra <= pend_cap_) return EPH_OK;
     }
-    std::swap(pend_co_.p, co.p); std::swap(pend_co_.count, co.count);
-    std::swap(pend_nc_.p, nc.p); std::swap(pend_nc_.count, nc.count);
-    pend_cap_ = cap;
-    return EPH_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const size_t need = pend_count_ + extra;
+        const size_t cap = attempt == 0 ? std::max(need + need / 2, (size_t)4096) : need;
+        DevBuf<double> co;
+        DevBuf<int32_t> nc;
+        int st;
+        if ((st = co.alloc(cap * kDiv * 3)) || (st = nc.alloc(cap))) {
+            if (st != EPH_ERR_OUT_OF_MEMORY || attempt == 1) return st;
+            (void)hipGetLastError();
+            if ((st = materialize())) return st;          // frees nothing by itself, but the copy below disappears
+            pend_co_.release();
+            pend_nc_.release();
+            pend_cap_ = 0;
+            continue;
+        }
+        if (pend_count_) {
+            EPH_HIP(hipMemcpyAsync(co.p, pend_co_.p, sizeof(double) * pend_count_ * kDiv * 3, hipMemcpyDeviceToDevice, s));
+            EPH_HIP(hipMemcpyAsync(nc.p, pend_nc_.p, sizeof(int32_t) * pend_count_, hipMemcpyDeviceToDevice, s));
+            EPH_HIP(hipStreamSynchronize(s));
+        }
+        std::swap(pend_co_.p, co.p); std::swap(pend_co_.count, co.count);
+        std::swap(pend_nc_.p, nc.p); std::swap(pend_nc_.count, nc.count);
+        pend_cap_ = cap;
+        return EPH_OK;
+    }
+    return EPH_ERR_OUT_OF_MEMORY;
 }
 
 // download the device-resident polynomials and perform the pushes the bounds already account for

@@ -151,9 +151,14 @@ uint64_t orc_pair_counter(void) { return g_pair_counter; }
  * (<= 0.7): dir = p_other - p_self ; n2 = dir.length_squared() (+ softening^2 = 0) ;
  * inv = 1 / (n2 * sqrt(n2)) ; (dir * (mu_other*inv), -dir * (mu_self*inv)).
  * glam DVec3::length_squared = x*x + y*y + z*z evaluated left to right (glam 0.30.10). */
-/* Sensitivity switch (tests only): other orders a point-mass routine could plausibly use for 1/r^3. 0 = the pinned
- * restatement; 1 = 1/(r*r*r), r = sqrt(n2); 2 = s*s*s, s = 1/sqrt(n2); 3 = (1/n2) * (1/sqrt(n2)).
- * tests/test_oracle.py::test_pair_formula_variants_stay_within_tolerance bounds what the unpinned choice can cost. */
+/* Sensitivity switch (tests only): other orders a point-mass routine could plausibly use. 0 = the pinned restatement
+ * `dir * (mu * (1 / (n2 * sqrt(n2))))`; 1 = 1/(r*r*r), r = sqrt(n2); 2 = s*s*s, s = 1/sqrt(n2); 3 = (1/n2) * (1/sqrt(n2))
+ * -- all of the shape "one reciprocal, then dir * (mu * inv)". The DIVISION forms, with p = n2 * sqrt(n2) and glam's
+ * component-wise `DVec3 / f64` (three true divisions):
+ *     4 = (dir * mu) / p      -- Rust `dir * mu / (mag_2 * mag_2.sqrt())`, the published crate's documented scalar form
+ *     5 = dir * (mu / p)
+ *     6 = (dir / p) * mu      -- a paired routine that shares `dir / p` between the two masses
+ * tests/test_oracle.py::test_pair_formula_variants_stay_bounded bounds what the unpinned choice can cost. */
 static int g_pair_variant = 0;
 void orc_set_pair_variant(int v) { g_pair_variant = v; }
 static inline double inv_r3(double n2) {
@@ -164,13 +169,23 @@ static inline double inv_r3(double n2) {
         default: return 1.0 / (n2 * sqrt(n2));
     }
 }
+/* the acceleration of a point mass mu seen along dir (n2 = |dir|^2), in the selected operation order */
+static inline v3 point_mass_term(v3 d, double n2, double mu) {
+    v3 a;
+    switch (g_pair_variant) {
+        case 4: { const double p = n2 * sqrt(n2); a.x = (d.x * mu) / p; a.y = (d.y * mu) / p; a.z = (d.z * mu) / p; break; }
+        case 5: { const double s = mu / (n2 * sqrt(n2)); a.x = d.x * s; a.y = d.y * s; a.z = d.z * s; break; }
+        case 6: { const double p = n2 * sqrt(n2); a.x = (d.x / p) * mu; a.y = (d.y / p) * mu; a.z = (d.z / p) * mu; break; }
+        default: { const double s = mu * inv_r3(n2); a.x = d.x * s; a.y = d.y * s; a.z = d.z * s; }
+    }
+    return a;
+}
 static inline void acceleration_paired(v3 pi, double mui, v3 pj, double muj, v3 *ai, v3 *aj) {
-    double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-    double n2 = dx * dx + dy * dy + dz * dz;
-    double inv = inv_r3(n2);
-    double si = muj * inv, sj = mui * inv;
-    ai->x = dx * si; ai->y = dy * si; ai->z = dz * si;
-    aj->x = -dx * sj; aj->y = -dy * sj; aj->z = -dz * sj;
+    const v3 d = {pj.x - pi.x, pj.y - pi.y, pj.z - pi.z};
+    const double n2 = d.x * d.x + d.y * d.y + d.z * d.z;
+    const v3 nd = {-d.x, -d.y, -d.z};
+    *ai = point_mass_term(d, n2, muj);
+    *aj = point_mass_term(nd, n2, mui);            /* -dir * ... : the negation is exact wherever it is applied */
 }
 
 static void gravity_eval(int n, const v3 *y, const double *mu, v3 *ddy) {
@@ -1347,8 +1362,7 @@ static int craft_rhs(void *ctx, double t, const double *y, double *dy) {
         const v3 bp = poly_eval(p, tau);
         const v3 d = v3_sub(bp, pos);
         const double n2 = v3_dot(d, d);
-        const double inv = inv_r3(n2);                 /* acceleration_at::<false>: same crate routine as the pairs */
-        acc = v3_add(acc, v3_scale(d, c->mu[b] * inv));
+        acc = v3_add(acc, point_mass_term(d, n2, c->mu[b])); /* acceleration_at::<false>: same crate routine as the pairs */
     }
     /* manoeuvre_acceleration: Segment::acceleration  spacecraft.rs:102-116,272-281 */
     v3 man = {0.0, 0.0, 0.0};

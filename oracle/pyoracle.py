@@ -51,12 +51,43 @@ class Vec(tuple):
         return Vec(-self[0], -self[1], -self[2])
 
 
+PAIR_VARIANT = 0   # evaluation order of the unpinned point-mass term, same numbering as eph_oracle.c / device_math.h
+
+
+def set_pair_variant(v):
+    global PAIR_VARIANT
+    PAIR_VARIANT = int(v)
+
+
+def point_mass_term(d, n2, mu, sqrt=math.sqrt):
+    """Acceleration of a point mass mu along d (n2 = |d|^2) in the selected operation order (eph_oracle.c
+    point_mass_term): 0-3 one reciprocal then d * (mu * inv); 4 (d * mu) / p; 5 d * (mu / p); 6 (d / p) * mu,
+    p = n2 * sqrt(n2), vector / scalar component-wise as glam's DVec3 / f64."""
+    v = PAIR_VARIANT
+    if v == 4:
+        return (d * mu) / (n2 * sqrt(n2))
+    if v == 5:
+        return d * (mu / (n2 * sqrt(n2)))
+    if v == 6:
+        return (d / (n2 * sqrt(n2))) * mu
+    if v == 1:
+        r = sqrt(n2)
+        inv = 1 / (r * r * r)
+    elif v == 2:
+        s = 1 / sqrt(n2)
+        inv = s * s * s
+    elif v == 3:
+        inv = (1 / n2) * (1 / sqrt(n2))
+    else:
+        inv = 1 / (n2 * sqrt(n2))
+    return d * (mu * inv)
+
+
 def accel_paired(pi, mui, pj, muj, sqrt=math.sqrt):
     """`particular` acceleration_paired with softening 0 -- source absent, PARITY UNPINNED (see eph_oracle.c)."""
     d = pj - pi
     n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
-    inv = 1 / (n2 * sqrt(n2))
-    return d * (muj * inv), (-d) * (mui * inv)
+    return point_mass_term(d, n2, muj, sqrt), point_mass_term(-d, n2, mui, sqrt)
 
 
 def gravity(y, mu, zero, sqrt=math.sqrt):
@@ -686,7 +717,7 @@ class Craft:
                 return None
             d = bp - pos
             n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
-            acc = acc + d * (self.mu[b] * (1.0 / (n2 * math.sqrt(n2))))
+            acc = acc + point_mass_term(d, n2, self.mu[b])
         man = Vec(0.0, 0.0, 0.0)
         _, _, bacc, ref = self.segs[self.cur]
         if bacc is not None:

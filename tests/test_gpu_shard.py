@@ -224,3 +224,29 @@ def test_two_ranks_in_one_process_workgroup_kernel_at_an_offset(gpu):
             assert (lo, hi) == (r * n // 2, (r + 1) * n // 2) and gathers > 0
             assert t == t0 and sc == sc0
             assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(a, a0), (n, r)
+
+
+def test_propagator_sharded_after_steps_keeps_the_polynomial_order(gpu):
+    """eph_prop_shard on a propagator that has already stepped (device-resident pending polynomials and a queue of
+    deferred steps): the older windows must reach the host splines before the sharded branch pushes newer ones."""
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    n = 256
+    pos, vel, mu = plummer(n)
+    count = (np.arange(n) % 3 + 1).astype(np.uint32)
+    degree = (np.arange(n) % 3 + 5).astype(np.uint32)
+    for direction in (ea.FORWARD, ea.BACKWARD):
+        p = ea.NBodyPropagator(pos, vel, mu, 0.0, H, direction, count, degree)
+        q = ea.NBodyPropagator(pos, vel, mu, 0.0, H, direction, count, degree)
+        p.step_n(70)
+        for _ in range(7):
+            p.step()                                  # queued, not yet run
+        p.shard(0, 1, unique_id=ea.rccl_unique_id())
+        p.step_n(90)
+        q.step_n(70 + 7 + 90)
+        assert p.time() == q.time()
+        sp, sq = p.take_solution(), q.take_solution()
+        for b in range(n):
+            assert sp.info(b) == sq.info(b) and sp.info(b)[2] > 1
+            (cp, np_), (cq, nq) = sp.coeffs(b), sq.coeffs(b)
+            assert np.array_equal(np_, nq) and np.array_equal(cp, cq), (direction, b)

@@ -35,6 +35,15 @@ rng = np.random.default_rng(k)
 for n in (40, 1000, 4096):
     pos, mu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
     assert same(ea.accel_eval(pos, mu), orc.gravity(pos, mu)), ("accel", n)
+# operands that leave the wrapper-free division of the division forms (device_math.h pair_quot): a zero separation
+# component (numerator +-0), a massless source (mu = 0), numerators below 2^-200 -- lane-level IEEE fallback
+for n in (40, 300, 1000):
+    epos, emu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
+    epos[:8, 0] = epos[0, 0]
+    epos[8:16, 1] = epos[8, 1]
+    epos[16:20, 2] = 0.0
+    emu[3], emu[5], emu[17] = 0.0, 1e-70, 1e-68
+    assert same(ea.accel_eval(epos, emu), orc.gravity(epos, emu)), ("accel edge", n)
 # the variant differs from variant 0 somewhere (the flag does something)
 orc.set_pair_variant(0)
 base = orc.gravity(pos, mu)
@@ -79,11 +88,21 @@ for ncraft in (2, 20000):
         kt, kp, kv = batch.knots(i)
         ot, op, ov = c.knots()
         assert same(kt, ot) and same(kp, op) and same(kv, ov), ("craft", ncraft, i)
+# what the order costs at the metric's size (recorded in profiles/r03_pair_variants.md)
+import time
+pos, vel, mu = plummer(4096)
+g3 = ea.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
+g3.advance(12 + 50)
+g3.state()
+t0 = time.perf_counter()
+g3.advance(500)
+g3.state()
+print("variant %d us_per_step_4096 %.2f" % (k, (time.perf_counter() - t0) / 500 * 1e6))
 print("variant", k, "ok")
 '''
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_pair_variant_build_matches_oracle_variant(gpu, variant):
     from ephemeris_explorer_amd import build as b
     lib = b.build(pair_variant=variant)
@@ -93,6 +112,10 @@ def test_pair_variant_build_matches_oracle_variant(gpu, variant):
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert f"variant {variant} ok" in r.stdout
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    with open(out / "pair_variant_times.txt", "a") as f:
+        f.write([ln for ln in r.stdout.splitlines() if "us_per_step_4096" in ln][0] + "\n")
 
 
 def test_default_build_is_variant_zero(gpu):

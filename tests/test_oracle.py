@@ -316,30 +316,61 @@ def test_target_partitioned_openmp_gravity_has_the_same_bits():
     assert np.array_equal(acc_par, orc.gravity(pos, mu))
 
 
-def test_pair_formula_variants_stay_bounded():
+def test_pair_formula_variants_stay_bounded(capsys):
     """What the one unpinned choice can cost: the `particular` crate's source is absent, so the order in
-    which 1/r^3 is evaluated is a restatement. Three other plausible orders (1/(r*r*r); s*s*s with s = 1/sqrt(n2);
-    (1/n2)*(1/sqrt(n2))) differ from the pinned one by round-off only; after 1e5 QuinlanTremaine12 steps that is
-    <= 2e-9 AU on sun_earth_moon (68 years, worst body the Moon) and ~2e-8 AU on the fast moons of the full system
-    (1.9 years) -- pure along-track round-off growth, the same size as the f64-vs-exact-arithmetic gap. So agreement
-    with the Rust binary to 1e-9 AU needs the same operation order; what this repository guarantees is bit-identity
-    with the committed restatement."""
+    which the point-mass term is evaluated is a restatement. Six other plausible orders -- three "one reciprocal"
+    forms (1/(r*r*r); s*s*s with s = 1/sqrt(n2); (1/n2)*(1/sqrt(n2))) and the three DIVISION forms ((d*mu)/p,
+    d*(mu/p), (d/p)*mu with p = n2*sqrt(n2)) -- differ from the pinned one by round-off only; after 1e5
+    QuinlanTremaine12 steps that is a few 1e-9 AU on sun_earth_moon (68 years, worst body the Moon) and ~2e-8 AU on
+    the fast moons of the full system (1.9 years) -- pure along-track round-off growth, the same size as the
+    f64-vs-exact-arithmetic gap. So agreement with the Rust binary to 1e-9 AU needs the same operation order; what this
+    repository guarantees is bit-identity with the committed restatement IN THE SELECTED ORDER. The measured
+    displacement of each order against order 0 is printed and recorded in profiles/r03_pair_variants.md."""
     au = 1.495978707e8
-    bounds = {"sun_earth_moon_2433282.5": 5e-9, "full_solar_system_2433282.5": 2e-7}
+    bounds = {"sun_earth_moon_2433282.5": 1e-8, "full_solar_system_2433282.5": 2e-7}
     try:
         for name, bound in bounds.items():
             s = load_system(name)
             states = []
-            for variant in (0, 1, 2, 3):
+            for variant in range(7):
                 orc.set_pair_variant(variant)
                 o = orc.NBody(s.pos, s.vel, s.mu, s.epoch, s.dt)
                 assert o.advance(100_000) == 0
                 states.append(o.state()[0])
-            for variant in (1, 2, 3):
+            for variant in range(1, 7):
                 d = np.abs(states[variant] - states[0]).max() / au
+                with capsys.disabled():
+                    print(f"\n  {name}: variant {variant} vs 0 after 1e5 steps: {d:.3e} AU", end="")
                 assert 0.0 < d < bound, (name, variant, d)
     finally:
         orc.set_pair_variant(0)
+
+
+@pytest.mark.parametrize("variant", range(1, 7))
+def test_c_and_python_restatements_agree_in_every_pair_variant(variant):
+    """The switch exists in both restatements (eph_oracle.c point_mass_term, pyoracle.point_mass_term): same bits in
+    the same order, different bits from order 0 somewhere (otherwise the switch does nothing)."""
+    s = load_system("simple_solar_system_2433282.5")
+    ref = orc.gravity(s.pos, s.mu)
+    try:
+        orc.set_pair_variant(variant)
+        po.set_pair_variant(variant)
+        acc = orc.gravity(s.pos, s.mu)
+        y = [po.Vec(*p) for p in s.pos]
+        pa = np.array(po.gravity(y, list(s.mu), 0.0))
+        assert np.array_equal(acc, pa)
+        assert not np.array_equal(acc, ref)
+        assert np.abs(acc / ref - 1.0).max() < 1e-12      # round-off only (cancellation in the sums included)
+        nb = orc.NBody(s.pos, s.vel, s.mu, s.epoch, s.dt)
+        pr = po.Problem(s.pos, s.vel, s.mu, s.epoch)
+        lm = po.LinearMultistep2("QuinlanTremaine12", s.dt, pr)
+        assert nb.advance(20) == 0
+        for _ in range(20):
+            lm.advance()
+        assert np.array_equal(nb.state()[0], np.array(pr.y))
+    finally:
+        orc.set_pair_variant(0)
+        po.set_pair_variant(0)
 
 
 def test_erkn_table_satisfies_the_nystrom_order_conditions():
