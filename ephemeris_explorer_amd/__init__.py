@@ -44,7 +44,8 @@ ABI_SYMBOLS = [
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
     "eph_nbody_enable_timing", "eph_nbody_sync", "eph_rccl_unique_id", "eph_nbody_shard", "eph_nbody_shard_info",
-    "eph_prop_shard",
+    "eph_prop_shard", "eph_peer_create", "eph_peer_handle", "eph_peer_connect", "eph_peer_destroy", "eph_nbody_shard_peer",
+    "eph_prop_shard_peer",
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
@@ -148,6 +149,12 @@ def _lib():
     L.eph_nbody_shard.argtypes = [vp, i32, i32, vp, EXCHANGE_FN, vp]
     L.eph_nbody_shard_info.argtypes = [vp, _i32p, _i32p, C.POINTER(C.c_uint64)]
     L.eph_prop_shard.argtypes = [vp, i32, i32, vp, EXCHANGE_FN, vp]
+    L.eph_peer_create.argtypes = [i32, i32, C.c_uint64, C.POINTER(vp)]
+    L.eph_peer_handle.argtypes = [vp, vp]
+    L.eph_peer_connect.argtypes = [vp, vp]
+    L.eph_peer_destroy.argtypes = [vp]
+    L.eph_nbody_shard_peer.argtypes = [vp, vp]
+    L.eph_prop_shard_peer.argtypes = [vp, vp]
     L.eph_nbody_kernel_time.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.eph_nbody_enable_timing.argtypes = [vp, i32]
     L.eph_nbody_sync.argtypes = [vp]
@@ -319,6 +326,34 @@ def _shard_call(fn, name, handle, rank, world, unique_id, exchange):
     return cb                                          # the caller keeps the trampoline alive with the handle
 
 
+class PeerTransport:
+    """eph_peer: the direct-write exchange (csrc/peer.hip). Create on every rank, pass `handle` (64 bytes) to every other
+    rank, `connect(handles)` with all of them in rank order, then hand it to `NBodyIntegration.shard_peer` /
+    `NBodyPropagator.shard_peer` (`parallel.peer_transport(dist)` does the hand-shake over torch.distributed)."""
+
+    def __init__(self, rank, world, slot_bytes=1 << 22):
+        self._L = _lib()
+        h = C.c_void_p()
+        _check(self._L.eph_peer_create(int(rank), int(world), int(slot_bytes), C.byref(h)), "eph_peer_create")
+        self._h = h
+        self.rank, self.world = int(rank), int(world)
+        buf = (C.c_char * 64)()
+        _check(self._L.eph_peer_handle(self._h, buf), "eph_peer_handle")
+        self.handle = bytes(buf)
+
+    def connect(self, handles):
+        table = b"".join(bytes(h) for h in handles)
+        if len(table) != 64 * self.world:
+            raise ValueError("need one 64-byte handle per rank")
+        _check(self._L.eph_peer_connect(self._h, (C.c_char * len(table)).from_buffer_copy(table)), "eph_peer_connect")
+        return self
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.eph_peer_destroy(self._h)
+            self._h = None
+
+
 def hip_runtime():
     """The HIP runtime libephemeris_amd.so is bound to IN THIS PROCESS, as a ctypes object with hipMemcpy and
     hipStreamSynchronize: symbols looked up through the library's own handle (dlsym searches its dependencies), not through
@@ -409,6 +444,12 @@ class NBodyIntegration:
         hip_stream) -> 0 performing the in-place all-gather (see parallel.host_staged_exchange)."""
         self._exchange_cb = _shard_call(self._L.eph_nbody_shard, "eph_nbody_shard", self._h, rank, world, unique_id,
                                         exchange)
+        return self
+
+    def shard_peer(self, peer):
+        """eph_nbody_shard_peer: the same partition with the direct-write transport (a connected PeerTransport)."""
+        _check(self._L.eph_nbody_shard_peer(self._h, peer._h), "eph_nbody_shard_peer")
+        self._peer = peer
         return self
 
     def shard_info(self):
@@ -527,6 +568,12 @@ class NBodyPropagator:
         every rank); arguments as NBodyIntegration.shard."""
         self._exchange_cb = _shard_call(self._L.eph_prop_shard, "eph_prop_shard", self._h, rank, world, unique_id,
                                         exchange)
+        return self
+
+    def shard_peer(self, peer):
+        """eph_prop_shard_peer: eph_prop_shard with the direct-write transport (a connected PeerTransport)."""
+        _check(self._L.eph_prop_shard_peer(self._h, peer._h), "eph_prop_shard_peer")
+        self._peer = peer
         return self
 
     def _step_status(self, st, where):

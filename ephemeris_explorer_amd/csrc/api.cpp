@@ -238,6 +238,57 @@ int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rcc
     }
     return eph_nbody_shard(&p->view, rank, world, rccl_unique_id, fn, ctx);
 }
+// ---- direct-write transport (peer.hip) ----------------------------------------------------------------
+struct eph_peer {
+    std::shared_ptr<PeerTransport> t;
+};
+int32_t eph_peer_create(int32_t rank, int32_t world, uint64_t slot_bytes, eph_peer **out) {
+    EPH_GUARD_BEGIN
+    if (!out) return EPH_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    int st = check_device();
+    if (st) return st;
+    std::unique_ptr<eph_peer> p(new eph_peer());
+    if ((st = PeerTransport::create(rank, world, (size_t)slot_bytes, &p->t))) return st;
+    *out = p.release();
+    return EPH_OK;
+    EPH_GUARD_END
+}
+int32_t eph_peer_handle(eph_peer *p, void *out64) {
+    if (!p || !p->t || !out64) return EPH_ERR_BAD_ARGUMENT;
+    std::memcpy(out64, p->t->handle(), kPeerHandleBytes);
+    return EPH_OK;
+}
+int32_t eph_peer_connect(eph_peer *p, const void *handles) {
+    EPH_GUARD_BEGIN
+    if (!p || !p->t) return EPH_ERR_BAD_ARGUMENT;
+    return p->t->connect(handles);
+    EPH_GUARD_END
+}
+int32_t eph_peer_destroy(eph_peer *p) {
+    delete p;
+    return EPH_OK;
+}
+int32_t eph_nbody_shard_peer(eph_nbody *h, eph_peer *p) {
+    EPH_GUARD_BEGIN
+    if (!h || !h->p || !p || !p->t) return EPH_ERR_BAD_ARGUMENT;
+    if (hipSetDevice(h->p->device()) != hipSuccess) return EPH_ERR_HIP;
+    std::shared_ptr<Exchange> x;
+    int st = Exchange::create_peer(p->t, &x);
+    if (st) return st;
+    return h->p->set_shard(std::move(x));
+    EPH_GUARD_END
+}
+int32_t eph_prop_shard_peer(eph_prop *p, eph_peer *peer) {
+    if (!p || !p->p) return EPH_ERR_BAD_ARGUMENT;
+    {
+        EPH_GUARD_BEGIN
+        const int st = p->p->settle();
+        if (st) return st;
+        EPH_GUARD_END
+    }
+    return eph_nbody_shard_peer(&p->view, peer);
+}
 int32_t eph_nbody_shard_info(eph_nbody *h, int32_t *lo, int32_t *hi, uint64_t *gathers) {
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
     if (lo) *lo = h->p->shard_lo();

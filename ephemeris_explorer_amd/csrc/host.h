@@ -46,13 +46,48 @@ struct DevBuf {   // owning device allocation
     int reserve(size_t n) { return n <= count ? EPH_OK : alloc(n + n / 2); }   // grow-only scratch; contents are lost
 };
 
+// Direct-write transport of the exchange step (peer.hip): every rank owns a mailbox that its peers map through
+// hipIpc and write into; no collective library involved.
+constexpr int kPeerMaxWorld = 16;
+constexpr size_t kPeerHandleBytes = 64;            // sizeof(hipIpcMemHandle_t)
+class PeerTransport {
+public:
+    ~PeerTransport();
+    static int create(int rank, int world, size_t slot_bytes, std::shared_ptr<PeerTransport> *out);
+    const void *handle() const { return handle_; }           // kPeerHandleBytes, to be passed to every peer
+    int connect(const void *handles);                         // world x kPeerHandleBytes in rank order
+    int all_gather_inplace(void *buf, size_t slice_bytes, hipStream_t s);
+    int poll_error() const;                                   // EPH_ERR_COMM once a wait has timed out
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    uint64_t epochs() const { return epoch_; }
+
+private:
+    PeerTransport() = default;
+    int rank_ = 0, world_ = 1, device_ = 0;
+    size_t slot_ = 0;
+    void *base_[kPeerMaxWorld] = {};
+    char handle_[kPeerHandleBytes] = {};
+    bool connected_ = false;
+    uint64_t epoch_ = 0;
+    unsigned *status_ = nullptr, *status_dev_ = nullptr;
+    unsigned long long timeout_ticks_ = 0;
+    // exchanges of one transport are totally ordered on the device, whatever stream they are issued on (a handle
+    // and its clones share the transport but not the stream): each launch waits for the previous one's event
+    hipEvent_t order_ = nullptr;
+    hipStream_t last_stream_ = nullptr;
+    bool have_last_ = false;
+};
+
 // The exchange step of a target-partitioned run (shard.cpp): in-place all-gather of equal slices over the ranks.
 class Exchange {
 public:
     ~Exchange();
     static int create(int rank, int world, const void *unique_id, eph_exchange_fn fn, void *ctx,
                       std::shared_ptr<Exchange> *out);
+    static int create_peer(std::shared_ptr<PeerTransport> t, std::shared_ptr<Exchange> *out);
     int all_gather_inplace(void *buf, size_t slice_bytes, hipStream_t s);
+    int poll_error() const { return peer_ ? peer_->poll_error() : EPH_OK; }
     int rank() const { return rank_; }
     int world() const { return world_; }
     uint64_t gathers() const { return gathers_; }
@@ -63,6 +98,7 @@ private:
     void *comm_ = nullptr;          // ncclComm_t
     eph_exchange_fn fn_ = nullptr;
     void *ctx_ = nullptr;
+    std::shared_ptr<PeerTransport> peer_;
     uint64_t gathers_ = 0;
 };
 int rccl_unique_id(void *out128);

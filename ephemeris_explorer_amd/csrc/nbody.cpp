@@ -150,7 +150,7 @@ int NBodyIntegration::gather_stage() {
 int NBodyIntegration::sync() {
     EPH_HIP(hipSetDevice(device_));
     EPH_HIP(hipStreamSynchronize(stream_));
-    return EPH_OK;
+    return xch_ ? xch_->poll_error() : EPH_OK;          // a peer that never delivered (peer.hip) surfaces here
 }
 
 // FixedRungeKuttaIntegrator::advance (runge_kutta/mod.rs:112-125) with SRKN::advance (symplectic.rs:69-102)

@@ -8,6 +8,8 @@
 //   * RCCL over xGMI: ncclAllGather on the handle's own stream, no host synchronisation between steps. The
 //     library is resolved at run time (dlopen) so that a process that already carries an RCCL (PyTorch ships
 //     one) does not get a second copy; EPH_RCCL_LIB overrides the search.
+//   * direct peer writes (peer.hip, eph_peer_*): each rank's slice written straight into hipIpc-mapped mailboxes of
+//     its peers, one small launch per exchange, no collective library -- the low-latency transport for small systems.
 //   * a caller-supplied function (eph_exchange_fn), e.g. MPI or a host-staged gather; it is handed the stream
 //     and must order itself after the work enqueued there.
 #include <dlfcn.h>
@@ -105,10 +107,21 @@ int Exchange::create(int rank, int world, const void *unique_id, eph_exchange_fn
     return EPH_OK;
 }
 
+int Exchange::create_peer(std::shared_ptr<PeerTransport> t, std::shared_ptr<Exchange> *out) {
+    if (!t) return EPH_ERR_BAD_ARGUMENT;
+    std::shared_ptr<Exchange> e(new Exchange());
+    e->rank_ = t->rank();
+    e->world_ = t->world();
+    e->peer_ = std::move(t);
+    *out = std::move(e);
+    return EPH_OK;
+}
+
 // buf = world * slice_bytes; this rank's slice (at rank * slice_bytes) is current, the rest is filled in
 int Exchange::all_gather_inplace(void *buf, size_t slice_bytes, hipStream_t s) {
     if (slice_bytes == 0 || (world_ == 1 && !comm_)) return EPH_OK;
     gathers_ += 1;
+    if (peer_) return peer_->all_gather_inplace(buf, slice_bytes, s);
     if (comm_) {                                             // (a one-rank communicator still goes through RCCL)
         int rc = rccl()->AllGather((const char *)buf + (size_t)rank_ * slice_bytes, buf, slice_bytes, kNcclInt8,
                                    (Comm)comm_, s);

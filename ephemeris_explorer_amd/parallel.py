@@ -110,9 +110,23 @@ def broadcast_unique_id(dist, make_id, device="cpu", group=None):
     return bytes(buf.cpu().tolist())
 
 
+def peer_transport(dist, slot_bytes=1 << 22, group=None):
+    """A connected PeerTransport over the ranks of the process group: the 64-byte hipIpc handles travel through
+    torch.distributed (all_gather_object: any backend), the data never does."""
+    from . import PeerTransport
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    t = PeerTransport(rank, world, slot_bytes)
+    handles = [None] * world
+    dist.all_gather_object(handles, t.handle, group=group)
+    t.connect(handles)
+    dist.barrier(group=group)                        # every rank has mapped every mailbox before the first push
+    return t
+
+
 def shard_nbody(integration, dist=None, transport="rccl", device="cpu"):
     """Partition `integration` (an NBodyIntegration every rank created identically) over the ranks of the
-    initialised process group. transport "rccl": RCCL inside the library; "host": host_staged_exchange."""
+    initialised process group. transport "rccl": RCCL inside the library; "peer": direct writes into hipIpc-mapped
+    mailboxes (csrc/peer.hip); "host": host_staged_exchange."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return integration
     from . import rccl_unique_id
@@ -120,6 +134,8 @@ def shard_nbody(integration, dist=None, transport="rccl", device="cpu"):
     if transport == "rccl":
         uid = broadcast_unique_id(dist, rccl_unique_id, device=device)
         integration.shard(rank, world, unique_id=uid)
+    elif transport == "peer":
+        integration.shard_peer(peer_transport(dist))
     elif transport == "host":
         integration.shard(rank, world, exchange=host_staged_exchange(dist))
     else:

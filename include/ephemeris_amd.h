@@ -137,6 +137,22 @@ typedef int32_t (*eph_exchange_fn)(void *ctx, void *device_buffer, uint64_t slic
 int32_t eph_rccl_unique_id(void *out128);
 int32_t eph_nbody_shard(eph_nbody *h, int32_t rank, int32_t world, const void *rccl_unique_id,
                         eph_exchange_fn fn, void *ctx);
+/* Third transport: direct peer writes (csrc/peer.hip; SURVEY 5 "fully-connected direct write"). Each rank creates an
+ * eph_peer -- a mailbox in its own device memory, world slots of slot_bytes (rounded up to 256) per exchange parity --
+ * hands its 64-byte hipIpc handle to every other rank through any channel the caller has (MPI, a pipe,
+ * torch.distributed ...), and connects with the table of all world handles in rank order. An exchange is then ONE
+ * small launch on the handle's stream: write my slice into every peer's mailbox, raise a flag there, wait for the
+ * peers' flags, copy their slices into place -- no collective library, no host synchronisation; slices larger than a
+ * slot move in several rounds. One eph_peer serves any number of handles of the process (clones share it), as long as
+ * every rank issues its exchanges in the same order. A peer that does not deliver within EPH_PEER_TIMEOUT_MS
+ * (default 20000) ends the wait; the failure is reported as EPH_ERR_COMM by the next exchange or eph_nbody_sync /
+ * get_state. Works between processes on one device as well as across devices with peer access (xGMI). world <= 16. */
+typedef struct eph_peer eph_peer;
+int32_t eph_peer_create(int32_t rank, int32_t world, uint64_t slot_bytes, eph_peer **out);
+int32_t eph_peer_handle(eph_peer *p, void *out64);
+int32_t eph_peer_connect(eph_peer *p, const void *handles_world_x_64);
+int32_t eph_peer_destroy(eph_peer *p);
+int32_t eph_nbody_shard_peer(eph_nbody *h, eph_peer *p);
 /* owned bodies [lo, hi) and the number of all-gathers issued so far (any output may be NULL) */
 int32_t eph_nbody_shard_info(eph_nbody *h, int32_t *lo, int32_t *hi, uint64_t *gathers);
 
@@ -156,6 +172,7 @@ int32_t eph_prop_create(int32_t n, const double *pos_xyz, const double *vel_xyz,
  * propagator. eph_prop_step* / step_to / propagate / clone become collective calls. */
 int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
                        void *ctx);
+int32_t eph_prop_shard_peer(eph_prop *p, eph_peer *peer);
 /* IncrementalPropagator::step  nbody.rs:200-207. Executed lazily: the reference's callers step in a loop and read
  * time() / has_reached() after every step (ephemeris_explorer/src/prediction.rs:422-443); both are functions of the number
  * of steps taken, so a steady-state step only advances that bookkeeping on the host (and returns the StepError the step

@@ -58,12 +58,30 @@ def test_two_ranks_replicas():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e6
 
 
+def test_gpus_flag_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` the way the driver calls `--gpus 1`: no RANK / WORLD_SIZE in the environment. bench.py
+    becomes the launcher (torch.distributed.run on 127.0.0.1) and still prints ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["EPH_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--prewarm", "0"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["blocks"] >= 3
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    s4 = d["sharded_4096"]                              # the strong-scaling figure of the metric's own system
+    assert s4["ranks"] == 2 and s4["ms_per_step"] > 0 and s4["bit_identical_to_single_device"] is True
+
+
 def test_two_ranks_craft_sweep_with_result_gather():
     d = _run(["--workload", "craft", "--craft", "4001", "--craft-days", "0.05", "--steps", "1", "--prewarm", "0"], 2)
     assert d["n_gpus"] == 2 and d["metric"] == "craft-steps/s" and "all-gather" in d["config"]["exchange"]
 
 
-def test_two_ranks_one_sharded_system():
-    d = _run(["--workload", "nbody-sharded", "--bodies", "1024", "--transport", "host", "--steps", "5", "--warmup", "2",
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_two_ranks_one_sharded_system(transport):
+    d = _run(["--workload", "nbody-sharded", "--bodies", "1024", "--transport", transport, "--steps", "5", "--warmup", "2",
               "--prewarm", "0"], 2)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_per_gpu"] == 512

@@ -79,7 +79,7 @@ def test_failing_exchange_is_reported(gpu):
     assert e.value.status == -6 and "7" in str(e.value)
 
 
-def _worker(rank, world, port, n, method, steps, out):
+def _worker(rank, world, port, n, method, steps, out, transport="host"):
     import sys
     sys.path.insert(0, str(ROOT))
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -91,7 +91,7 @@ def _worker(rank, world, port, n, method, steps, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pos, vel, mu = plummer(n)
     nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H, method)
-    parallel.shard_nbody(nb, dist, transport="host")
+    parallel.shard_nbody(nb, dist, transport=transport)
     half = steps // 2
     nb.advance(half)
     twin = nb.clone()                                 # collective: every rank clones, the clones share the ranks
@@ -106,16 +106,22 @@ def _worker(rank, world, port, n, method, steps, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world,method,steps", [
-    (1024, 2, "QuinlanTremaine12", 12 + 40),          # wave kernel, start-up and steady state sharded
-    (1000, 2, "QuinlanTremaine12", 12 + 9),           # ragged: the last rank owns 488 bodies
-    (512, 4, "BlanesMoan6B", 5),                      # SRKN only
+@pytest.mark.parametrize("n,world,method,steps,transport", [
+    (1024, 2, "QuinlanTremaine12", 12 + 40, "host"),  # wave kernel, start-up and steady state sharded
+    (1000, 2, "QuinlanTremaine12", 12 + 9, "host"),   # ragged: the last rank owns 488 bodies
+    (512, 4, "BlanesMoan6B", 5, "host"),              # SRKN only
+    # the REAL device-to-device transport between processes: hipIpc-mapped mailboxes, direct writes, flags (peer.hip)
+    (1024, 2, "QuinlanTremaine12", 12 + 40, "peer"),
+    (1000, 2, "QuinlanTremaine12", 12 + 9, "peer"),
+    (4096, 4, "QuinlanTremaine12", 12 + 20, "peer"),  # the metric's system: 1024 targets per rank, workgroup kernel
+    (512, 4, "BlanesMoan6B", 5, "peer"),
 ])
-def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps):
+def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps, transport, monkeypatch):
     import torch.multiprocessing as mp
+    monkeypatch.setenv("EPH_PEER_TIMEOUT_MS", "5000")   # a rank that never delivers costs seconds, not the GPU
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, method, steps, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, method, steps, out, transport), nprocs=world, join=True)
     (p0, v0, t0, sc0), a0 = _single(n, method, steps)
     assert set(out.keys()) == set(range(world))
     npad = (n + 63) // 64 * 64
@@ -126,7 +132,7 @@ def test_ranks_on_one_gpu_match_single_device(gpu, n, world, method, steps):
         assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(a, a0), (r, n, method)
 
 
-def _prop_worker(rank, world, port, n, out):
+def _prop_worker(rank, world, port, n, out, transport="host"):
     import sys
     sys.path.insert(0, str(ROOT))
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -140,7 +146,10 @@ def _prop_worker(rank, world, port, n, out):
     count = (np.arange(n) % 3 + 1).astype(np.uint32)       # ragged sampling periods: the ranks own unequal window counts
     degree = (np.arange(n) % 3 + 5).astype(np.uint32)
     p = ea.NBodyPropagator(pos, vel, mu, 0.0, H, ea.FORWARD, count, degree)
-    parallel.shard_nbody(p, dist, transport="host")
+    if transport == "peer":
+        p.shard_peer(parallel.peer_transport(dist, slot_bytes=4096))   # small slots: the record gather goes in rounds
+    else:
+        parallel.shard_nbody(p, dist, transport=transport)
     sol = p.propagate(100 * H)
     rows = [(sol.info(b), sol.coeffs(b)) for b in (0, 1, n // 2 - 1, n // 2, n - 2, n - 1)]
     out[rank] = (p.time(), rows)
@@ -148,16 +157,18 @@ def _prop_worker(rank, world, port, n, out):
     dist.destroy_process_group()
 
 
-def test_sharded_propagator_builds_the_same_ephemeris(gpu):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_sharded_propagator_builds_the_same_ephemeris(gpu, transport, monkeypatch):
     """eph_prop_shard: two ranks on one GPU (host-staged exchange) each sample and fit the bodies they own, the
     polynomials are all-gathered: every rank ends with the single-device Vec<UniformSpline>, bit for bit."""
     import torch.multiprocessing as mp
     import ephemeris_explorer_amd as ea
     from ephemeris_explorer_amd.workloads import plummer
     n, world = 256, 2
+    monkeypatch.setenv("EPH_PEER_TIMEOUT_MS", "5000")
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_prop_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    mp.spawn(_prop_worker, args=(world, _free_port(), n, out, transport), nprocs=world, join=True)
     pos, vel, mu = plummer(n)
     count = (np.arange(n) % 3 + 1).astype(np.uint32)
     degree = (np.arange(n) % 3 + 5).astype(np.uint32)
@@ -250,3 +261,36 @@ def test_propagator_sharded_after_steps_keeps_the_polynomial_order(gpu):
             assert sp.info(b) == sq.info(b) and sp.info(b)[2] > 1
             (cp, np_), (cq, nq) = sp.coeffs(b), sq.coeffs(b)
             assert np.array_equal(np_, nq) and np.array_equal(cp, cq), (direction, b)
+
+
+def _lost_peer_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), EPH_PEER_TIMEOUT_MS="300")
+    import torch.distributed as dist
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel, mu = plummer(256)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H, "BlanesMoan6B")
+    parallel.shard_nbody(nb, dist, transport="peer")
+    if rank == 0:                                      # rank 1 never steps: rank 0's wait must end by itself
+        try:
+            nb.advance(1)
+            nb.sync()
+            out[0] = "no error"
+        except ea.EphemerisError as e:
+            out[0] = (e.status, str(e))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_that_never_delivers_is_an_error_not_a_hang(gpu):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lost_peer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    status, text = out[0]
+    assert status == -6 and "rank 1" in text
