@@ -93,3 +93,13 @@ def test_header_is_plain_c_and_the_c_example_links(product_lib, tmp_path):
         assert r.returncode == 77 and "no HIP device" in r.stderr.lower() or "-2" in r.stderr, (r.returncode, r.stderr)
     else:
         assert r.returncode == 0 and "inside=1" in r.stdout, (r.stdout, r.stderr)
+    # examples/craft.c: the spacecraft seam (a batch of one with the app's solout) from plain C
+    exe2 = tmp_path / "craft"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}",
+                           str(ROOT / "examples" / "craft.c"), f"-L{libdir}", "-lephemeris_amd",
+                           f"-Wl,-rpath,{libdir}", "-lm", "-o", str(exe2)])
+    r = subprocess.run([str(exe2)], capture_output=True, text=True)
+    if ea.device_count() < 1:
+        assert r.returncode == 77, (r.returncode, r.stderr)
+    else:
+        assert r.returncode == 0 and "apsides" in r.stdout, (r.stdout, r.stderr)

@@ -109,3 +109,45 @@ def test_c_example_runs_on_the_device(gpu, tmp_path):
     want = o.take_solution().eval(1, s.epoch + 10 * 86400.0)[0]
     got = np.array([float(x) for x in m.groups()])
     assert np.abs(got - want).max() < 1e-3 + 1e-12 * np.abs(want).max()
+
+
+def test_c_spacecraft_example_runs_on_the_device(gpu, tmp_path):
+    """examples/craft.c: INTEGRATION.md 4b's batch-of-one spacecraft propagator driven from plain C -- create, the app's
+    solout, a step_n loop until has_reached, knots + events. Everything it prints equals the restatement stepped the same
+    number of times (the burn in the Earth's TNB frame included)."""
+    import re
+    import subprocess
+    from conftest import ROOT, load_system
+    from ephemeris_explorer_amd.systems import soi_radii
+    exe = tmp_path / "craft"
+    libdir = ROOT / "ephemeris_explorer_amd"
+    subprocess.check_call(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "craft.c"), f"-L{libdir}",
+                           "-lephemeris_amd", f"-Wl,-rpath,{libdir}", "-lm", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    m = re.search(r"steps (\d+) in (\d+) calls, knots (\d+), t - t0 = ([-0-9.]+) s, r = \(([-0-9.]+), ([-0-9.]+), ([-0-9.]+)\) km", r.stdout)
+    e = re.search(r"transitions (\d+) \(first: body (-?\d+) at ([-0-9.]+) s\), apsides (\d+) \(event status (\d+)\)", r.stdout)
+    a = re.search(r"first apsis: (\w+) of body (\d+) at ([-0-9.]+) s, ([-0-9.]+) km", r.stdout)
+    assert m and e and a, r.stdout
+    steps, calls, knots = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert steps == 64 * calls and knots == steps + 1
+    s = load_system("sun_earth_moon_2433282.5")
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert o.step_to(s.epoch + 40 * 86400.0) == 0
+    eph = o.take_solution()
+    t0 = s.epoch
+    c = orc.Craft(eph, s.mu, t0, [-27204249.668775786, 132947582.43848978, 57641619.74241204],
+                  [-22.207539106181895, -5.189518219791726, -2.2515617105336263], "Verner87",
+                  burns=[(t0 + 7200.0, t0 + 7260.0, [5e-4, 0.0, 0.0], 1)], soi_radius=soi_radii(s))
+    for _ in range(steps):
+        assert c.step() == 0
+    st = c.state()
+    assert st["t"] >= t0 + 3 * 86400.0 and abs((st["t"] - t0) - float(m.group(4))) < 1e-6
+    assert np.abs(st["pos"] - np.array([float(m.group(k)) for k in (5, 6, 7)])).max() < 1e-6 + 1e-15 * np.abs(st["pos"]).max()
+    trt, trb = c.transitions()
+    apt, apd, apb, apk = c.apsides()
+    assert len(trt) == int(e.group(1)) and len(apt) == int(e.group(4)) and int(e.group(5)) == 0
+    assert trb[0] == int(e.group(2)) and abs((trt[0] - t0) - float(e.group(3))) < 1e-3
+    assert ("apoapsis" if apk[0] else "periapsis") == a.group(1) and apb[0] == int(a.group(2))
+    assert abs((apt[0] - t0) - float(a.group(3))) < 1e-3 and abs(apd[0] - float(a.group(4))) < 1e-6
+    assert len(apt) > 40                                  # ~15 orbits a day around the Earth
