@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
-    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div", "eph_debug_rsq",
 ]
 
 
@@ -217,6 +217,7 @@ def _lib():
                                    _i32p, _i64p]
     L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
     L.eph_debug_div.argtypes = [i64, _dp, _dp, _dp, _dp]
+    L.eph_debug_rsq.argtypes = [i64, _dp, _dp, _dp]
     if L.eph_abi_version() != 1:
         raise ImportError("libephemeris_amd.so ABI version mismatch")
     _L = L
@@ -896,6 +897,14 @@ def debug_div(a, b):
     fast, ieee = np.zeros_like(a), np.zeros_like(a)
     _check(_lib().eph_debug_div(a.size, _p(a), _p(b), _p(fast), _p(ieee)), "eph_debug_div")
     return fast, ieee
+
+
+def debug_rsq(x):
+    """test hook: (v_rsq_f64(x), h after the square root's coupled step) on the device"""
+    x = _f64(x).ravel()
+    y, h = np.zeros_like(x), np.zeros_like(x)
+    _check(_lib().eph_debug_rsq(x.size, _p(x), _p(y), _p(h)), "eph_debug_rsq")
+    return y, h
 
 
 def debug_pow(x, y):

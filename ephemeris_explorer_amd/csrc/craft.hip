@@ -2059,6 +2059,35 @@ int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast,
     } catch (...) { return EPH_ERR_HIP; }
 }
 
+// raw v_rsq_f64(x) and the h = 0.5 / sqrt(x) that the square root's coupled step leaves (the reciprocal's seed is 8 h^3):
+// the two quantities the error-bound note of inv_r3_seeded (device_math.h) starts from
+__global__ void k_debug_rsq(long long n, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ h1) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double yy = __builtin_amdgcn_rsq(x[i]);
+    const double g = x[i] * yy, h = yy * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    y[i] = yy;
+    h1[i] = __builtin_fma(h, r, h);
+}
+int32_t eph_debug_rsq(int64_t n, const double *x, double *rsq, double *h) {
+    try {
+        if (n < 0 || (n > 0 && (!x || !rsq || !h))) return EPH_ERR_BAD_ARGUMENT;
+        int st = check_device();
+        if (st) return st;
+        if (n == 0) return EPH_OK;
+        DevBuf<double> dx, dy, dh;
+        if ((st = dx.alloc(n)) || (st = dy.alloc(n)) || (st = dh.alloc(n))) return st;
+        EPH_HIP(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_debug_rsq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (long long)n, dx.p, dy.p, dh.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error("k_debug_rsq", e); return EPH_ERR_HIP; }
+        EPH_HIP(hipMemcpy(rsq, dy.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+        EPH_HIP(hipMemcpy(h, dh.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return EPH_OK;
+    } catch (...) { return EPH_ERR_HIP; }
+}
+
 int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out) {
     try {
         if (n < 0 || (n > 0 && (!x || !out))) return EPH_ERR_BAD_ARGUMENT;

@@ -73,12 +73,36 @@ __device__ __forceinline__ double rcp_inrange(double p) {
 // equal the compiler's IEEE expansions: n2 in [2^-300, 2^300) => sqrt in [2^-150, 2^150), products and reciprocals
 // within [2^-450, 2^450].
 // Variant 0 with the reciprocal's seed taken from the square root's own refinement instead of a second quarter-rate
-// v_rcp_f64: after the coupled step h = 0.5 / sqrt(x) to ~2^-45 or better, so 8 h^3 = 1 / (x sqrt(x)) to ~2^-43 -- far
-// tighter than the hardware seed (~2^-26), which makes the first of rcp_inrange's two Newton steps redundant. One
-// Newton step leaves r within half an ulp (+2^-80) of 1 / p, the same faithful value the compiler's sequence reaches,
-// and the closing residual step rounds it correctly: bit-identical to 1.0 / (x * sqrt(x)) (same tests as rcp_inrange,
-// plus eph_debug_inv_r3_sweep: 2.7e11 device-generated operands without a mismatch, 2^33 of them in
-// tests/test_gpu_parity.py). Saves a transcendental and one fma per interaction.
+// v_rcp_f64 (saves a transcendental and one fma per interaction). WHY THE RESULT IS RN(1 / p), p = RN(x RN(sqrt x)),
+// for every in-range x -- u = 2^-53, all fma single-rounded, "d_k" = a rounding error with |d_k| <= u:
+//  (1) Seed. y = v_rsq_f64(x) = (1 + e0) / sqrt(x); the ISA documents |e0| <= 2^29 ulp = 2^-23, measured max 2^-24.2
+//      (scripts/probe_rcp_edge.py, 4e6 operands). The coupled step gives h = (1 + e_h) / (2 sqrt x) with
+//      e_h = -(3/2) e0^2 - d_1/2 + d_4 + O(e0^3), so |e_h| <= 1.5 * 2^-46 + 1.5 u < 2^-45.3 (measured max 2^-47.8).
+//  (2) q0 = RN(RN(RN(h h) h) 8) = (1 + 3 e_h + d + d') / (x sqrt x), and p = x sqrt(x) (1 + eta)(1 + d_p) with |eta| <= u
+//      (g is the correctly rounded root: the lines up to `g = ...` ARE the compiler's sqrt expansion). Against 1 / p:
+//      q0 = (1 + eps) / p,  |eps| <= 3 |e_h| + 4u + (second order) < 2^-43.5.
+//  (3) Newton step. e = RN(1 - p q0) = -eps (1 + d_a) (the product is exact inside the fma), q1 = RN(q0 + q0 e)
+//      = RN((1 - eps^2 - eps d_a (1 + eps)) / p): q1 is the rounding of a value within 2^-86 (relative) of 1 / p,
+//      so |rho| <= 2^-54 p' + 2^-85 for rho = p q1 - 1, p' in [1, 2) the significand of p.
+//  (4) Residual step. p q1 is a 106-bit product within 2^-52 of 1, so 1 - p q1 = -rho is a multiple of 2^-105 below
+//      2^-52: representable, the fma returns it exactly; the last fma rounds v = q1 (1 - rho) = (1 - rho^2) / p ONCE.
+//      v < 1 / p, so RN(v) = RN(1 / p) unless a rounding boundary m (odd multiple of half an ulp) lies in [v, 1 / p).
+//      Scale p' into [1, 2), 1 / p' into (1/2, 1]: m p' is a multiple of 2^-106 and != 1, so 1 / p' - m = j 2^-106 / p'
+//      with an integer j >= 1, while 1 / p' - v = rho^2 / p' < 2^-106 (p'/2)^2 (1 + 2^-29) / p'. A boundary can be
+//      crossed only if j = 1 and p' > 2 - 2^-28. Writing p' = 2 - k 2^-52: the boundary just below 1 / p' is
+//      m = (2^53 + k) 2^-54 for odd k, with m p' = 1 - k^2 2^-106, i.e. j = k^2; for even k the nearest boundary is
+//      half an ulp away. So the ONLY significand for which the residual step can fail is k = 1, all ones (Markstein's
+//      exception): there 1 / p = m + 2^-107, an iterate from below rounds to q1 = 2^-(E+1), and v is an exact tie.
+//  (5) That significand cannot occur. x -> 4x maps g -> 2g and p -> 8p exactly, so which significands p can take
+//      just below a power of two depends only on the binade of p modulo 3; enumerating the x around (2^(E+1))^(2/3)
+//      for the three classes (tests/exceptional_operands.py) gives p = 2^(E+1) - k ulp with smallest k = 2, 3, 2:
+//      never 1. Those operands (every binade, k <= 64: 19 618 of them) are in
+//      tests/test_gpu_parity.py::test_inrange_sqrt_and_reciprocal_sequences_are_ieee, next to the random sweeps
+//      (eph_debug_inv_r3_sweep: 2.7e11 operands) that the argument above makes redundant but that stay as a guard
+//      against a transcription slip.
+// (The other variants and div_refined keep the compiler's own v_rcp_f64-seeded expansion, for which the same all-ones
+// exception exists in principle; on this hardware 1/b, 3/b and (2-ulp)/b come out correctly rounded for all-ones b in
+// every binade -- the same test -- because of where v_rcp_f64's seed falls, a measured property, not a theorem.)
 #ifndef EPH_RCP_SEED_FROM_RSQ
 #define EPH_RCP_SEED_FROM_RSQ 1
 #endif

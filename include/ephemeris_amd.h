@@ -392,6 +392,9 @@ int32_t eph_apsides_join(int64_t n_lhs, const double *t_lhs, const double *dista
                          const int32_t *kind_rhs, const int32_t *body_rhs, double at, int64_t capacity, double *t_out,
                          double *distance_out, int32_t *kind_out, int32_t *body_out, int64_t *n_out);
 
+/* Test hook: the hardware's v_rsq_f64(x[i]) and the h ~ 0.5/sqrt(x[i]) left by the square root's coupled refinement
+ * step -- the inputs of the error-bound note on inv_r3_seeded (csrc/device_math.h) */
+int32_t eph_debug_rsq(int64_t n, const double *x, double *rsq, double *h);
 /* Test hook: the step-size controller's correctly rounded pow(x[i], y) on the device */
 int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out);
 /* test hook: a[i] / b[i] through the shared-reciprocal division of k_craft_wave and through the compiler's IEEE

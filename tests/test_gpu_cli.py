@@ -130,7 +130,7 @@ def test_c_spacecraft_example_runs_on_the_device(gpu, tmp_path):
     a = re.search(r"first apsis: (\w+) of body (\d+) at ([-0-9.]+) s, ([-0-9.]+) km", r.stdout)
     assert m and e and a, r.stdout
     steps, calls, knots = int(m.group(1)), int(m.group(2)), int(m.group(3))
-    assert steps == 64 * calls and knots == steps + 1
+    assert knots == steps + 1 and 0 < steps <= 64 * calls, r.stdout   # a call that fills the slab stops early
     s = load_system("sun_earth_moon_2433282.5")
     o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
     assert o.step_to(s.epoch + 40 * 86400.0) == 0

@@ -203,12 +203,31 @@ def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu):
     x = np.ldexp(mant, expo)
     x = np.concatenate([x, np.arange(1, 4097, dtype=np.float64) ** 2, np.ldexp(1.0, np.arange(-300, 300)),
                         np.ldexp(np.nextafter(2.0, 0), np.arange(-300, 299))])
+    # the operands whose denominator p = x sqrt(x) comes closest to the top of its binade, p = 2^(E+1) - k ulp: k = 1 (all
+    # ones) is the one significand for which the reciprocal's closing residual step can fail, and it cannot occur
+    # (csrc/device_math.h, note on inv_r3_seeded); k = 2 .. 64 in every binade of the guarded range are here
+    from exceptional_operands import top_of_binade_operands
+    xt, kt = top_of_binade_operands(kmax=64)
+    assert len(xt) > 15000 and kt.min() == 2
+    x = np.concatenate([x, xt])
     fast, ieee = gpu.debug_inv_r3(x)
     host = 1.0 / (x * np.sqrt(x))
     ok = ~np.isnan(fast)
     assert ok.mean() > 0.999                       # only the range ends fall to the IEEE form
     assert_same_bits(ieee, host, "device IEEE expansions vs host")
     assert_same_bits(fast[ok], host[ok], "in-range sequences vs host")
+    # the seed the error bound starts from: v_rsq_f64 within its documented 2^-23, h after the coupled step within 2^-45
+    y, h = gpu.debug_rsq(x[:500_000])
+    xl = x[:500_000].astype(np.longdouble)
+    assert np.abs((y.astype(np.longdouble) * np.sqrt(xl) - 1).astype(np.float64)).max() < 2.0 ** -23
+    assert np.abs((h.astype(np.longdouble) * 2 * np.sqrt(xl) - 1).astype(np.float64)).max() < 2.0 ** -45
+    # the device's own division (and the shared-reciprocal form of it) on all-ones denominators, the exceptional
+    # significand of ITS residual step: correctly rounded on this hardware in every binade
+    b = np.ldexp(np.nextafter(2.0, 0), np.arange(-199, 199))
+    for a in (1.0, 3.0, np.nextafter(2.0, 0), 1.0 + 2.0 ** -52):
+        qf, qi = gpu.debug_div(np.full_like(b, a), b)
+        assert_same_bits(qi, a / b, "compiler division, all-ones denominator")
+        assert_same_bits(qf, a / b, "shared-reciprocal division, all-ones denominator")
     # outside the guard the fast form is not used
     out = np.array([0.0, 1e-300, 1e300, np.inf, 5e-324])
     f2, _ = gpu.debug_inv_r3(out)
