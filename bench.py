@@ -139,12 +139,11 @@ def craft_main(args):
     ship = load_ship(sysdir / "ships" / "Mars Transfer Ship.json")
     sol = ea.NBodyPropagator.from_system(s).propagate(s.epoch + (args.craft_days + 40.0) * 86400.0)
     eph = ea.Ephemeris(sol, s.mu)
-    rng = np.random.default_rng(20260926)
-    pos = ship.pos + rng.normal(0.0, 100.0, size=(args.craft, 3))
-    vel = ship.vel + rng.normal(0.0, 0.01, size=(args.craft, 3))
+    from ephemeris_explorer_amd.workloads import craft_population, wave_divergence
+    pos, vel, family = craft_population(args.population, args.craft, s, ship, order=args.population_order)
     lo, hi = shard_range(args.craft, rank, world)
     t_end = ship.start + args.craft_days * 86400.0
-    max_knots = int(1200 * args.craft_days) + 64
+    max_knots = int((1200 if args.population == "transfer" else 400) * args.craft_days) + 64   # (a low orbit: ~215 knots a day)
 
     def make():          # one SpacecraftPropagator per craft: states, timelines and knot slabs resident in HBM
         return ea.SpacecraftBatch(eph, ship.start, pos[lo:hi], vel[lo:hi], "Verner87", max_knots=max_knots)
@@ -174,14 +173,14 @@ def craft_main(args):
     t0 = time.perf_counter()
     for b in batches:
         sweep(b)
-        st = b.status()
+        st = b.summary()                                # ONE device-packed record per craft, one copy
         assert (st["status"] == 0).all()
         steps_local += int(st["steps"].sum())
         attempts_local += int(st["attempts"].sum())
         ms += b.kernel_ms()
         # the sweep's one exchange step: final states of all craft on every rank -- ncclAllGather over
         # xGMI for world > 1 (north_star: "RCCL over xGMI only for the embarrassingly-parallel spacecraft sweep")
-        table = gather_craft_states(b.state(), args.craft, dist, device="cuda" if backend_is_nccl else "cpu")
+        table = gather_craft_states(st, args.craft, dist, device="cuda" if backend_is_nccl else "cpu")
     barrier()
     elapsed = time.perf_counter() - t0
     assert table.shape == (args.craft, 7) and np.isfinite(table).all() and (table[:, 0] >= t_end).all()
@@ -196,7 +195,11 @@ def craft_main(args):
             "n_gpus": world, "steps": nsweeps, "warmup": 2, "ms_per_step": elapsed / nsweeps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"full_solar_system ephemeris + {args.craft} craft x {args.craft_days} d, Verner87 "
-                                   "tol 1e-3 (BASELINE.json configs[3], bounded)", "parallelism": f"craft sharded x{world}",
+                                   "tol 1e-3 (BASELINE.json configs[3], bounded)"
+                                   + ("" if args.population == "transfer" else
+                                      f"; population '{args.population}' ({args.population_order}): LEO / GTO / lunar transfer / "
+                                      "heliocentric in equal numbers"),
+                       "parallelism": f"craft sharded x{world}",
                        "exchange": "1 all-gather of the final states per sweep (56 B per craft)" if world > 1 else "none (1 rank)"},
             "kernel_ms_rank0": ms, "includes": "sweep kernel + per-craft status / final state read-back + result all-gather "
                                               "(batches created before the timed region: state resident in HBM)",
@@ -210,6 +213,13 @@ def craft_main(args):
                      "flop_per_launch": flop / nsweeps, "attempts_per_launch": attempts_local / nsweeps,
                      "count": "13 stages x 32 bodies x 74 flop per attempt (SURVEY 8(d))"},
         }
+        # lane idling of a static craft -> lane assignment: per wave max / mean attempts (1.0 = none), and what the
+        # kernel did about it (the work queue of k_craft_propagate refills finished lanes)
+        att = st["attempts"].astype(np.float64)
+        out["divergence"] = {"attempts_max_over_mean_per_wave": wave_divergence(att),
+                             "attempts_per_craft_min": float(att.min()), "attempts_per_craft_max": float(att.max()),
+                             "steps_by_family": {str(f): float(st["steps"][family[lo:hi] == f].mean())
+                                                 for f in sorted(set(family[lo:hi].tolist()))}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = craft_cpu_baseline(s, ship, pos, vel, t_end, args.craft_days)
         print(json.dumps(out), flush=True)
@@ -362,6 +372,10 @@ def main():
                          "steady shader clock instead of the ramp from idle (0 = off)")
     ap.add_argument("--craft", type=int, default=262144)
     ap.add_argument("--craft-days", type=float, default=0.25)
+    ap.add_argument("--population", choices=["transfer", "mixed"], default="transfer",
+                    help="craft workload: transfer (SURVEY 8(d)4: one heliocentric arc +- 100 km) | mixed: LEO / GTO / lunar "
+                         "transfer / heliocentric in equal numbers (step counts spanning > 10x)")
+    ap.add_argument("--population-order", choices=["interleaved", "blocked"], default="interleaved")
     args = ap.parse_args()
     if args.workload == "craft":
         return craft_main(args)

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_inv_r3_sweep", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
-    "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
+    "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_summary", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div", "eph_debug_rsq",
 ]
@@ -194,6 +194,7 @@ def _lib():
     L.eph_craft_batch_state.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.eph_craft_batch_knots.argtypes = [vp, i64, _dp, _dp, _dp]
     L.eph_craft_batch_kernel_time.argtypes = [vp, _dp]
+    L.eph_craft_batch_summary.argtypes = [vp, vp]
     L.eph_craft_batch_clone.argtypes = [vp, C.POINTER(vp)]
     L.eph_solution_create.argtypes = [i32, _dp, _dp, _i64p, _dp, _i32p, C.POINTER(vp)]
     L.eph_solution_clear.argtypes = [vp, i32, f64, i32]
@@ -714,6 +715,17 @@ class SpacecraftBatch:
         _check(self._L.eph_craft_batch_status(self._h, _p(st, _i32p), _p(nk, _i32p), _p(at, _u32p), _p(sp, _u32p)),
                "eph_craft_batch_status")
         return dict(status=st, nknots=nk, attempts=at, steps=sp)
+
+    RECORD = np.dtype([("t", "f8"), ("pos", "f8", 3), ("vel", "f8", 3), ("next_h", "f8"), ("status", "i4"), ("nknots", "i4"),
+                       ("attempts", "u4"), ("steps", "u4")])        # eph_craft_record
+
+    def summary(self):
+        """status() and state() in one device-packed record array (eph_craft_batch_summary): fields t, pos, vel, next_h,
+        status, nknots, attempts, steps."""
+        rec = np.zeros(self.n, dtype=self.RECORD)
+        assert rec.itemsize == 80
+        _check(self._L.eph_craft_batch_summary(self._h, rec.ctypes.data_as(C.c_void_p)), "eph_craft_batch_summary")
+        return rec
 
     def state(self):
         t, h = np.zeros(self.n), np.zeros(self.n)

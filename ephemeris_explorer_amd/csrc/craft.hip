@@ -57,6 +57,7 @@ struct CraftArgs {
     unsigned n_max;
     double t_end;
     unsigned step_limit;      // accepted steps this call may take per craft (0 = until t_end)
+    unsigned long long *queue;   // k_craft_propagate's work queue: the next craft nobody has started (set by craft_launch)
 };
 
 struct V3 { double x, y, z; };
@@ -396,6 +397,9 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
 // by batch size. (Also measured: a runtime stage loop around ONE copy of the right-hand side, stage combinations
 // selected by a uniform switch -- 4x less code than this unrolled form, which exceeds the instruction cache -- is
 // slower, 1.03e8 / 1.12e8: every k[][] element then stays live across the loop and the allocator spills more.)
+// The sweep, STATIC form: craft i on thread i for the whole call. The right form when every craft takes about the same
+// number of attempts (the north star's sweep: one transfer arc +- 100 km, max / mean attempts per wave 1.09) or when the
+// batch fits the chip at once; k_craft_queue below is the form for heterogeneous batches (craft_launch chooses).
 template <int S, bool FSAL, bool NYS = false, int OCC = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 k_craft_propagate(const CraftArgs a) {
@@ -448,85 +452,15 @@ k_craft_propagate(const CraftArgs a) {
             const double h = next_h;
             if (time >= bound) { status = EPH_BOUND_REACHED; failed = true; break; }
             if (time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; break; }
-            // ERK::advance  explicit.rs:72-106
-            bool ok = true;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (FSAL && s == 0 && rk_i > 0) {
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) { const double t = k[0][d]; k[0][d] = k[S - 1][d]; k[S - 1][d] = t; }
-                    continue;
-                }
-                if (!ok) continue;
-                const double ti = time + h * a.rk.C[s];
-                double yi[6];
-                if (NYS) {
-                    const double hc = h * a.rk.C[s];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { yi[d] = y[d] + y[3 + d] * hc; yi[3 + d] = y[3 + d]; }
-#pragma unroll
-                    for (int j = 0; j < s; ++j) {
-                        const double hhap = h * h * a.rk.A[s][j], hav = h * a.rk.A2[s & 7][j & 7];
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            yi[d] = yi[d] + k[j][d] * hhap;
-                            yi[3 + d] = yi[3 + d] + k[j][d] * hav;
-                        }
-                    }
-                    double out[6];
-                    ok = craft_rhs<false>(a, sg, ti, yi, out, nullptr);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) k[s][d] = out[3 + d];
-                    continue;
-                }
-#pragma unroll
-                for (int d = 0; d < 6; ++d) yi[d] = y[d];
-#pragma unroll
-                for (int j = 0; j < s; ++j) {
-                    const double ha = h * a.rk.A[s][j];
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) yi[d] = yi[d] + k[j][d] * ha;
-                }
-                ok = craft_rhs<false>(a, sg, ti, yi, k[s], nullptr);
-            }
+#define EPH_RK a.rk
+#define EPH_ATTEMPT_PART 1
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
             if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
-            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (NYS) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) y[d] = y[d] + y[3 + d] * h;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const double hhbp = h * h * a.rk.B[s], hbv = h * a.rk.B2[s & 7];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        y[d] = y[d] + k[s][d] * hhbp;
-                        y[3 + d] = y[3 + d] + k[s][d] * hbv;
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const double hhep = h * h * a.rk.E[s], hev = h * a.rk.E2[s & 7];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        e[d] = e[d] + k[s][d] * hhep;
-                        e[3 + d] = e[3 + d] + k[s][d] * hev;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const double hb = h * a.rk.B[s];
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) y[d] = y[d] + k[s][d] * hb;
-                }
-                // RKEmbedded::error
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const double he = h * a.rk.E[s];
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) e[d] = e[d] + k[s][d] * he;
-                }
-            }
+#define EPH_ATTEMPT_PART 2
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+#undef EPH_RK
             time = time + h;
             rk_i += 1;
             n_att += 1;
@@ -574,6 +508,169 @@ k_craft_propagate(const CraftArgs a) {
     if (FSAL) {
 #pragma unroll
         for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+    }
+}
+
+// The sweep, QUEUE form, for batches whose craft need very different numbers of attempts (adaptive step counts differ by
+// more than 10x between a low orbit and a heliocentric cruise: bench.py --population mixed, max / mean attempts per wave
+// 2.9). A PERSISTENT grid (craft_launch sizes it to what the chip holds) and a work queue: lane L starts with craft L; a
+// lane whose craft is finished (reached t_end, took its steps, failed, or filled its knot slab) stores it and takes the
+// next unstarted craft from an atomic counter (a.queue), so a wave does not idle 63 lanes waiting for its slowest craft.
+// For the same reason the loop is FLAT: one iteration = one ATTEMPT of every active lane; accepting (knot) or rejecting
+// (restore) is lane-local bookkeeping after it, so an accepted lane does not sit through its neighbours' retries.
+// Measured (MI355X, Verner87, 524 288 mixed craft x 2 d): static 605 ms, queue with whole steps per iteration 492 ms, this
+// form 370 ms; on the homogeneous sweep it is 10 % slower than the static kernel (42.6 vs 38.7 ms) -- hence two kernels.
+// Craft are independent and every craft's operations are the reference's in the reference's order, so which lane
+// integrates a craft, and when, does not touch a bit of its result (tests/test_gpu_craft.py runs both forms).
+template <int S, bool FSAL, bool NYS = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_craft_queue(const CraftArgs a) {
+    const long long n = a.n_craft;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+
+    // the craft this lane is integrating (registers); `have` = it still has work in this call
+    int status = EPH_OK;
+    double time = 0.0, y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, next_h = 0.0, last_knot = 0.0, bound = 0.0;
+    unsigned n_att = 0, rk_i = 0, steps = 0, taken = 0;
+    int cur = 0, nk = 0;
+    const SegmentDev *segs = a.segs;
+    SegmentDev sg{};
+    double k[S][6];
+    double prev_t = 0.0, prev_y[6], prev_klast[6];
+    unsigned prev_i = 0;
+    bool in_step = false;                               // between a step's prologue and its acceptance
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { prev_y[d] = 0.0; prev_klast[d] = 0.0; }
+
+    auto load = [&]() -> bool {                         // craft i -> registers; false: nothing to do for it
+        status = a.status[i];
+        if (status != EPH_OK && status != EPH_KNOTS_FULL) return false;    // a failed craft stays failed
+        status = EPH_OK;
+        time = a.time[i];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) y[d] = a.y[d * n + i];
+        next_h = a.next_h[i];
+        n_att = a.n_attempts[i]; rk_i = a.rk_i[i]; steps = a.steps[i];
+        cur = a.cur_seg[i]; nk = a.nknots[i];
+        last_knot = a.last_knot_t[i];
+        segs = a.segs + a.seg_off[i];
+        sg = segs[cur];
+        bound = sg.end;
+        if (FSAL) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) k[S - 1][d] = a.klast[d * n + i];
+        }
+        taken = 0;
+        in_step = false;
+        return true;
+    };
+    auto store = [&]() {
+        a.time[i] = time;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.y[d * n + i] = y[d];
+        a.next_h[i] = next_h;
+        a.n_attempts[i] = n_att;
+        a.rk_i[i] = rk_i;
+        a.steps[i] = steps;
+        a.cur_seg[i] = cur;
+        a.nknots[i] = nk;
+        a.last_knot_t[i] = last_knot;
+        a.status[i] = status;
+        if (FSAL) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+        }
+    };
+
+    bool have = i < n && load();
+    bool drained = i >= n;                              // this lane will get no more craft
+    for (;;) {
+        // ---- lanes without work take the next craft from the queue
+        while (!have && !drained) {
+            i = (long long)atomicAdd(a.queue, 1ull);
+            if (i >= n) { drained = true; break; }
+            have = load();
+        }
+        if (__builtin_amdgcn_ballot_w64(have) == 0) break;          // every lane of the wave is out of work
+        if (have) {
+            // ---- between steps: is this craft done?  (has_reached: solution.end() >= time; the step budget; the slab)
+            if (!in_step) {
+                bool done = last_knot >= a.t_end || (a.step_limit && taken >= a.step_limit);
+                if (!done && nk >= a.max_knots) { status = EPH_KNOTS_FULL; done = true; }
+                if (done) { store(); have = false; continue; }
+                // SpacecraftPropagator::step: advance_timeline + reset_integrator  spacecraft.rs:606-609
+                if (time >= sg.end) {
+                    cur += 1;
+                    sg = segs[cur];
+                    bound = sg.end;
+                    next_h = a.h_init;
+                    n_att = 0;
+                    rk_i = 0;
+                }
+                // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439: PreviousStep
+                prev_t = time;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? k[S - 1][d] : 0.0; }
+                prev_i = rk_i;
+                in_step = true;
+            }
+            // ---- one attempt. The method table through a pointer the optimiser cannot see through: hoisted out of the
+            // persistent loop, the kernel-argument copy (a.rk) pins ~130 coefficients in SGPRs and spills 268 of them to
+            // VGPR lanes; re-read per attempt they are scalar-cache hits
+            const ErkCoeffs *rkp = a.rkd;
+            asm volatile("" : "+s"(rkp));
+#define EPH_RK (*rkp)
+            bool failed = false;
+            if (n_att > a.n_max) { status = EPH_MAX_ITERATIONS_REACHED; failed = true; }
+            if (!failed && time + next_h > bound) next_h = bound - time;
+            const double h = next_h;
+            if (!failed && time >= bound) { status = EPH_BOUND_REACHED; failed = true; }
+            if (!failed && time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; }
+            if (!failed) {
+#define EPH_ATTEMPT_PART 1
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+                if (!ok) { status = EPH_EVAL_FAILED; failed = true; }
+            }
+            if (failed) { store(); have = false; continue; }   // a StepError ends the craft (state as the reference leaves it)
+#define EPH_ATTEMPT_PART 2
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+#undef EPH_RK
+            time = time + h;
+            rk_i += 1;
+            n_att += 1;
+            // AbsTol::err_over_tol
+            const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
+            const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
+            const double err = fmax(pm, vm);
+            // IController::step  mod.rs:225-243
+            const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
+            const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
+            const double nh = next_h * c;
+            next_h = nh > a.h_max ? a.h_max : nh;
+            if (err <= 1.0) {
+                // accepted. CubicHermiteSplineSolout::solout: push (t, r, v)
+                steps += 1;
+                taken += 1;
+                a.knot_t[(long long)nk * n + i] = time;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + i] = y[d];
+                nk += 1;
+                last_knot = time;
+                in_step = false;
+            } else {
+                time = prev_t;                            // PreviousStep::restore
+#pragma unroll
+                for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+                rk_i = prev_i;
+                if (FSAL) {
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) k[S - 1][d] = prev_klast[d];
+                }
+            }
+        }
     }
 }
 
@@ -1390,7 +1487,7 @@ static bool craft_wave_form(long long n_craft) {
     }();
     return form ? form == 1 : n_craft <= kCraftWaveMax;
 }
-static int craft_launch(hipStream_t s, const CraftArgs &a) {
+static int craft_launch(hipStream_t s, const CraftArgs &a, bool heterogeneous) {
     const bool wave = craft_wave_form(a.n_craft);
     if (wave) {
         const dim3 grid((unsigned)a.n_craft), block(64);
@@ -1400,17 +1497,52 @@ static int craft_launch(hipStream_t s, const CraftArgs &a) {
         if (e != hipSuccess) { set_last_error("k_craft_wave", e); return EPH_ERR_HIP; }
         return EPH_OK;
     }
-    const dim3 grid((unsigned)((a.n_craft + 63) / 64)), block(64);
+    static const long long simds = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (long long)std::max(cus, 1) * 4;
+    }();
+    const long long waves = (a.n_craft + 63) / 64;
+    const int S = a.rk.stages;
+    const bool F = a.rk.fsal != 0;
+    // Which sweep kernel. The queue form pays when craft need very different numbers of attempts AND there are more
+    // craft than the chip holds at once (two waves per SIMD), so that a finished lane has something to take; otherwise
+    // the static form is the faster one (see k_craft_queue). `heterogeneous` is eph_craft_batch_create's estimate from the
+    // initial states; EPH_CRAFT_QUEUE=0|1 overrides (tuning, tests).
+    static const int forced_q = [] { const char *e = getenv("EPH_CRAFT_QUEUE"); return !e || !*e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    const bool queue = forced_q >= 0 ? forced_q == 1 : (heterogeneous && waves > 2 * simds);
+    if (queue) {
+        const long long resident = std::min(waves, 2 * simds);
+        const dim3 grid((unsigned)resident), block(64);
+        // the queue starts behind the craft the grid's own lanes begin with
+        if (hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s) != hipSuccess ||
+            hipMemsetD32Async((hipDeviceptr_t)a.queue, (int)(resident * 64), 1, s) != hipSuccess) {
+            set_last_error("craft queue reset", hipGetLastError());
+            return EPH_ERR_HIP;
+        }
+        if (a.rk.nystrom) {
+            if (S == 7 && F) hipLaunchKernelGGL((k_craft_queue<7, true, true>), grid, block, 0, s, a);
+            else return EPH_ERR_UNSUPPORTED;
+        } else if (S == 6 && !F) hipLaunchKernelGGL((k_craft_queue<6, false>), grid, block, 0, s, a);
+        else if (S == 7 && F) hipLaunchKernelGGL((k_craft_queue<7, true>), grid, block, 0, s, a);
+        else if (S == 7 && !F) hipLaunchKernelGGL((k_craft_queue<7, false>), grid, block, 0, s, a);
+        else if (S == 9 && !F) hipLaunchKernelGGL((k_craft_queue<9, false>), grid, block, 0, s, a);
+        else if (S == 13 && !F) hipLaunchKernelGGL((k_craft_queue<13, false>), grid, block, 0, s, a);
+        else if (S == 16 && !F) hipLaunchKernelGGL((k_craft_queue<16, false>), grid, block, 0, s, a);
+        else return EPH_ERR_UNSUPPORTED;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_last_error("k_craft_queue", e); return EPH_ERR_HIP; }
+        return EPH_OK;
+    }
+    const dim3 grid((unsigned)waves), block(64);
     // more waves of craft than SIMDs (256 CUs x 4): hold the kernel to two waves per SIMD (EPH_CRAFT_OCC overrides)
     static const int forced = [] { const char *e = getenv("EPH_CRAFT_OCC"); return e ? atoi(e) : 0; }();
-    const bool occ2 = forced ? forced == 2 : (a.n_craft + 63) / 64 > 1024;
+    const bool occ2 = forced ? forced == 2 : waves > simds;
 #define EPH_CRAFT_CASE(S_, F_)                                                                     \
     do {                                                                                           \
         if (occ2) hipLaunchKernelGGL((k_craft_propagate<S_, F_, false, 2>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((k_craft_propagate<S_, F_, false, 1>), grid, block, 0, s, a);      \
     } while (0)
-    const int S = a.rk.stages;
-    const bool F = a.rk.fsal != 0;
     if (a.rk.nystrom) {
         if (S == 7 && F) hipLaunchKernelGGL((k_craft_propagate<7, true, true, 2>), grid, block, 0, s, a);
         else return EPH_ERR_UNSUPPORTED;
@@ -1438,6 +1570,7 @@ struct eph_ephemeris {
     DevBuf<double> coeffs;
     DevBuf<int> ncoef;
     std::vector<BodyEntry> host_bodies;
+    std::vector<double> host_coeffs;           // the coefficient rows as uploaded (host-side estimates only, never results)
 };
 
 struct eph_craft_batch {
@@ -1455,6 +1588,9 @@ struct eph_craft_batch {
     DevBuf<long long> seg_off;
     DevBuf<SegmentDev> segs;
     DevBuf<ErkCoeffs> rk_dev;
+    DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (allocated on first use)
+    DevBuf<unsigned long long> queue;         // k_craft_queue's work queue (one counter)
+    bool heterogeneous = false;               // the craft's dynamical time scales differ widely (craft_time_scales): queue form
     // SpacecraftSolout events (optional)
     bool events = false;
     int max_tr = 0, max_ap = 0;
@@ -1471,6 +1607,43 @@ struct eph_craft_batch {
         }
     }
 };
+
+// Scheduling estimate (never part of a result): does the batch mix craft whose adaptive step sizes will differ widely?
+// The step size of an embedded pair follows the local dynamical time sqrt(d^3 / mu) of the nearest massive body, so a
+// sample of up to 512 craft gets tau_i = min over bodies of sqrt(|r_i - r_b(t0_i)|^3 / mu_b) from the host copy of the
+// ephemeris (plain Horner, approximate is fine) and the batch counts as heterogeneous when the 95th and 5th percentile
+// of tau differ by more than 4x: a low orbit 860 s, a lunar transfer's perigee the same but its apogee days, a
+// heliocentric cruise 5e6 s. craft_launch uses it to pick k_craft_queue over the static kernel.
+static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const double *t0, const double *pos) {
+    if (n < 128 || e.host_coeffs.empty()) return false;
+    const long long m = std::min<long long>(n, 512), stride = n / m;
+    std::vector<double> tau;
+    tau.reserve((size_t)m);
+    for (long long q = 0; q < m; ++q) {
+        const long long i = q * stride;
+        double best = INFINITY;
+        for (const BodyEntry &b : e.host_bodies) {
+            if (!(b.mu > 0.0) || b.npoly <= 0) continue;
+            const double local = t0[i] - b.start;
+            if (!(local >= 0.0) || local > b.span) continue;
+            long long idx = (long long)std::ceil(local / b.interval) - 1;
+            idx = std::min(std::max<long long>(idx, 0), b.npoly - 1);
+            const double tq = (local - b.interval * (double)idx) / b.interval;
+            const double *c = &e.host_coeffs[(size_t)(b.coeff_off + idx) * kDiv * 3];
+            double bp[3] = {0.0, 0.0, 0.0};
+            for (int k = kDiv - 1; k >= 0; --k)
+                for (int d = 0; d < 3; ++d) bp[d] = bp[d] * tq + c[k * 3 + d];
+            const double dx = pos[3 * i] - bp[0], dy = pos[3 * i + 1] - bp[1], dz = pos[3 * i + 2] - bp[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            best = std::min(best, std::sqrt(d2 * std::sqrt(d2) / b.mu));
+        }
+        if (std::isfinite(best)) tau.push_back(best);
+    }
+    if (tau.size() < 64) return false;
+    std::sort(tau.begin(), tau.end());
+    const double lo = tau[tau.size() / 20], hi = tau[tau.size() - 1 - tau.size() / 20];
+    return hi > 4.0 * lo;
+}
 
 // Timeline::new  ephemeris/src/propagators/spacecraft.rs:129-152: stable sort by start, coast segments in the gaps,
 // from Epoch::MIN to Epoch::MAX; appended to `segs`
@@ -1534,6 +1707,7 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
         if (nb) EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * nb, hipMemcpyHostToDevice));
         EPH_HIP(hipMemcpy(e->coeffs.p, co.data(), sizeof(double) * co.size(), hipMemcpyHostToDevice));
         EPH_HIP(hipMemcpy(e->ncoef.p, nc.data(), sizeof(int) * nc.size(), hipMemcpyHostToDevice));
+        e->host_coeffs = std::move(co);
         *out = e.release();
         return EPH_OK;
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
@@ -1642,7 +1816,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             (st = b->rk_i.alloc(nn)) || (st = b->steps.alloc(nn)) || (st = b->cur_seg.alloc(nn)) ||
             (st = b->status.alloc(nn)) || (st = b->nknots.alloc(nn)) || (st = b->seg_off.alloc(n + 1)) ||
             (st = b->segs.alloc(std::max<size_t>(segs.size(), 1))) || (st = b->knot_t.alloc(nn * max_knots)) ||
-            (st = b->knot_y.alloc(6 * nn * max_knots)) || (st = b->rk_dev.alloc(1)))
+            (st = b->knot_y.alloc(6 * nn * max_knots)) || (st = b->rk_dev.alloc(1)) || (st = b->queue.alloc(1)))
             return st;
         EPH_HIP(hipMemcpy(b->rk_dev.p, &b->rk, sizeof(ErkCoeffs), hipMemcpyHostToDevice));
         if (n > 0) {
@@ -1666,6 +1840,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             // knot 0 = the initial state (CubicHermiteSplineSolout::new_solution)
             EPH_HIP(hipMemcpy(b->knot_t.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
             EPH_HIP(hipMemcpy(b->knot_y.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+            b->heterogeneous = craft_time_scales_differ(*e, n, t0, pos);
         }
         *out = b.release();
         return EPH_OK;
@@ -1699,8 +1874,9 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
     a.fac = b->params.fac; a.n_max = b->params.n_max;
     a.t_end = t_end;
     a.step_limit = step_limit;
+    a.queue = b->queue.p;
     EPH_HIP(hipEventRecord(b->ev0, b->stream));
-    int st = craft_launch(b->stream, a);
+    int st = craft_launch(b->stream, a, b->heterogeneous);
     if (st) return st;
     if (b->events) {                                  // the app's SpacecraftSolout on the steps just taken
         EventArgs e{};
@@ -1752,6 +1928,39 @@ int32_t eph_craft_batch_state(eph_craft_batch *b, double *t, double *pos, double
                 if (vel) vel[3 * i + d] = y[(3 + d) * n + i];
             }
     }
+    return EPH_OK;
+}
+
+// one 80-byte record per craft from the SoA state arrays (coalesced reads, one record per thread written as ten 8-byte words)
+__global__ void __launch_bounds__(256) k_craft_summary(long long n, const double *__restrict__ time, const double *__restrict__ y,
+                                                       const double *__restrict__ next_h, const int *__restrict__ status,
+                                                       const int *__restrict__ nknots, const unsigned *__restrict__ attempts,
+                                                       const unsigned *__restrict__ steps, eph_craft_record *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    eph_craft_record r;
+    r.t = time[i];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { r.pos[d] = y[d * n + i]; r.vel[d] = y[(3 + d) * n + i]; }
+    r.next_h = next_h[i];
+    r.status = status[i];
+    r.nknots = nknots[i];
+    r.attempts = attempts[i];
+    r.steps = steps[i];
+    out[i] = r;
+}
+int32_t eph_craft_batch_summary(eph_craft_batch *b, eph_craft_record *out) {
+    if (!b || (b->n > 0 && !out)) return EPH_ERR_BAD_ARGUMENT;
+    if (b->n == 0) return EPH_OK;
+    EPH_HIP(hipSetDevice(b->device));
+    int st;
+    if ((st = b->summary.reserve((size_t)b->n))) return st;
+    hipLaunchKernelGGL(k_craft_summary, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->stream, b->n, b->time.p, b->y.p,
+                       b->next_h.p, b->status.p, b->nknots.p, b->n_attempts.p, b->steps.p, b->summary.p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error("k_craft_summary", e); return EPH_ERR_HIP; }
+    EPH_HIP(hipMemcpyAsync(out, b->summary.p, sizeof(eph_craft_record) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    EPH_HIP(hipStreamSynchronize(b->stream));
     return EPH_OK;
 }
 
@@ -1892,6 +2101,7 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
         std::unique_ptr<eph_craft_batch> c(new eph_craft_batch());
         c->eph = b->eph; c->device = b->device; c->n = b->n; c->max_knots = b->max_knots; c->rk = b->rk;
         c->params = b->params; c->events = b->events; c->max_tr = b->max_tr; c->max_ap = b->max_ap;
+        c->heterogeneous = b->heterogeneous;
         EPH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         EPH_HIP(hipEventCreate(&c->ev0));
         EPH_HIP(hipEventCreate(&c->ev1));
@@ -1909,7 +2119,8 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
             (st = clone_buf(b->ap_dist, c->ap_dist, s)) || (st = clone_buf(b->ev_seg, c->ev_seg, s)) ||
             (st = clone_buf(b->ntr, c->ntr, s)) || (st = clone_buf(b->nap, c->nap, s)) ||
             (st = clone_buf(b->ev_status, c->ev_status, s)) || (st = clone_buf(b->tr_body, c->tr_body, s)) ||
-            (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)))
+            (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)) ||
+            (st = c->queue.alloc(1)))
             return st;
         EPH_HIP(hipStreamSynchronize(s));
         *out = c.release();

@@ -50,7 +50,11 @@ def gather_craft_states(state, n_total, dist=None, device="cpu"):
     device="cuda" (56 B per craft: 56 MB for 1e6), gloo on CPU in the tests. `state` = SpacecraftBatch.state()."""
     import numpy as np
     import torch
-    mine = np.concatenate([state["t"][:, None], state["pos"], state["vel"]], axis=1)
+    if isinstance(state, np.ndarray) and state.dtype.names and state.dtype.itemsize == 80:
+        # SpacecraftBatch.summary(): t, pos, vel are the first seven doubles of every 80-byte record -- a view, no copy
+        mine = state.view(np.float64).reshape(-1, 10)[:, :7]
+    else:                                                          # the dict of arrays from SpacecraftBatch.state()
+        mine = np.concatenate([np.asarray(state["t"])[:, None], np.asarray(state["pos"]), np.asarray(state["vel"])], axis=1)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         assert len(mine) == n_total
         return mine
@@ -59,7 +63,7 @@ def gather_craft_states(state, n_total, dist=None, device="cpu"):
     lo, hi = shard_range(n_total, rank, world)
     assert hi - lo == len(mine)
     send = torch.zeros((width, 7), dtype=torch.float64, device=device)
-    send[: hi - lo] = torch.from_numpy(mine).to(device)
+    send[: hi - lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(device)
     recv = torch.empty((world * width, 7), dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(recv, send)
     recv = recv.cpu().numpy().reshape(world, width, 7)

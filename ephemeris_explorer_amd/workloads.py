@@ -60,3 +60,66 @@ def sha256_of(*arrays):
     for a in arrays:
         h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
     return h.hexdigest()
+
+
+def craft_population(kind, n, system, ship, seed=20260926, order="interleaved"):
+    """Initial states of n spacecraft for the massless sweep, at `ship.start` (the epoch of `system`, barycentric km, km/s).
+    kind "transfer": SURVEY 8(d)4 -- the Mars Transfer Ship's state perturbed by normal(0, 100 km / 0.01 km/s) per
+    component (every craft on the same heliocentric arc: equal work per craft).
+    kind "mixed": four orbit families around / away from the Earth in equal numbers, whose adaptive step sizes differ by
+    more than an order of magnitude -- low Earth orbit (6678 km circular), geostationary transfer (6678 x 42 164 km), lunar
+    transfer (6678 x 384 400 km), and a heliocentric cruise (the Earth's own orbit 60 +- 5 degrees ahead of it: days
+    per step); random orbital planes, perigee states.
+    order "interleaved": craft i belongs to family i % 4 (every wave of 64 holds all four: the worst case for a static
+    craft -> lane assignment); "blocked": families in four contiguous blocks. Returns (pos [n,3], vel [n,3], family [n])."""
+    rng = np.random.default_rng(seed)
+    tpos = ship.pos + rng.normal(0.0, 100.0, size=(n, 3))
+    tvel = ship.vel + rng.normal(0.0, 0.01, size=(n, 3))
+    if kind == "transfer":
+        return tpos, tvel, np.full(n, 3, dtype=np.int32)
+    if kind != "mixed":
+        raise ValueError(kind)
+    earth = system.names.index("Earth")
+    mu = system.mu[earth]
+    rp = 6678.0
+    apo = np.array([6678.0, 42164.0, 384400.0])
+    fam = (np.arange(n) % 4) if order == "interleaved" else (np.arange(n) * 4 // n)
+    fam = fam.astype(np.int32)
+    pos, vel = tpos.copy(), tvel.copy()
+    for f in range(3):
+        idx = np.nonzero(fam == f)[0]
+        m = len(idx)
+        a = 0.5 * (rp + apo[f])
+        vp = np.sqrt(mu * (2.0 / rp - 1.0 / a))
+        # random orthonormal pair (perigee direction, velocity direction)
+        u = rng.normal(size=(m, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        w = rng.normal(size=(m, 3))
+        w -= (w * u).sum(axis=1, keepdims=True) * u
+        w /= np.linalg.norm(w, axis=1, keepdims=True)
+        pos[idx] = system.pos[earth] + rp * u
+        vel[idx] = system.vel[earth] + vp * w
+    idx = np.nonzero(fam == 3)[0]
+    sun = system.names.index("Sun")
+    r, v = system.pos[earth] - system.pos[sun], system.vel[earth] - system.vel[sun]
+    axis = np.cross(r, v)
+    axis /= np.linalg.norm(axis)
+    ang = np.radians(rng.uniform(55.0, 65.0, len(idx)))[:, None]
+
+    def rot(x):                                            # Rodrigues rotation about the orbit normal
+        return x * np.cos(ang) + np.cross(axis, x) * np.sin(ang) + axis * (x @ axis) * (1.0 - np.cos(ang))
+
+    pos[idx] = system.pos[sun] + rot(r)
+    vel[idx] = system.vel[sun] + rot(v)
+    return pos, vel, fam
+
+
+def wave_divergence(attempts, wave=64):
+    """How unevenly the attempts of a sweep fall on the lanes of a wave when craft i runs on lane i % 64 of wave i // 64
+    for the whole sweep: per wave max / mean of the per-craft attempt counts, averaged over the waves weighted by their
+    cost (a wave runs as long as its slowest lane). 1.0 = no lane ever idles."""
+    a = np.asarray(attempts, dtype=np.float64)
+    pad = (-len(a)) % wave
+    a = np.concatenate([a, np.zeros(pad)]).reshape(-1, wave)
+    mx, mean = a.max(axis=1), a.sum(axis=1) / wave
+    return float(mx.sum() / max(mean.sum(), 1e-300))

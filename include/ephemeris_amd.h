@@ -276,6 +276,15 @@ int32_t eph_craft_batch_status(eph_craft_batch *b, int32_t *status, int32_t *nkn
                                uint32_t *steps);
 /* current problem state of every craft: time, position, velocity, next step size */
 int32_t eph_craft_batch_state(eph_craft_batch *b, double *t, double *pos_xyz, double *vel_xyz, double *next_h);
+/* Everything eph_craft_batch_status and eph_craft_batch_state return, as ONE record per craft packed on the device and
+ * brought over in one copy (a sweep of 1e5..1e6 craft reads its outcome this way: eight strided copies and their host
+ * transposes were a third of a sweep's wall time). out: n_craft records. */
+typedef struct eph_craft_record {
+    double t, pos[3], vel[3], next_h;
+    int32_t status, nknots;
+    uint32_t attempts, steps;
+} eph_craft_record;
+int32_t eph_craft_batch_summary(eph_craft_batch *b, eph_craft_record *out);
 /* the CubicHermiteSpline of one craft: nknots[craft] x (t, pos, vel) */
 int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, double *pos_xyz, double *vel_xyz);
 /* The app's solout, SpacecraftSolout (ephemeris_explorer/src/dynamics/spacecraft.rs:514-587): besides the knots,

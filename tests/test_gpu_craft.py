@@ -528,3 +528,71 @@ def test_single_steps(gpu, simple_system):
     for i, c in enumerate(cs):
         assert compare_knots(batch.knots(i), c.knots(), f"single steps, craft {i}")
     assert list(batch.status()["steps"]) == [65, 65]
+
+
+_QUEUE_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import ephemeris_explorer_amd as ea
+from ephemeris_explorer_amd.systems import load_system, load_ship
+from ephemeris_explorer_amd.workloads import craft_population
+root = sys.argv[1] + "/tests/golden/systems/full_solar_system_2433282.5"
+s = load_system(root)
+ship = load_ship(root + "/ships/Mars Transfer Ship.json")
+sol = ea.NBodyPropagator.from_system(s).propagate(s.epoch + 45 * 86400.0)
+eph = ea.Ephemeris(sol, s.mu)
+n = 6000
+pos, vel, fam = craft_population("mixed", n, s, ship)
+earth = s.names.index("Earth")
+burns = [[(ship.start + 3000.0, ship.start + 3090.0, [2e-4, 1e-4, 0.0], earth)] if i % 7 == 0 else [] for i in range(n)]
+b = ea.SpacecraftBatch(eph, ship.start, pos, vel, sys.argv[3], max_knots=4000, burns=burns)
+b.propagate(ship.start + 0.6 * 86400.0)           # two legs: the second resumes craft from stored state
+b.propagate(ship.start + 1.5 * 86400.0)
+rec = b.summary()
+kt, ky = b.knot_slabs(0, int(rec["nknots"].max()))
+for i in range(n):                                 # entries beyond a craft's knots are unspecified
+    kt[rec["nknots"][i]:, i] = 0.0
+    ky[rec["nknots"][i]:, :, i] = 0.0
+np.savez(sys.argv[2], rec=rec, kt=kt, ky=ky, pos=pos, vel=vel)
+'''
+
+
+@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "Fine45"])
+def test_queue_and_static_sweeps_give_the_same_bits(gpu, tmp_path, method):
+    """k_craft_queue (persistent grid, work queue, one attempt per iteration) against k_craft_propagate (craft i on
+    thread i) on a mixed population -- low orbits, transfer orbits, a heliocentric cruise, every seventh craft with a
+    burn in the Earth's TNB frame -- in two legs: every record and every knot identical, and a craft of each family
+    identical to the restatement."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    outs = []
+    for q in ("0", "1"):
+        out = tmp_path / f"q{q}.npz"
+        env = dict(os.environ, EPH_CRAFT_QUEUE=q, EPH_CRAFT_FORM="thread")
+        r = subprocess.run([sys.executable, "-c", _QUEUE_SCRIPT, str(ROOT), str(out), method], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert (a["rec"]["status"] == 0).all()
+    assert a["rec"].tobytes() == b["rec"].tobytes()
+    assert np.array_equal(a["kt"], b["kt"]) and np.array_equal(a["ky"], b["ky"])
+    steps = a["rec"]["steps"]
+    assert steps.max() > 8 * steps.min()                       # the population is what it claims to be
+    s = load_system("full_solar_system_2433282.5")
+    ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    assert o.step_to(s.epoch + 45 * 86400.0) == 0
+    osol = o.take_solution()
+    earth = s.names.index("Earth")
+    for i in (0, 1, 2, 3, 7):
+        burns = [(ship.start + 3000.0, ship.start + 3090.0, [2e-4, 1e-4, 0.0], earth)] if i % 7 == 0 else []
+        c = orc.Craft(osol, s.mu, ship.start, a["pos"][i], a["vel"][i], method, burns=burns)
+        assert c.step_to(ship.start + 0.6 * 86400.0) == 0 and c.step_to(ship.start + 1.5 * 86400.0) == 0
+        ot, op, ov = c.knots()
+        nk = a["rec"]["nknots"][i]
+        assert nk == len(ot)
+        assert np.array_equal(b["kt"][:nk, i], ot) and np.array_equal(b["ky"][:nk, :3, i], op) and np.array_equal(b["ky"][:nk, 3:, i], ov)
