@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
     "eph_nbody_enable_timing", "eph_nbody_sync", "eph_rccl_unique_id", "eph_nbody_shard", "eph_nbody_shard_info",
     "eph_prop_shard", "eph_peer_create", "eph_peer_handle", "eph_peer_connect", "eph_peer_destroy", "eph_nbody_shard_peer",
-    "eph_prop_shard_peer",
+    "eph_prop_shard_peer", "eph_nbody_advance_many", "eph_prop_step_n_many",
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
@@ -155,6 +155,8 @@ def _lib():
     L.eph_peer_destroy.argtypes = [vp]
     L.eph_nbody_shard_peer.argtypes = [vp, vp]
     L.eph_prop_shard_peer.argtypes = [vp, vp]
+    L.eph_nbody_advance_many.argtypes = [C.POINTER(vp), i32, i64]
+    L.eph_prop_step_n_many.argtypes = [C.POINTER(vp), i32, i64]
     L.eph_nbody_kernel_time.argtypes = [vp, _dp, C.POINTER(C.c_uint64)]
     L.eph_nbody_enable_timing.argtypes = [vp, i32]
     L.eph_nbody_sync.argtypes = [vp]
@@ -326,6 +328,22 @@ def _shard_call(fn, name, handle, rank, world, unique_id, exchange):
         uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
     _check(fn(handle, int(rank), int(world), uid, cb if cb else EXCHANGE_FN(0), None), name)
     return cb                                          # the caller keeps the trampoline alive with the handle
+
+
+def advance_many(integrations, n_steps):
+    """eph_nbody_advance_many: advance(n_steps) on every NBodyIntegration of the list, small systems in one launch."""
+    arr = (C.c_void_p * len(integrations))(*[g._h for g in integrations])
+    st = _check(_lib().eph_nbody_advance_many(arr, len(integrations), int(n_steps)), "eph_nbody_advance_many")
+    if st:
+        raise StepError(st)
+
+
+def step_n_many(propagators, n_steps):
+    """eph_prop_step_n_many: step_n(n_steps) on every NBodyPropagator of the list, small systems in shared launches."""
+    arr = (C.c_void_p * len(propagators))(*[p._h for p in propagators])
+    st = _check(_lib().eph_prop_step_n_many(arr, len(propagators), int(n_steps)), "eph_prop_step_n_many")
+    if st:
+        raise StepError(st)
 
 
 class PeerTransport:
@@ -909,6 +927,14 @@ def debug_div(a, b):
     fast, ieee = np.zeros_like(a), np.zeros_like(a)
     _check(_lib().eph_debug_div(a.size, _p(a), _p(b), _p(fast), _p(ieee)), "eph_debug_div")
     return fast, ieee
+
+
+def debug_wg_cycles():
+    """tuning hook: the eight debug counters the workgroup kernels leave (EPH_DEBUG_WG / EPH_DEBUG_SMALL)"""
+    out = (C.c_int64 * 8)()
+    _lib().eph_debug_wg_cycles.argtypes = [C.POINTER(C.c_int64)]
+    _check(_lib().eph_debug_wg_cycles(out), "eph_debug_wg_cycles")
+    return list(out)
 
 
 def debug_rsq(x):

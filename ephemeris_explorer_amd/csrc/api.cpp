@@ -146,6 +146,17 @@ int32_t eph_nbody_advance(eph_nbody *h, int64_t n_steps) {
     return h->p->advance(n_steps);
     EPH_GUARD_END
 }
+int32_t eph_nbody_advance_many(eph_nbody *const *handles, int32_t count, int64_t n_steps) {
+    EPH_GUARD_BEGIN
+    if (count < 0 || n_steps < 0 || (count > 0 && !handles)) return EPH_ERR_BAD_ARGUMENT;
+    std::vector<NBodyIntegration *> igs;
+    for (int32_t i = 0; i < count; ++i) {
+        if (!handles[i] || !handles[i]->p) return EPH_ERR_BAD_ARGUMENT;
+        igs.push_back(handles[i]->p);
+    }
+    return NBodyIntegration::advance_many(igs.data(), count, n_steps);
+    EPH_GUARD_END
+}
 int32_t eph_nbody_get_state(eph_nbody *h, double *pos, double *vel, double *t, uint32_t *sc) {
     EPH_GUARD_BEGIN
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
@@ -322,6 +333,17 @@ int32_t eph_prop_step_n(eph_prop *p, int64_t n) {
     EPH_GUARD_BEGIN
     if (!p || n < 0) return EPH_ERR_BAD_ARGUMENT;
     return p->p->step_n(n);
+    EPH_GUARD_END
+}
+int32_t eph_prop_step_n_many(eph_prop *const *props, int32_t count, int64_t n) {
+    EPH_GUARD_BEGIN
+    if (count < 0 || n < 0 || (count > 0 && !props)) return EPH_ERR_BAD_ARGUMENT;
+    std::vector<NBodyPropagator *> ps;
+    for (int32_t i = 0; i < count; ++i) {
+        if (!props[i] || !props[i]->p) return EPH_ERR_BAD_ARGUMENT;
+        ps.push_back(props[i]->p.get());
+    }
+    return NBodyPropagator::step_n_many(ps.data(), count, n);
     EPH_GUARD_END
 }
 int32_t eph_prop_step_to(eph_prop *p, double t) {

@@ -107,6 +107,9 @@ int launch_kick_drift(hipStream_t s, int n, int npad, const double *a, double *v
 int launch_lm_predict(hipStream_t s, const LmArgs &a);              // y_{m+1} from the ring (no force)
 int launch_lm_step(hipStream_t s, const LmArgs &a);                 // one fused step, all CUs
 int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps);
+// `count` single-workgroup systems (n <= kGangMaxN each, same L), one workgroup each, argv in device memory
+constexpr int kGangMaxN = 32;
+int launch_lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);
 // opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
 int fast_slices(int npad);                                          // S
 int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial /*[S][3][npad]*/, bool approx_rsq = false);  // n <= 64: nsteps steps, one workgroup

@@ -156,6 +156,11 @@ public:
     uint64_t kernel_launches() const { return kernel_launches_; }
     // how many of the next k advance() calls would succeed before BoundReached / StepSizeUnderflow
     int64_t steps_available(int64_t k, int *status_after) const;
+    // `count` independent single-workgroup systems advanced by k steps in ONE launch (k_lm_small, one workgroup each):
+    // the same as advance(k) on every one of them. Systems that do not qualify (start-up not finished, more than
+    // kGangMaxN bodies, sharded, a forced kernel path, a step that would fail) make the call fall back to that.
+    static int advance_many(NBodyIntegration *const *igs, int count, int64_t k);
+    bool gang_ready(int64_t k) const;
 
 private:
     NBodyIntegration() = default;
@@ -192,6 +197,9 @@ private:
     DevBuf<Body4> P_[2];
     DevBuf<double> Y_, A_, V_, ASR_, mu_, stage_;
     DevBuf<double> fast_partial_;             // EPH_PATH_FAST scratch: [S][3][npad] partial sums
+    std::vector<LmArgs> *collect_ = nullptr;  // advance_many: lm_batch hands its launch arguments over instead of launching
+    DevBuf<LmArgs> gang_args_;                // advance_many: the argument array of the gang this handle leads
+    hipEvent_t gang_ev_ = nullptr;
 };
 
 // Polynomial<DVec3> (SmallVec<[DVec3; 8]>)   ephemeris/src/trajectory.rs:337-396
@@ -279,6 +287,8 @@ public:
                       std::unique_ptr<NBodyPropagator> *out);
     int clone(std::unique_ptr<NBodyPropagator> *out);
     int step_n(int64_t k);                    // k x IncrementalPropagator::step
+    // step_n(k) on every propagator of `ps`, the steady-state steps of all of them in shared launches (advance_many)
+    static int step_n_many(NBodyPropagator *const *ps, int count, int64_t k);
     int step_to(double t);
     // ONE IncrementalPropagator::step, executed lazily: the reference's callers step in a loop and look at time() /
     // has_reached() after every step (ephemeris_explorer/src/prediction.rs:422-443). Everything those two return is a
@@ -300,6 +310,7 @@ private:
     NBodyPropagator() = default;
     Solution new_solution() const;
     int run_batch(int64_t k);
+    int batch_begin();                         // run_batch up to the integrator's advance: sampling schedule on the device
     int64_t steps_until_reached(double t, int64_t cap) const;
     double bound_of(const UniformSpline &s) const { return direction_ > 0 ? s.end() : s.start; }
     int ensure_log_capacity(const std::vector<uint64_t> &need);

@@ -1371,13 +1371,48 @@ __device__ __forceinline__ void small_steps(Step &step, long long &s, long long 
                                               rot = (L - Ks + L - 1) % L, more = ++s <= nsteps, 0)
                                            : 0)...};
 }
-constexpr int kSmallMaxN = 40;           // two zero-padded contribution arrays must fit 160 KiB of LDS
-constexpr int kSmallRow = 48 + 2;        // doubles per row (n <= 40 -> 48 walked): 16-byte aligned, conflict-free
-template <int L>
-__global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nsteps) {
-    __shared__ __attribute__((aligned(16))) double U[3 * kSmallMaxN][kSmallRow];    // [body*3 + comp][source]
-    __shared__ __attribute__((aligned(16))) double Lw[3 * kSmallMaxN][kSmallRow];
+constexpr int kSmallMaxN = 32;           // bodies (the reference's shipped system has exactly 32); 33..64 -> k_lm_persistent
+constexpr int kSmallRow = 32 + 2;        // doubles per row: 16-byte aligned rows an odd number of 16-byte units apart
+constexpr int kSmallRows = 3 * kSmallMaxN;
+// -DEPH_SMALL_ACCOUNT=1 (tuning build, scripts/build_exp.sh): thread 0 of k_lm_small accumulates shader-clock ticks per phase
+// of a step into g_wg_cycles[3..7] (wait at barrier A | sum1 + pair | wait at barrier B | row sums | sum2 + hand-over)
+#ifndef EPH_SMALL_ACCOUNT
+#define EPH_SMALL_ACCOUNT 0
+#endif
+#define SMALL_TICK(k) do { if constexpr (EPH_SMALL_ACCOUNT) { const long long now_ = (long long)__builtin_readcyclecounter(); acct[k] += now_ - acct_t; acct_t = now_; } } while (0)
+// the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2] on both halves of the double)
+__device__ __forceinline__ double dpp_xor1(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+    const int h2 = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(h2, l2);
+}
+// A workgroup-wide barrier for LDS hand-offs only: __syncthreads() also waits for every outstanding GLOBAL access
+// (vmcnt(0)) -- the solout's sample stores would stall all eight waves for a memory round trip at every sampled step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// k_lm_small, round 3. The per-phase tick accounting of round 2's kernel (thread 0, 32 bodies, 2125 ticks per step:
+// wait 124 | sum1 + pair 802 | wait 183 | row sums 643 | sum2 + hand-over 373) and its ISA showed:
+//   * the partner exchange of the two half sums was a ds_bpermute -- an LDS round trip between two dependent chains;
+//   * the position half of the predictor (sum1) and the pair arithmetic sat in separate exec-masked regions, executed one
+//     after the other instead of interleaved -- and once that was fixed in the source the compiler SANK sum1 back behind
+//     the force (its only user is there), so it is pinned where it is computed;
+//   * Cowell's velocity was formed at every step although nothing reads it before the launch ends;
+//   * __syncthreads() waited for the solout's global stores as well.
+// Built and measured on the way (gpurun_out r03, scripts/clock_small.py): contributions of both directions stored in one
+// orientation ([i][c][j], rows of 49 doubles: conflict-free writes), the "before" chains walking columns through 32
+// per-lane LDS addresses with everything outside a chain's range redirected to one shared zero -- SLOWER, 0.87 vs 0.80
+// us per step: 32 ds_read_b64 per chain thread cost the workgroup's one LDS pipe more than 16 ds_read_b128 of half
+// padding, and the transposed writes it removed were not what the pair phase waits for.
+// MULTI: one workgroup per SYSTEM, its arguments argv[blockIdx.x] (eph_nbody_advance_many / eph_prop_step_n_many: the
+// app runs a forward and a backward propagator concurrently, ephemeris_explorer/src/load/mod.rs:673-687, and ensembles
+// are independent too): K latency-bound single-workgroup systems advance in the time of one.
+template <int L, bool MULTI>
+__global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs *__restrict__ argv, long long nsteps) {
+    __shared__ __attribute__((aligned(16))) double U[kSmallRows][kSmallRow];    // [body*3 + comp][source]: sources after the body
+    __shared__ __attribute__((aligned(16))) double Lw[kSmallRows][kSmallRow];   //                        sources before the body
     __shared__ __attribute__((aligned(32))) Body4 sP[kTile];
+    const LmArgs &a = MULTI ? argv[blockIdx.x] : a0;
 
     const int tid = threadIdx.x, n = a.n;
     // chain threads: tid = (body*3 + comp)*2 + half   (half 0 = sources before, 1 = sources after)
@@ -1388,69 +1423,76 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + my_i;
     const int npairs = n * (n - 1) / 2;
-    const int nrow = (n + 15) & ~15;   // row length the chains walk (the padding holds zeros)
+    const int wg_flags = a.wg_flags;
 
-    for (int k = tid; k < 3 * kSmallMaxN * kSmallRow; k += blockDim.x) { (&U[0][0])[k] = 0.0; (&Lw[0][0])[k] = 0.0; }
+    const int nrow = (n + 15) & ~15;   // row length the chains walk (the padding holds zeros)
+    for (int k = tid; k < kSmallRows * kSmallRow; k += blockDim.x) { (&U[0][0])[k] = 0.0; (&Lw[0][0])[k] = 0.0; }
     if (tid < kTile) sP[tid] = a.pos_cur[tid < n ? tid : n - 1];
     // history and coefficients live in VGPRs for the whole launch: yv[j] / av[j] = level (newest - j).
     // (Kernel arguments would otherwise be re-fetched through the scalar cache every step.)
-    double yv[L], av[L], wa[L], wb[L], cw[L];
+    double yv[L], av[L], wa[L], wb[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const int slot = (a.cur + j) % L;
         yv[j] = a.Y[slot * lvl + off];
         av[j] = a.A[slot * lvl + off];
-        wa[j] = a.wa[j]; wb[j] = a.wb[j]; cw[j] = a.cw[j];
-        asm volatile("" : "+v"(wa[j]), "+v"(wb[j]), "+v"(cw[j]));
+        wa[j] = a.wa[j]; wb[j] = a.wb[j];
+        asm volatile("" : "+v"(wa[j]), "+v"(wb[j]));
     }
-    double hh = a.hh, hc = a.hc, h = a.h;
-    asm volatile("" : "+v"(hh), "+v"(hc), "+v"(h));
+    double hh = a.hh;
+    asm volatile("" : "+v"(hh));
     double v = owner ? a.V[off] : 0.0;
     // solout sampling schedule of this thread's body, read once (maybe_sample would fetch it every step)
     // (a countdown instead of `(phase + s) % period` every step: samples fall on the steps where phase + s is a
     // multiple of the period, the q-th of them into slot offset + q)
     uint32_t samp_m = 0, samp_left = 0;
     uint64_t samp_slot = 0;
+    double *samp_log = a.samp.log;
     if (owner && a.samp.period) {
         samp_m = a.samp.period[my_i];
         samp_left = samp_m ? samp_m - a.samp.phase[my_i] % samp_m : 0;
         samp_slot = a.samp.offset[my_i];
     }
-    // this thread's unordered pairs (i < j), row-major over the strict upper triangle, 2 per thread at most for
-    // n <= 40 (780 pairs over 512 threads): decode once
-    int pi0 = -1, pj0 = 0, pi1 = -1, pj1 = 0;
-    for (int q = 0; q < 2; ++q) {
-        const int p = tid + q * (int)blockDim.x;
-        if (p < npairs) {
-            int i = 0;
-            while ((i + 1) * (2 * n - i - 2) / 2 <= p) ++i;
-            const int j = i + 1 + (p - i * (2 * n - i - 1) / 2);
-            if (q == 0) { pi0 = i; pj0 = j; } else { pi1 = i; pj1 = j; }
-        }
+    // this thread's unordered pair (i < j), row-major over the strict upper triangle (n <= 32: at most 496 pairs for 512
+    // threads), decoded once. A thread without one runs pair (0, 1) again and stores nothing: straight-line code.
+    int pi0 = 0, pj0 = 1;
+    const bool live0 = tid < npairs && !(wg_flags & 1);    // (wg_flags: tuning switches, EPH_DEBUG_SMALL; 0 in normal runs)
+    if (tid < npairs) {
+        int i = 0;
+        while ((i + 1) * (2 * n - i - 2) / 2 <= tid) ++i;
+        pi0 = i;
+        pj0 = i + 1 + (tid - i * (2 * n - i - 1) / 2);
     }
     __syncthreads();
 
-    auto pair = [&](int i, int j) {
-        const Body4 bi = sP[i], bj = sP[j];
-        const double dx = bj.x - bi.x, dy = bj.y - bi.y, dz = bj.z - bi.z;
+    // Every thread runs the pair arithmetic: straight-line code, so the scheduler interleaves it with the predictor's
+    // position chain (sum1) instead of executing one exec-masked region after the other. The wrapper-free sqrt /
+    // reciprocal sequences run first and unconditionally; the range test that validates them (device_math.h) is decided
+    // behind them, where the branch no longer stalls the wave, and an out-of-range operand anywhere in the wave redoes
+    // the term in the full IEEE form.
+    auto pair = [&]() {
+        const double4 vi = *reinterpret_cast<const double4 *>(&sP[pi0]), vj = *reinterpret_cast<const double4 *>(&sP[pj0]);
+        const double dx = vj.x - vi.x, dy = vj.y - vi.y, dz = vj.z - vi.z;
         const double n2 = dx * dx + dy * dy + dz * dz;
-        // IEEE sqrt and divide; the wrapper-free sequences when every lane's operand is in range (device_math.h)
         double ax, ay, az, bx, by, bz;
-        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) {
+        {
             const PairDen den = pair_den<true>(n2);
-            pair_apply<true>(den, dx, dy, dz, bj.mu, ax, ay, az);
-            pair_apply<true>(den, -dx, -dy, -dz, bi.mu, bx, by, bz);
-        } else {
-            const PairDen den = pair_den<false>(n2);
-            pair_apply<false>(den, dx, dy, dz, bj.mu, ax, ay, az);
-            pair_apply<false>(den, -dx, -dy, -dz, bi.mu, bx, by, bz);
+            pair_apply<true>(den, dx, dy, dz, vj.w, ax, ay, az);
+            pair_apply<true>(den, -dx, -dy, -dz, vi.w, bx, by, bz);
         }
-        U[i * 3 + 0][j] = ax;
-        U[i * 3 + 1][j] = ay;
-        U[i * 3 + 2][j] = az;
-        Lw[j * 3 + 0][i] = bx;
-        Lw[j * 3 + 1][i] = by;
-        Lw[j * 3 + 2][i] = bz;
+        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) != 0) {
+            const PairDen den = pair_den<false>(n2);
+            pair_apply<false>(den, dx, dy, dz, vj.w, ax, ay, az);
+            pair_apply<false>(den, -dx, -dy, -dz, vi.w, bx, by, bz);
+        }
+        if (live0) {
+            U[pi0 * 3 + 0][pj0] = ax;
+            U[pi0 * 3 + 1][pj0] = ay;
+            U[pi0 * 3 + 2][pj0] = az;
+            Lw[pj0 * 3 + 0][pi0] = bx;
+            Lw[pj0 * 3 + 1][pi0] = by;
+            Lw[pj0 * 3 + 2][pi0] = bz;
+        }
     };
 
     // ---- predictor (ELM2::advance) of the first step, in the (body, comp) threads
@@ -1462,65 +1504,106 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a, long long nste
     // One step with the history ring at rotation R: level (newest - j) lives in yv[(R + j) % L]. The new level
     // overwrites the oldest in place, so the ring never moves through registers; the step loop is unrolled over
     // the L rotations (R is a compile-time constant in each copy).
+    // What is NOT done every step: Cowell's velocity (cowell.rs:17-53). The recurrence never reads it -- only
+    // get_state / a clone / the next launch do -- so it is formed once, for the last level of the launch, from the same
+    // twelve accelerations and two positions the reference would have used at that step: the same bits, eleven
+    // multiply-adds per component and step less in the threads every barrier waits for.
+    long long acct[5] = {0, 0, 0, 0, 0}, acct_t = EPH_SMALL_ACCOUNT ? (long long)__builtin_readcyclecounter() : 0;
     auto step = [&](auto rc, long long s) {
         constexpr int R = decltype(rc)::value;
         constexpr int Rn = (R + L - 1) % L;            // slot of the oldest level = slot of the level being built
-        __syncthreads();   // positions of the new level visible
+        lds_barrier();     // positions of the new level visible
+        SMALL_TICK(0);
+        // ---- the position half of the NEXT level's predictor (sum1 of ELM2::advance): it needs this level's position,
+        // not its acceleration, so its chain of dependent adds runs here, interleaved with the pair arithmetic below
+        // instead of behind the force where everybody waits for it (every thread: non-owners carry junk, unused)
+        // (all the products first, then the dependent adds: a v_mul_f64 issued right in front of the v_add_f64 that needs it
+        // costs the chain its full latency every term -- measured ~25 cycles per term instead of ~8.4, 330 cycles for the
+        // twelve terms behind the force. The eleven products of the acceleration half that do not involve the new
+        // acceleration are formed here too.)
+        double p1[L], q2[L];
+        p1[0] = ynew * wa[0];
+#pragma unroll
+        for (int j = 1; j < L; ++j) { p1[j] = yv[(R + j - 1) % L] * wa[j]; q2[j] = av[(R + j - 1) % L] * wb[j]; }
+        __builtin_amdgcn_sched_barrier(0);
+        double s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) s1 = s1 + p1[j];
         // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
-        if (!(a.wg_flags & 1)) {                       // (wg_flags: tuning switches, EPH_DEBUG_SMALL; 0 in normal runs)
-            if (pi0 >= 0) pair(pi0, pj0);
-            if (pi1 >= 0) pair(pi1, pj1);
-        }
-        __syncthreads();   // contributions visible
-        // ---- ordered chains: plain in-order sums over the rows (zeros outside each chain's range)
+        pair();
+        asm volatile("" : "+v"(s1));                   // computed HERE (the compiler would sink it behind the force)
+#pragma unroll
+        for (int j = 1; j < L; ++j) asm volatile("" : "+v"(q2[j]));
+        if constexpr (EPH_SMALL_ACCOUNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SMALL_TICK(1);
+        lds_barrier();     // contributions visible
+        SMALL_TICK(2);
+        // ---- ordered chains: plain in-order sums over the rows (zeros outside each chain's range; adding +0.0 is exact and
+        // the sums never are -0.0), every read in flight before the first add
         double acc = 0.0;
-        if (chain_thread && !(a.wg_flags & 2)) {
+        if (chain_thread && !(wg_flags & 2)) {
             const double *row = half ? &U[chain][0] : &Lw[chain][0];
-            for (int c = 0; c < nrow; c += 16) {
-                double2 r[8];
+            auto sum_blocks = [&](auto nb) {
+                constexpr int NB = decltype(nb)::value;
+                double2 r[8 * NB];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const double2 *>(row + c + 2 * k);
+                for (int k = 0; k < 8 * NB; ++k) r[k] = *reinterpret_cast<const double2 *>(row + 2 * k);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 8 * NB; ++k) {
                     acc = acc + r[k].x;
                     acc = acc + r[k].y;
                 }
-            }
+            };
+            if (nrow == 16) sum_blocks(std::integral_constant<int, 1>{});
+            else sum_blocks(std::integral_constant<int, 2>{});
         }
-        const double other = __shfl_xor(acc, 1);          // the partner half (adjacent lane, same wave)
+        // the partner half sits in the adjacent lane: a DPP quad permutation, not an LDS round trip (ds_bpermute)
+        const double other = dpp_xor1(acc);
+        if constexpr (EPH_SMALL_ACCOUNT) asm volatile("" :: "v"(other));
+        SMALL_TICK(3);
         if (owner) {
             const double anew = acc + other;               // ddy[i] (lower sum) += output_i (upper sum)
-            double yl[L], al[L];                           // the levels before this step, newest first
+            // the acceleration half of the predictor (sum2), the only chain behind the force
+            double s2 = 0.0;
+            s2 = s2 + anew * wb[0];
 #pragma unroll
-            for (int j = 0; j < L; ++j) { yl[j] = yv[(R + j) % L]; al[j] = av[(R + j) % L]; }
-            // Cowell velocity of this level and the predictor of the NEXT level are independent dependent-add
-            // chains over the same history: issued together so each fills the other's issue gaps; the predictor's
-            // result is what the other waves wait for at the barrier
-            double y2[L], a2[L];
-            y2[0] = ynew;
-            a2[0] = anew;
-#pragma unroll
-            for (int j = 1; j < L; ++j) { y2[j] = yl[j - 1]; a2[j] = al[j - 1]; }
-            const double ynext = lm_predict<L>(y2, a2, wa, wb, hh);
+            for (int j = 1; j < L; ++j) s2 = s2 + q2[j];
+            const double ynext = s1 + s2 * hh;             // *y = *sum1 + *sum2 * (h * h * Ratio::from_recip(BETA_D))
             if (s < nsteps) reinterpret_cast<double *>(&sP[my_i])[cc] = ynext;
-            v = lm_cowell<L>(anew, al, ynew, yl[0], cw, h, hc);
             if (samp_m && --samp_left == 0) {              // SplineInterpolators::solout_with  nbody.rs:389-397
-                a.samp.log[samp_slot * 3 + cc] = ynew;
+                samp_log[samp_slot * 3 + cc] = ynew;
                 samp_slot += 1;
                 samp_left = samp_m;
+            }
+            if (s == nsteps) {                             // Cowell::update_velocity of the launch's last level
+                double al[L], cw[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) { al[j] = av[(R + j) % L]; cw[j] = a.cw[j]; }
+                v = lm_cowell<L>(anew, al, ynew, yv[R], cw, a.h, a.hc);
             }
             yv[Rn] = ynew;
             av[Rn] = anew;
             ynew = ynext;
         }
+        if constexpr (EPH_SMALL_ACCOUNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SMALL_TICK(4);
         // the predictor writes sP after every pair thread of this step passed the barrier above; U / Lw are
         // rewritten only after the next "positions visible" barrier
     };
     int rot = 0;                                       // rotation after the steps taken so far
+    const long long dbg_c0 = (wg_flags & 4) ? (long long)__builtin_readcyclecounter() : 0;
+    const long long dbg_w0 = (wg_flags & 4) ? (long long)wall_clock64() : 0;
     {
         long long s = 1;
         bool more = nsteps >= 1;
         while (more) small_steps(step, s, nsteps, rot, more, std::make_integer_sequence<int, L>{});
+    }
+    if ((wg_flags & 4) && tid == 0 && blockIdx.x == 0) {   // tuning (EPH_DEBUG_SMALL=4): shader-clock ticks, 100 MHz ticks, steps
+        g_wg_cycles[0] = (long long)__builtin_readcyclecounter() - dbg_c0;
+        g_wg_cycles[1] = (long long)wall_clock64() - dbg_w0;
+        g_wg_cycles[2] = nsteps;
+        if constexpr (EPH_SMALL_ACCOUNT)
+            for (int q = 0; q < 5; ++q) g_wg_cycles[3 + q] = acct[q];
     }
 
     if (owner) {
@@ -1941,11 +2024,7 @@ static int launch_lm_persistent_L(hipStream_t s, const LmArgs &a, int64_t nsteps
         static const int dbg = [] { const char *e = getenv("EPH_DEBUG_SMALL"); return e ? atoi(e) : 0; }();
         LmArgs b = a;
         b.wg_flags = dbg;                              // 1: no pair stage, 2: no chain stage (timing breakdown only)
-        hipLaunchKernelGGL(k_lm_small<L>, dim3(1), dim3(512), 0, s, b, (long long)nsteps);
-        return done("k_lm_small");
-    }
-    if (false) {
-        hipLaunchKernelGGL(k_lm_small<L>, dim3(1), dim3(512), 0, s, a, (long long)nsteps);
+        hipLaunchKernelGGL((k_lm_small<L, false>), dim3(1), dim3(512), 0, s, b, (const LmArgs *)nullptr, (long long)nsteps);
         return done("k_lm_small");
     }
     const int per_wave = (a.n + 7) / 8;
@@ -1962,6 +2041,16 @@ int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps) {
     if (a.L == 12) return launch_lm_persistent_L<12>(s, a, nsteps);
     if (a.L == 13) return launch_lm_persistent_L<13>(s, a, nsteps);
     return EPH_ERR_UNSUPPORTED;
+}
+
+int launch_lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps) {
+    static_assert(kGangMaxN == kSmallMaxN, "the gang launch is k_lm_small's");
+    if (count <= 0 || nsteps <= 0) return EPH_OK;
+    const LmArgs none{};
+    if (L == 12) hipLaunchKernelGGL((k_lm_small<12, true>), dim3((unsigned)count), dim3(512), 0, s, none, argv_dev, (long long)nsteps);
+    else if (L == 13) hipLaunchKernelGGL((k_lm_small<13, true>), dim3((unsigned)count), dim3(512), 0, s, none, argv_dev, (long long)nsteps);
+    else return EPH_ERR_UNSUPPORTED;
+    return done("k_lm_small (gang)");
 }
 
 int launch_pack(hipStream_t s, int n, int npad, const double *Yslot, const double *mu, Body4 *pos) {

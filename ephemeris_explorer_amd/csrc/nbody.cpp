@@ -20,6 +20,7 @@ NBodyIntegration::~NBodyIntegration() {
         (void)hipStreamSynchronize(stream_);
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
+        if (gang_ev_) (void)hipEventDestroy(gang_ev_);
         (void)hipStreamDestroy(stream_);
     }
 }
@@ -232,12 +233,14 @@ int NBodyIntegration::lm_batch(int64_t k) {
     }
     const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3 && !fast;
     if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
-    if (timing_) EPH_HIP(hipEventRecord(ev0_, stream_));
+    if (collect_ && !persistent) return EPH_ERR_UNSUPPORTED;           // (advance_many checks gang_ready first)
+    if (timing_ && !collect_) EPH_HIP(hipEventRecord(ev0_, stream_));
     if (persistent) {
         a.cur = cur_;
         a.pos_cur = P_[pp_].p;
         a.pos_next = P_[pp_ ^ 1].p;
-        if ((st = launch_lm_persistent(stream_, a, k))) return st;
+        if (collect_) collect_->push_back(a);                           // launched by advance_many with the gang's others
+        else if ((st = launch_lm_persistent(stream_, a, k))) return st;
         cur_ = (int)(((int64_t)cur_ - k % L_ + L_) % L_);
         if (timing_) kernel_launches_ += 1;
     } else {
@@ -260,7 +263,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
         }
         if (timing_) kernel_launches_ += (uint64_t)k;
     }
-    if (timing_) {
+    if (timing_ && !collect_) {
         EPH_HIP(hipEventRecord(ev1_, stream_));
         EPH_HIP(hipEventSynchronize(ev1_));
         float ms = 0;
@@ -320,6 +323,68 @@ int NBodyIntegration::advance(int64_t n_steps, int64_t *done_out) {
     samp_ = SampleArgs{};
     if (done_out) *done_out = done;
     return st;
+}
+
+bool NBodyIntegration::gang_ready(int64_t k) const {
+    if (!is_multistep_ || !started() || sharded() || n_ > kGangMaxN || n_ <= 0 || (path_ != 0 && path_ != 2)) return false;
+    if (k <= 0 || k > ((int64_t)1 << 30)) return false;
+    int after = EPH_OK;
+    return steps_available(k, &after) == k;
+}
+
+int NBodyIntegration::advance_many(NBodyIntegration *const *igs, int count, int64_t k) {
+    if (count < 0 || (count > 0 && !igs) || k < 0) return EPH_ERR_BAD_ARGUMENT;
+    if (count == 0 || k == 0) return EPH_OK;
+    bool gang = count > 1;
+    for (int i = 0; i < count && gang; ++i)
+        gang = igs[i] && igs[i]->gang_ready(k) && igs[i]->device_ == igs[0]->device_ && igs[i]->L_ == igs[0]->L_;
+    for (int i = 0; i < count; ++i) {
+        if (!igs[i]) return EPH_ERR_BAD_ARGUMENT;
+        for (int j = 0; j < i; ++j)
+            if (igs[j] == igs[i]) return EPH_ERR_BAD_ARGUMENT;          // a system cannot be in the gang twice
+    }
+    if (!gang) {                                                        // the plain meaning: advance(k) on each
+        int first = EPH_OK;
+        for (int i = 0; i < count; ++i) {
+            const int st = igs[i]->advance(k);
+            if (st && !first) first = st;
+        }
+        return first;
+    }
+    NBodyIntegration &lead = *igs[0];
+    EPH_HIP(hipSetDevice(lead.device_));
+    std::vector<LmArgs> args;
+    args.reserve((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        NBodyIntegration &ig = *igs[i];
+        ig.collect_ = &args;
+        int64_t done = 0;
+        const int st = ig.advance(k, &done);                            // bookkeeping as usual, launch arguments into `args`
+        ig.collect_ = nullptr;
+        if (st || done != k || args.size() != (size_t)i + 1) return st ? st : EPH_ERR_HIP;
+    }
+    int st;
+    if ((st = lead.gang_args_.reserve((size_t)count))) return st;
+    if (!lead.gang_ev_) EPH_HIP(hipEventCreateWithFlags(&lead.gang_ev_, hipEventDisableTiming));
+    // the gang's launch goes on the lead's stream, behind whatever the other handles still have in flight on theirs
+    for (int i = 1; i < count; ++i) {
+        EPH_HIP(hipEventRecord(lead.gang_ev_, igs[i]->stream_));
+        EPH_HIP(hipStreamWaitEvent(lead.stream_, lead.gang_ev_, 0));
+    }
+    EPH_HIP(hipMemcpyAsync(lead.gang_args_.p, args.data(), sizeof(LmArgs) * (size_t)count, hipMemcpyHostToDevice, lead.stream_));
+    if (lead.timing_) EPH_HIP(hipEventRecord(lead.ev0_, lead.stream_));
+    if ((st = launch_lm_small_many(lead.stream_, lead.gang_args_.p, count, lead.L_, k))) return st;
+    if (lead.timing_) {
+        EPH_HIP(hipEventRecord(lead.ev1_, lead.stream_));
+        EPH_HIP(hipEventSynchronize(lead.ev1_));
+        float ms = 0;
+        EPH_HIP(hipEventElapsedTime(&ms, lead.ev0_, lead.ev1_));
+        lead.kernel_ms_ += ms;
+    }
+    EPH_HIP(hipEventRecord(lead.gang_ev_, lead.stream_));
+    for (int i = 1; i < count; ++i) EPH_HIP(hipStreamWaitEvent(igs[i]->stream_, lead.gang_ev_, 0));
+    EPH_HIP(hipStreamSynchronize(lead.stream_));                        // `args` (pageable) must outlive the copy
+    return EPH_OK;
 }
 
 int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *sc) {

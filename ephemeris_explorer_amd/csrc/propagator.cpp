@@ -203,8 +203,9 @@ int NBodyPropagator::materialize() {
     return EPH_OK;
 }
 
-// One device batch of k integrator steps + solout   (k x [Integration::advance -> Solout::solout], lib.rs:379-391)
-int NBodyPropagator::run_batch(int64_t k) {
+// One device batch of k integrator steps + solout   (k x [Integration::advance -> Solout::solout], lib.rs:379-391):
+// batch_begin puts the sampling schedule of the batch on the device, the integrator advances, fit_and_push does the rest.
+int NBodyPropagator::batch_begin() {
     if (failed_) return failed_;
     const int n = (int)interp_.size();
     NBodyIntegration &ig = *integ_;
@@ -223,14 +224,76 @@ int NBodyPropagator::run_batch(int64_t k) {
     }
     SampleArgs sa{d_period_.p, d_phase_.p, d_offset_.p, log_.p};
     ig.set_sampling(sa);
+    return EPH_OK;
+}
+int NBodyPropagator::run_batch(int64_t k) {
+    int st = batch_begin();
+    if (st) return st;
+    NBodyIntegration &ig = *integ_;
     int64_t done = 0;
     const int st_adv = ig.advance(k, &done);
     // From here on the integrator has moved: a failure between now and the push of the fitted polynomials would
     // leave counters, sample log and solution out of step with it, so it is made sticky -- every later step /
     // step_to / take_solution / clone returns the same error instead of a spline with a missing segment.
-    const int st_fit = fit_and_push(done, s);
+    const int st_fit = fit_and_push(done, ig.stream());
     if (st_fit) return failed_ = st_fit;
     return st_adv;
+}
+
+// step_n(k) on several propagators at once. Start-up steps (and anything else advance_many would not take) run per
+// propagator as usual; the steady-state steps of all of them share launches: every propagator still has `rem` steps to
+// go, the gang advances min(rem, kmax) of them in ONE k_lm_small launch with a workgroup per system, then each fits and
+// pushes its own windows. Results are those of step_n(k) on each.
+int NBodyPropagator::step_n_many(NBodyPropagator *const *ps, int count, int64_t k) {
+    if (count < 0 || (count > 0 && !ps) || k < 0) return EPH_ERR_BAD_ARGUMENT;
+    std::vector<int64_t> rem((size_t)count, k);
+    for (int i = 0; i < count; ++i) {
+        if (!ps[i]) return EPH_ERR_BAD_ARGUMENT;
+        for (int j = 0; j < i; ++j)
+            if (ps[j] == ps[i]) return EPH_ERR_BAD_ARGUMENT;
+        NBodyPropagator &p = *ps[i];
+        if (p.failed_) return p.failed_;
+        if (p.deferred_) { const int st = p.flush(); if (st) return st; }
+        while (rem[i] > 0 && !p.integ_->started()) {                 // start-up: one macro step at a time, as step_n does
+            const int st = p.run_batch(1);
+            if (st) return st;
+            rem[i] -= 1;
+        }
+    }
+    std::vector<NBodyPropagator *> act;
+    std::vector<NBodyIntegration *> igs;
+    for (;;) {
+        act.clear();
+        int64_t chunk = INT64_MAX;
+        for (int i = 0; i < count; ++i)
+            if (rem[i] > 0) { act.push_back(ps[i]); chunk = std::min(chunk, std::min(rem[i], ps[i]->kmax_)); }
+        if (act.empty()) return EPH_OK;
+        bool gang = act.size() > 1;
+        for (NBodyPropagator *p : act) gang = gang && p->integ_->gang_ready(chunk);
+        if (!gang) {                                                 // somebody cannot: everybody finishes alone
+            for (int i = 0; i < count; ++i)
+                if (rem[i] > 0) { const int st = ps[i]->step_n(rem[i]); if (st) return st; }
+            return EPH_OK;
+        }
+        igs.clear();
+        for (NBodyPropagator *p : act) {
+            const int st = p->batch_begin();
+            if (st) return st;
+            igs.push_back(p->integ_.get());
+        }
+        const int st_adv = NBodyIntegration::advance_many(igs.data(), (int)igs.size(), chunk);
+        if (st_adv) {                                                // (gang_ready held for all: not a StepError)
+            for (NBodyPropagator *p : act) p->failed_ = st_adv;
+            return st_adv;
+        }
+        for (NBodyPropagator *p : act) {
+            p->integ_->set_sampling(SampleArgs{});
+            const int st = p->fit_and_push(chunk, p->integ_->stream());
+            if (st) return p->failed_ = st;
+        }
+        for (int i = 0; i < count; ++i)
+            if (rem[i] > 0) rem[i] -= chunk;
+    }
 }
 
 // the per-step bookkeeping of SplineInterpolators::solout_with (nbody.rs:371-400) replayed for `done` steps, the

@@ -116,6 +116,13 @@ int32_t eph_nbody_kernel_time(eph_nbody *h, double *total_ms, uint64_t *launches
 int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on);
 /* block until every launch queued on the handle's stream has finished */
 int32_t eph_nbody_sync(eph_nbody *h);
+/* eph_nbody_advance(h, n_steps) on `count` independent systems at once. Systems of at most 32 bodies advance in ONE
+ * workgroup each (a step is a chain of dependent operations, not work: 32 bodies use one of 256 compute units), so the
+ * steady-state steps of all of them go into one launch with a workgroup per system -- the reference runs its forward and
+ * backward propagators concurrently (ephemeris_explorer/src/load/mod.rs:673-687), and ensembles are independent too.
+ * Same results as the separate calls; systems that do not qualify (start-up steps, more bodies, a sharded handle, a
+ * step that would return a StepError) simply make the call do those. Handles must be distinct and on one device. */
+int32_t eph_nbody_advance_many(eph_nbody *const *handles, int32_t count, int64_t n_steps);
 
 /* ---- multi-GPU: the massive-body system partitioned by TARGET body over the ranks of one node -----------------
  * (the reference runs one propagator per task, ephemeris_explorer/src/prediction.rs:422-443, and has
@@ -173,6 +180,9 @@ int32_t eph_prop_create(int32_t n, const double *pos_xyz, const double *vel_xyz,
 int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rccl_unique_id, eph_exchange_fn fn,
                        void *ctx);
 int32_t eph_prop_shard_peer(eph_prop *p, eph_peer *peer);
+/* eph_prop_step_n(p, n) on `count` propagators at once, their steady-state steps in shared launches
+ * (eph_nbody_advance_many); each propagator samples, fits and pushes its own windows. */
+int32_t eph_prop_step_n_many(eph_prop *const *props, int32_t count, int64_t n);
 /* IncrementalPropagator::step  nbody.rs:200-207. Executed lazily: the reference's callers step in a loop and read
  * time() / has_reached() after every step (ephemeris_explorer/src/prediction.rs:422-443); both are functions of the number
  * of steps taken, so a steady-state step only advances that bookkeeping on the host (and returns the StepError the step
