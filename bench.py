@@ -360,7 +360,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0,
                     help="how many times the K-step block is timed (0 = as many as make the timed region >= 50 ms, at "
                          "least 3); ms_per_step is the MEDIAN block")
-    ap.add_argument("--path", choices=["exact", "fast", "fast-rsq"], default="exact",
+    ap.add_argument("--path", choices=["exact", "fast", "fast-rsq", "f32-pairs"], default="exact",
                     help="exact (default): the reference's summation order, bit-identical to the CPU path | fast: the "
                          "opt-in slice-parallel sums (EPH_PATH_FAST) -- a second, separately labelled line "
                          "(config.workload ..._fast) with its measured divergence from the reference order")
@@ -416,8 +416,8 @@ def main():
     # rank r integrates its own replica (seed + r): independent systems, no exchange -- or, sharded, every rank
     # builds the SAME system and owns n/world target bodies of it
     pos, vel, mu = plummer(n, seed=20260926 + (0 if sharded else rank))
-    fast = args.path in ("fast", "fast-rsq")
-    fast_path = {"fast": ea.PATH_FAST, "fast-rsq": ea.PATH_FAST_RSQ}.get(args.path)
+    fast = args.path in ("fast", "fast-rsq", "f32-pairs")
+    fast_path = {"fast": ea.PATH_FAST, "fast-rsq": ea.PATH_FAST_RSQ, "f32-pairs": ea.PATH_F32_PAIRS}.get(args.path)
     if fast and sharded:
         raise SystemExit("--path fast is not sharded")
     g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
@@ -485,20 +485,25 @@ def main():
             "timing": f"the {args.steps}-step block timed {len(blocks)} times (barrier + device sync around each); "
                       "value and ms_per_step are the median block",
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": ("f32 pair arithmetic, f64 accumulation and integrator (mixed)" if args.path == "f32-pairs" else "f64"),
+            "data": "synthetic",
             "config": ({"workload": f"plummer_{n}_f64_qt12, one system partitioned by target body "
                                     f"(BASELINE.json configs[4] in f64; h=1/1024, seed 20260926)",
                         "bodies_per_gpu": nt, "method": "QuinlanTremaine12",
                         "parallelism": f"target-partition x{world}, 1 all-gather of {32 * n} B per step "
                                        f"({args.transport})"} if sharded else
-                       {"workload": f"plummer_{n}_f64_qt12{'_' + args.path.replace('-', '_') if fast else ''} (BASELINE.json configs[2]; h=1/1024, "
-                                    "seed 20260926+rank)" + ("; OPT-IN fast path: slice-parallel partial sums, NOT the "
-                                                             "reference's summation order" if fast else ""),
+                       {"workload": (f"plummer_{n}_qt12_f32pairs (BASELINE.json configs[4] on one GPU; h=1/1024, seed 20260926+rank); "
+                                     "OPT-IN mixed precision: pair arithmetic in binary32, f64 accumulation in slice order, f64 "
+                                     "integrator -- the reference has no f32 path, no parity claim" if args.path == "f32-pairs" else
+                                     f"plummer_{n}_f64_qt12{'_' + args.path.replace('-', '_') if fast else ''} (BASELINE.json configs[2]; h=1/1024, "
+                                     "seed 20260926+rank)" + ("; OPT-IN fast path: slice-parallel partial sums, NOT the "
+                                                              "reference's summation order" if fast else "")),
                         "bodies_per_gpu": n, "method": "QuinlanTremaine12", "parallelism": f"replicas x{world}",
                         "path": args.path}),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("k_fast_partial + k_fast_finish<12>" if fast else
+                         "kernel": ("k_fast_partial_f32 + k_fast_finish<12>" if args.path == "f32-pairs" else
+                                    "k_fast_partial + k_fast_finish<12>" if fast else
                                     "k_lm_step_wg<12,LAYOUT>" if nt >= 1024 else "k_lm_step<BPW,12>"),
                          "launch_us": launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * nt,
@@ -518,7 +523,9 @@ def main():
             out["fp64"]["valu_issue"] = {"achieved": lane_ops / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS / 2.0,
                                          "unit": "T lane-ops/s", "frac": lane_ops / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
                                          "valu_wave_insts_per_launch": valu_insts}
-        if world == 1 and not args.no_cpu_baseline and n == N_BODIES:
+        if world == 1 and not args.no_cpu_baseline and n != N_BODIES and not sharded:
+            out["cpu_baseline"] = sharded_cpu_baseline(pos, mu, n)
+        if world == 1 and not args.no_cpu_baseline and n == N_BODIES and args.path != "f32-pairs":
             base, o = cpu_baseline(pos, vel, mu, args.cpu_steps)
             out["cpu_baseline"] = base
             # parity beside the number: a fresh GPU run of the same steps vs the oracle
@@ -531,8 +538,24 @@ def main():
             out["parity"] = {"max_abs_dpos": float(dp), "steps": int(nsteps), "vs": "oracle (port)"}
         if world == 1 and not args.no_cpu_baseline and sharded:
             out["cpu_baseline"] = sharded_cpu_baseline(pos, mu, n)
+        if world == 1 and args.path == "f32-pairs":
+            # what the mixed path is to be judged against: the build's own exact f64 path on the same system
+            ex = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            mx = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            mx.set_path(fast_path)
+            done, dv = 0, {}
+            for k in (12 + 10, 12 + 100, 12 + 1000):
+                if n > 16384 and k > 12 + 100:
+                    break                                   # (an exact step of 65 536 bodies is 8 ms; keep the default run short)
+                ex.advance(k - done); mx.advance(k - done)
+                done = k
+                dv[str(k - 12)] = float(np.abs(mx.state()[0] - ex.state()[0]).max())
+            a_ex, a_mx = ex.acc(), mx.acc()
+            out["parity"] = {"vs": "this library's exact f64 path on the same system (the reference has no f32 path)",
+                             "max_abs_dpos_after_steady_steps": dv,
+                             "max_rel_dacc": float(np.abs(a_mx - a_ex).max() / np.abs(a_ex).max())}
         fx = ROOT / "tests" / "golden" / "plummer4096_horizon.npz"
-        if world == 1 and n == N_BODIES and not sharded and args.horizon > 0 and fx.exists():
+        if world == 1 and n == N_BODIES and not sharded and args.horizon > 0 and fx.exists() and args.path != "f32-pairs":
             # north_star: "positions within 1e-9 AU of the reference over 1e5 steps": max |dpos| against the oracle's
             # committed positions (generator tests/golden/make_plummer_horizon.py) at every 10^k-th step
             ref = np.load(fx)

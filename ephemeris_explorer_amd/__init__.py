@@ -30,6 +30,7 @@ if _os.environ.get("EPH_AMD_LIBRARY"):            # tuning builds (scripts/): an
 FORWARD, BACKWARD = 1, -1
 PATH_FAST = 4
 PATH_FAST_RSQ = 5
+PATH_F32_PAIRS = 6   # OPT-IN mixed precision: f32 pair arithmetic, f64 accumulation and integrator (include/ephemeris_amd.h)
 
 OK = 0
 STEP_SIZE_UNDERFLOW, MAX_ITERATIONS_REACHED, BOUND_REACHED, EVAL_FAILED, SOLOUT_EXIT = 1, 2, 3, 4, 5

@@ -195,7 +195,7 @@ int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count) {
     return EPH_OK;
 }
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path) {
-    if (!h || !h->p || path < 0 || path > EPH_PATH_FAST_RSQ) return EPH_ERR_BAD_ARGUMENT;
+    if (!h || !h->p || path < 0 || path > EPH_PATH_F32_PAIRS) return EPH_ERR_BAD_ARGUMENT;
     h->p->set_path(path);
     return EPH_OK;
 }

@@ -112,7 +112,7 @@ constexpr int kGangMaxN = 32;
 int launch_lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);
 // opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
 int fast_slices(int npad);                                          // S
-int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial /*[S][3][npad]*/, bool approx_rsq = false);  // n <= 64: nsteps steps, one workgroup
+int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr);   // posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body
 int lm_bodies_per_wave(int n);
 int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step);
 // carry: samples [src[b], src[b]+cnt[b]) of body b's region move to its front (src[b] == 0: nothing to do)

@@ -197,6 +197,7 @@ private:
     DevBuf<Body4> P_[2];
     DevBuf<double> Y_, A_, V_, ASR_, mu_, stage_;
     DevBuf<double> fast_partial_;             // EPH_PATH_FAST scratch: [S][3][npad] partial sums
+    DevBuf<float> posf_;                      // EPH_PATH_F32_PAIRS scratch: the level's positions and mu as 4 floats per body
     std::vector<LmArgs> *collect_ = nullptr;  // advance_many: lm_batch hands its launch arguments over instead of launching
     DevBuf<LmArgs> gang_args_;                // advance_many: the argument array of the gang this handle leads
     hipEvent_t gang_ev_ = nullptr;

@@ -43,8 +43,20 @@ __device__ __forceinline__ PairPre pair_pre(double xi, double yi, double zi, con
 }
 template <bool FAST>
 __device__ __forceinline__ void pair_finish(const PairPre &p, double mu, double &cx, double &cy, double &cz) {
-    // IEEE correctly rounded f64 sqrt and divide in the build's evaluation order (device_math.h pair_den / pair_apply)
-    pair_apply<FAST>(pair_den<FAST>(p.n2), p.dx, p.dy, p.dz, mu, cx, cy, cz);
+    // IEEE correctly rounded f64 sqrt and divide in the build's evaluation order (device_math.h)
+    if constexpr (kPairVariant <= 3) {
+        // (written out, not through pair_den / pair_apply: the same operations, but that route costs the workgroup kernel
+        // 0.3 us per step at N = 4096 -- 37.2 vs 36.9 -- through a different instruction order; gpurun_out r03 A/B)
+        double inv;
+        if (FAST) inv = inv_r3_inrange(p.n2);
+        else inv = inv_r3_ieee(p.n2);
+        const double s = mu * inv;
+        cx = p.dx * s;
+        cy = p.dy * s;
+        cz = p.dz * s;
+    } else {
+        pair_apply<FAST>(pair_den<FAST>(p.n2), p.dx, p.dy, p.dz, mu, cx, cy, cz);
+    }
 }
 __global__ void k_debug_inv_r3(long long n, const double *__restrict__ n2, double *__restrict__ fast,
                                double *__restrict__ ieee) {
@@ -1077,6 +1089,10 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
         if (tail_wave) {
             double yv[L], av[L];
             load_history(yv, av);
+            // (Forming everything that does not need the new acceleration here, ahead of the barriers -- the predictor's
+            // position sum, the products of both acceleration sums, Cowell's difference quotient -- was built and measured:
+            // 37.55 vs 37.2 us per step at N = 4096. The early arithmetic takes issue slots from the pair wave and the chain
+            // wave of this SIMD when they are the critical path, and the tail's work was not on it; gpurun_out r03 A/B.)
             const int tiles = (a.n + kTile - 1) / kTile;
             __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER();   // the idle wave's role: TB + 1 barriers
             __syncthreads();                              // the chain wave's result is in LDS
@@ -1201,6 +1217,81 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
     if (j0 < j1) {
         if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
         else fast_slice<false, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+    }
+    double *pp = partial + (size_t)slice * 3 * npad + i;
+    pp[0] = ax;
+    pp[(size_t)npad] = ay;
+    pp[(size_t)2 * npad] = az;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// OPT-IN MIXED PRECISION (eph_nbody_set_path(.., EPH_PATH_F32_PAIRS); BASELINE.json configs[4] "65 536-body f32 system"):
+// the pair arithmetic in binary32 -- differences of positions rounded to f32, n2 by fma, v_rsq_f32 + one Newton step,
+// y^3, mu y^3, the three products -- two sources at a time in the packed f32 instructions (v_pk_add / v_pk_mul /
+// v_pk_fma_f32: the only VALU form that runs at twice the f64 rate), every contribution then converted to f64 and
+// ACCUMULATED in f64 in the fast path's slice order; Cowell, predictor and the whole integrator state stay f64 (a
+// twelfth-order multistep recurrence cannot hold its state in binary32). The reference has no f32
+// path (ephemeris/src/propagators/nbody.rs:13,19): no parity claim, never the default, for large systems only.
+// ------------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct BodyF { float x, y, z, mu; };
+__global__ void __launch_bounds__(256) k_pos_to_f32(int n, int npad, const Body4 *__restrict__ pos, BodyF *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    BodyF b{0.f, 0.f, 0.f, 0.f};
+    if (i < n) { const Body4 p = pos[i]; b = BodyF{(float)p.x, (float)p.y, (float)p.z, (float)p.mu}; }
+    out[i] = b;
+}
+template <bool DIAG>
+__device__ __forceinline__ void f32_slice(const __attribute__((address_space(4))) BodyF *src, int j0, int j1, int n, int i,
+                                          float xi, float yi, float zi, double &ax, double &ay, double &az) {
+    constexpr int U = 4;                               // sources per iteration: two packed pairs
+    const v2f x2{xi, xi}, y2{yi, yi}, z2{zi, zi};
+    for (int j = j0; j < j1; j += U) {                 // j1 - j0 is a multiple of U; sources >= n are padding
+        BodyF p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { p[u].x = src[j + u].x; p[u].y = src[j + u].y; p[u].z = src[j + u].z; p[u].mu = src[j + u].mu; }
+        v2f cx[2], cy[2], cz[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const BodyF &pa = p[2 * h], &pb = p[2 * h + 1];
+            const v2f dx = v2f{pa.x, pb.x} - x2, dy = v2f{pa.y, pb.y} - y2, dz = v2f{pa.z, pb.z} - z2;
+            v2f n2 = dx * dx;
+            n2 = __builtin_elementwise_fma(dy, dy, n2);
+            n2 = __builtin_elementwise_fma(dz, dz, n2);
+            v2f y{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)};
+            const v2f hn = n2 * v2f{0.5f, 0.5f};
+            const v2f r = __builtin_elementwise_fma(-(hn * y), y, v2f{0.5f, 0.5f});   // 0.5 (1 - n2 y^2)
+            y = __builtin_elementwise_fma(y, r, y);
+            const v2f sc = v2f{pa.mu, pb.mu} * (y * y * y);
+            cx[h] = dx * sc; cy[h] = dy * sc; cz[h] = dz * sc;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (DIAG && j + u == i) continue;          // the body itself (n2 = 0 -> NaN): not a source
+            if (j + u >= n) continue;                  // padding rows
+            ax = ax + (double)cx[u >> 1][u & 1];
+            ay = ay + (double)cy[u >> 1][u & 1];
+            az = az + (double)cz[u >> 1][u & 1];
+        }
+    }
+}
+__global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int npad, const BodyF *__restrict__ posf, int S,
+                                                                      int slice_len, double *__restrict__ partial) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgs_per_block = S / kFastWaves;
+    const int block = blockIdx.x / wgs_per_block;
+    const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
+    const int i = block * 64 + lane;
+    const int ic = min(i, n - 1);
+    const auto *src = (const __attribute__((address_space(4))) BodyF *)(unsigned long long)posf;
+    const float xi = posf[ic].x, yi = posf[ic].y, zi = posf[ic].z;
+    const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (j0 < j1) {
+        if (j0 < block * 64 + 64 && j1 > block * 64) f32_slice<true>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        else f32_slice<false>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
     }
     double *pp = partial + (size_t)slice * 3 * npad + i;
     pp[0] = ax;
@@ -1988,7 +2079,7 @@ int fast_slices(int npad) {
     S = std::max(kFastWaves, std::min(kFastMaxSlices, S));
     return (S + kFastWaves - 1) / kFastWaves * kFastWaves;
 }
-int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, bool approx) {
+int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf) {
     if (a.n <= 0) return EPH_OK;
     if (a.lo != 0 || a.hi != a.n) return EPH_ERR_UNSUPPORTED;          // the fast path is not sharded
     static const int unroll = [] { const char *e = getenv("EPH_FAST_UNROLL"); return e && atoi(e) == 8 ? 8 : 4; }();
@@ -1997,7 +2088,11 @@ int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, bool ap
     const int un = approx ? 4 : unroll;
     slice_len = (slice_len + un - 1) / un * un;
     const dim3 pgrid((unsigned)(a.npad / 64 * (S / kFastWaves))), pblock(64 * kFastWaves);
-    if (approx)
+    if (posf) {                                                         // EPH_PATH_F32_PAIRS
+        BodyF *pf = reinterpret_cast<BodyF *>(posf);
+        hipLaunchKernelGGL(k_pos_to_f32, dim3((unsigned)((a.npad + 255) / 256)), dim3(256), 0, s, a.n, a.npad, a.pos_cur, pf);
+        hipLaunchKernelGGL(k_fast_partial_f32, pgrid, pblock, 0, s, a.n, a.npad, (const BodyF *)pf, S, slice_len, partial);
+    } else if (approx)
         hipLaunchKernelGGL((k_fast_partial<4, true>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     else if (unroll == 8 && a.npad % 8 == 0)
         hipLaunchKernelGGL((k_fast_partial<8, false>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);

@@ -226,10 +226,13 @@ int NBodyIntegration::lm_batch(int64_t k) {
     a.samp = samp_;
     a.kind = force_kind();
     int st;
-    const bool fast = path_ == EPH_PATH_FAST || path_ == EPH_PATH_FAST_RSQ;
+    const bool fast = path_ == EPH_PATH_FAST || path_ == EPH_PATH_FAST_RSQ || path_ == EPH_PATH_F32_PAIRS;
     if (fast && (n_ <= kSmallN || sharded())) return EPH_ERR_UNSUPPORTED;
     if (fast && !fast_partial_.p) {
         if ((st = fast_partial_.alloc((size_t)fast_slices(npad_) * 3 * npad_))) return st;
+    }
+    if (path_ == EPH_PATH_F32_PAIRS && !posf_.p) {
+        if ((st = posf_.alloc((size_t)4 * npad_))) return st;
     }
     const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3 && !fast;
     if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
@@ -257,7 +260,9 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.pos_next = P_[pp_ ^ 1].p;
             a.do_predict = s < k;
             a.step = (uint32_t)s;
-            if ((st = fast ? launch_lm_step_fast(stream_, a, fast_partial_.p, path_ == EPH_PATH_FAST_RSQ) : launch_lm_step(stream_, a)))
+            if ((st = fast ? launch_lm_step_fast(stream_, a, fast_partial_.p, path_ == EPH_PATH_FAST_RSQ,
+                                                 path_ == EPH_PATH_F32_PAIRS ? posf_.p : nullptr)
+                           : launch_lm_step(stream_, a)))
                 return st;
             if (a.do_predict && (st = gather_packed(a.pos_next))) return st;
         }

@@ -109,6 +109,11 @@ int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count);
 /* 5 = EPH_PATH_FAST_RSQ, OPT-IN: the fast path with 1/r^3 from v_rsq_f64 + two Newton steps instead of the IEEE square
  * root and division (SURVEY 7 stage 3 "fast mode"): the pair terms themselves differ from the reference's in the last bit. */
 #define EPH_PATH_FAST_RSQ 5
+/* 6 = EPH_PATH_F32_PAIRS, OPT-IN, for large systems (BASELINE.json configs[4], "65 536-body f32"): the fast path with the
+ * PAIR arithmetic in binary32 (packed f32 instructions, v_rsq_f32 + one Newton step), contributions accumulated in f64 in
+ * slice order, integrator state and formulae f64. The reference has no f32 path (nbody.rs:13,19): accelerations agree
+ * with the exact path to ~1e-6 relative, trajectories diverge accordingly. Never the default. */
+#define EPH_PATH_F32_PAIRS 6
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path);
 /* device time of the steady-state kernels launched by this handle so far, measured with HIP events on the
  * handle's stream: total milliseconds and launch count (used by bench.py for the roofline figure) */

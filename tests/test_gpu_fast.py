@@ -55,7 +55,7 @@ def test_fast_rsq_path(gpu):
     scale = np.abs(exact).max()
     assert 0.0 < np.abs(rsq - exact).max() < 1e-13 * scale and not np.array_equal(rsq, fast)
     with pytest.raises(gpu.EphemerisError):
-        gpu.NBodyIntegration(pos, vel, mu, 0.0, H).set_path(6)
+        gpu.NBodyIntegration(pos, vel, mu, 0.0, H).set_path(7)
 
 
 def test_fast_path_refuses_what_it_does_not_cover(gpu):
@@ -128,3 +128,27 @@ def test_fast_path_body_at_the_origin_with_padded_sources(gpu, path):
     a, ae = g.acc(), exact.acc()
     assert np.isfinite(a).all() and np.isfinite(g.state()[0]).all()
     assert np.abs(a - ae).max() < 1e-9 * np.abs(ae).max()
+
+
+@pytest.mark.parametrize("n", [1000, 16384])
+def test_f32_pairs_path(gpu, n):
+    """EPH_PATH_F32_PAIRS (BASELINE.json configs[4]'s precision): pair arithmetic in binary32, f64 accumulation in slice
+    order, f64 integrator. Deterministic; accelerations at single-precision distance from the exact path's, the state after
+    a few steps accordingly close; a body at the origin with padded sources stays finite."""
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(n)
+    pos[5] = 0.0
+    runs = []
+    for path in (0, 6, 6):
+        g = gpu.NBodyIntegration(pos, vel, mu, 0.0, H)
+        g.set_path(path)
+        g.advance(12 + 1)
+        a1 = g.acc()
+        g.advance(20)
+        runs.append((a1, g.state()[0]))
+    (ae, pe), (am, pm), (am2, pm2) = runs
+    assert np.array_equal(am, am2) and np.array_equal(pm, pm2)
+    assert np.isfinite(am).all() and np.isfinite(pm).all()
+    rel = np.abs(am - ae).max() / np.abs(ae).max()
+    assert 1e-9 < rel < 2e-5, rel                      # binary32 pair terms: ~6e-8 each, a few close pairs dominate
+    assert 0.0 < np.abs(pm - pe).max() < 1e-6
