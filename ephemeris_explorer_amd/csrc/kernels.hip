@@ -830,6 +830,12 @@ __device__ __forceinline__ double chain_full_asm(const double *row, double acc) 
     return acc;
 }
 
+// (Round 3, for the 8- and 4-body workgroups where the step IS the chain wave's time: the chains split by LANE between two
+// chain waves -- wave 4 and an idle wave, first of the same SIMD, then of another -- each owning its chains from the first
+// tile to the last, no hand-over. Bit-identical and SLOWER: N = 2048 22.0 / 23.2 us against 18.4, N = 1024 13.9 / 13.6
+// against 11.9. A ds_read_b128 costs the workgroup's one LDS pipe the same whether 24 or 12 lanes carry a chain, so two
+// chain waves double the LDS time of the ordered sums instead of overlapping one wave's reads with the other's adds. What
+// would keep the read count is a split by TILE with the 3 * WB partial sums handed over between the waves every tile.)
 // Returns on chain-wave lane ch < 48: component ch%3 of body i0 + ch/3. All 320 threads must call it.
 template <int LAYOUT, int WB = kWgBodies, typename PosPtr>
 __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg = 0) {
