@@ -1616,11 +1616,12 @@ struct eph_craft_batch {
 // heliocentric cruise 5e6 s. craft_launch uses it to pick k_craft_queue over the static kernel.
 static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const double *t0, const double *pos) {
     if (n < 128 || e.host_coeffs.empty()) return false;
-    const long long m = std::min<long long>(n, 512), stride = n / m;
+    const long long m = std::min<long long>(n, 512);
     std::vector<double> tau;
     tau.reserve((size_t)m);
     for (long long q = 0; q < m; ++q) {
-        const long long i = q * stride;
+        // scattered sample (a fixed stride would alias with any periodic arrangement of the craft, e.g. families interleaved)
+        const long long i = (long long)(((unsigned long long)q * 0x9E3779B97F4A7C15ull >> 11) % (unsigned long long)n);
         double best = INFINITY;
         for (const BodyEntry &b : e.host_bodies) {
             if (!(b.mu > 0.0) || b.npoly <= 0) continue;

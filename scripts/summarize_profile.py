@@ -21,11 +21,17 @@ bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
 (dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1) + "\n")
 
 
-for extra in ("bench_fast", "bench_fast_rsq", "bench_craft", "bench_sharded"):                      # the round's other bench lines
+for extra in ("bench_fast", "bench_fast_rsq", "bench_craft", "bench_sharded", "bench_f32pairs", "bench_f32pairs_4096",
+              "bench_craft_mixed", "bench_craft_mixed_static", "bench_gpus2_shared_device", "bench_gpus4_shared_device",
+              "bench_20a", "bench_20b"):                                                              # the round's other bench lines
     f = src / f"{extra}.json"
     if f.exists() and f.read_text().strip():
         (dst / f"{tag}_{extra}.json").write_text(json.dumps(json.loads(f.read_text().strip().splitlines()[-1]), indent=1) + "\n")
-for extra in ("fast_stats", "craft_stats"):
+for extra in ("time_small.txt", "time_sizes.txt"):
+    f = src / extra
+    if f.exists():
+        shutil.copy(f, dst / f"{tag}_{extra}")
+for extra in ("fast_stats", "craft_stats", "f32_stats"):
     f = src / f"{extra}_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, dst / f"{tag}_{extra.replace('_stats', '')}_kernel_stats.csv")
