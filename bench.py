@@ -205,7 +205,10 @@ def craft_main(args):
                                               "(batches created before the timed region: state resident in HBM)",
             "roofline": {"bound": "hbm", "achieved": 56.0 * steps_local / nsweeps / launch_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": 56.0 * steps_local / nsweeps / launch_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_craft_propagate<13,false,false,2>", "launch_us": launch_s * 1e6,
+                         "traffic": None,
+                         "kernel": "k_craft_propagate<13,false,false,2> (static) or k_craft_queue<13,false> (work queue): "
+                                   "chosen per batch from the spread of dynamical times inside a wave (craft.hip craft_launch)",
+                         "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": 56.0 * steps_local / nsweeps,
                          "note": "rank 0's shard; the sweep is f64-VALU bound (every ephemeris row is an L1 hit), see fp64"},
             "fp64": {"bound": "fp64_valu", "achieved": flop / nsweeps / launch_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -1608,20 +1608,17 @@ struct eph_craft_batch {
     }
 };
 
-// Scheduling estimate (never part of a result): does the batch mix craft whose adaptive step sizes will differ widely?
-// The step size of an embedded pair follows the local dynamical time sqrt(d^3 / mu) of the nearest massive body, so a
-// sample of up to 512 craft gets tau_i = min over bodies of sqrt(|r_i - r_b(t0_i)|^3 / mu_b) from the host copy of the
-// ephemeris (plain Horner, approximate is fine) and the batch counts as heterogeneous when the 95th and 5th percentile
-// of tau differ by more than 4x: a low orbit 860 s, a lunar transfer's perigee the same but its apogee days, a
-// heliocentric cruise 5e6 s. craft_launch uses it to pick k_craft_queue over the static kernel.
+// Scheduling estimate (never part of a result): do the 64 craft that would share a WAVE need very different numbers of
+// steps? The step size of an embedded pair follows the local dynamical time sqrt(d^3 / mu) of the nearest massive body,
+// so eight waves scattered over the batch (64 consecutive craft each) get tau_i = min over bodies of
+// sqrt(|r_i - r_b(t0_i)|^3 / mu_b) from the host copy of the ephemeris (plain Horner; approximate is fine), and the batch
+// counts as heterogeneous when inside any of them the largest and smallest tau differ by more than 4x: a low orbit 860 s,
+// a heliocentric cruise 5e6 s. Families in contiguous blocks do NOT count (measured: the static kernel is then the
+// faster one, 183 against 213 ms -- the hardware's wave dispatch already is a queue of whole waves); craft_launch uses
+// the answer to pick k_craft_queue over the static kernel.
 static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const double *t0, const double *pos) {
     if (n < 128 || e.host_coeffs.empty()) return false;
-    const long long m = std::min<long long>(n, 512);
-    std::vector<double> tau;
-    tau.reserve((size_t)m);
-    for (long long q = 0; q < m; ++q) {
-        // scattered sample (a fixed stride would alias with any periodic arrangement of the craft, e.g. families interleaved)
-        const long long i = (long long)(((unsigned long long)q * 0x9E3779B97F4A7C15ull >> 11) % (unsigned long long)n);
+    auto tau_of = [&](long long i) {
         double best = INFINITY;
         for (const BodyEntry &b : e.host_bodies) {
             if (!(b.mu > 0.0) || b.npoly <= 0) continue;
@@ -1638,12 +1635,21 @@ static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const 
             const double d2 = dx * dx + dy * dy + dz * dz;
             best = std::min(best, std::sqrt(d2 * std::sqrt(d2) / b.mu));
         }
-        if (std::isfinite(best)) tau.push_back(best);
+        return best;
+    };
+    const long long waves = n / 64;
+    for (int w = 0; w < 8; ++w) {
+        const long long first = (long long)(((unsigned long long)w * 0x9E3779B97F4A7C15ull >> 11) % (unsigned long long)waves) * 64;
+        double lo = INFINITY, hi = 0.0;
+        for (long long i = first; i < first + 64; ++i) {
+            const double t = tau_of(i);
+            if (!std::isfinite(t)) continue;
+            lo = std::min(lo, t);
+            hi = std::max(hi, t);
+        }
+        if (hi > 4.0 * lo) return true;
     }
-    if (tau.size() < 64) return false;
-    std::sort(tau.begin(), tau.end());
-    const double lo = tau[tau.size() / 20], hi = tau[tau.size() - 1 - tau.size() / 20];
-    return hi > 4.0 * lo;
+    return false;
 }
 
 // Timeline::new  ephemeris/src/propagators/spacecraft.rs:129-152: stable sort by start, coast segments in the gaps,
