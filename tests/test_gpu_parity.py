@@ -237,7 +237,7 @@ def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu):
 def test_inrange_sequence_sweep_on_the_device(gpu):
     """The same comparison over 2^33 device-generated operands (random mantissa, exponent uniform over the guarded range):
     the in-range 1/(x*sqrt(x)) -- whose reciprocal is seeded from the square root's refinement, device_math.h -- must
-    equal the compiler's IEEE expansion in every bit. (scripts/r02_twelfth.sh ran 2.7e11 operands: no mismatch.)"""
+    equal the compiler's IEEE expansion in every bit. (`git show d7efbfa:scripts/r02_twelfth.sh` ran 2.7e11 operands: no mismatch.)"""
     for seed in (1, 0xDEADBEEF):
         bad, example = gpu.debug_inv_r3_sweep(seed, 1 << 32)
         assert bad == 0, f"{bad} mismatches, e.g. operand bits {example:#x}"
