@@ -67,7 +67,7 @@ def test_fast_path_refuses_what_it_does_not_cover(gpu):
     with pytest.raises(gpu.EphemerisError):                   # 32 bodies: one workgroup, nothing to slice
         g.advance(1)
     with pytest.raises(gpu.EphemerisError):
-        g.set_path(6)
+        g.set_path(7)
 
 
 def test_fast_path_with_solout_sampling(gpu):
