@@ -215,9 +215,10 @@ __device__ __forceinline__ void pair_apply(const PairDen &d, double dx, double d
             const bool bad = !(quot_ok(nx) && quot_ok(ny) && quot_ok(nz));
             if (__builtin_amdgcn_ballot_w64(bad) != 0 && bad) { cx = nx / d.v; cy = ny / d.v; cz = nz / d.v; }
         } else if constexpr (kPairVariant == 5) {
-            double s = quot_fast(mu, d);
-            const bool bad = !quot_ok(mu);
-            if (__builtin_amdgcn_ballot_w64(bad) != 0 && bad) s = mu / d.v;
+            double s;                                  // (one quotient: plain lane branches measured faster here, 42.9 vs 50.8 us)
+            if (mu == 0.0) s = mu;
+            else if (in_range_div(mu)) s = div_refined(mu, d.v, d.r);
+            else s = mu / d.v;
             cx = dx * s; cy = dy * s; cz = dz * s;
         } else {
             double qx = quot_fast(dx, d), qy = quot_fast(dy, d), qz = quot_fast(dz, d);
