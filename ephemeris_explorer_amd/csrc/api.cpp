@@ -143,6 +143,7 @@ int32_t eph_nbody_create(int32_t n, const double *pos, const double *vel, const 
 int32_t eph_nbody_advance(eph_nbody *h, int64_t n_steps) {
     EPH_GUARD_BEGIN
     if (!h || !h->p || n_steps < 0) return EPH_ERR_BAD_ARGUMENT;
+    if (const int st = h->settle()) return st;
     return h->p->advance(n_steps);
     EPH_GUARD_END
 }
@@ -152,6 +153,7 @@ int32_t eph_nbody_advance_many(eph_nbody *const *handles, int32_t count, int64_t
     std::vector<NBodyIntegration *> igs;
     for (int32_t i = 0; i < count; ++i) {
         if (!handles[i] || !handles[i]->p) return EPH_ERR_BAD_ARGUMENT;
+        if (const int st = handles[i]->settle()) return st;
         igs.push_back(handles[i]->p);
     }
     return NBodyIntegration::advance_many(igs.data(), count, n_steps);
@@ -160,27 +162,33 @@ int32_t eph_nbody_advance_many(eph_nbody *const *handles, int32_t count, int64_t
 int32_t eph_nbody_get_state(eph_nbody *h, double *pos, double *vel, double *t, uint32_t *sc) {
     EPH_GUARD_BEGIN
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (const int st = h->settle()) return st;
     return h->p->get_state(pos, vel, t, sc);
     EPH_GUARD_END
 }
 int32_t eph_nbody_get_acc(eph_nbody *h, double *acc) {
     EPH_GUARD_BEGIN
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (const int st = h->settle()) return st;
     return h->p->get_acc(acc);
     EPH_GUARD_END
 }
 int32_t eph_nbody_set_bound(eph_nbody *h, double bound) {
+    EPH_GUARD_BEGIN
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (const int st = h->settle()) return st;         // queued steps were accepted against the old bound: run them first
     h->p->set_bound(bound);
     return EPH_OK;
+    EPH_GUARD_END
 }
 int32_t eph_nbody_clone(eph_nbody *h, eph_nbody **out) {
     EPH_GUARD_BEGIN
     if (!h || !h->p || !out) return EPH_ERR_BAD_ARGUMENT;
     *out = nullptr;
     std::unique_ptr<eph_nbody> c(new eph_nbody());
-    int st = h->p->clone(&c->own);
+    int st = h->settle();
     if (st) return st;
+    if ((st = h->p->clone(&c->own))) return st;
     c->p = c->own.get();
     *out = c.release();
     return EPH_OK;
@@ -191,6 +199,7 @@ void eph_nbody_destroy(eph_nbody *h) {
 }
 int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count) {
     if (!h || !h->p || !count) return EPH_ERR_BAD_ARGUMENT;
+    (void)h->settle();
     *count = h->p->evals();
     return EPH_OK;
 }
@@ -212,8 +221,11 @@ int32_t eph_nbody_enable_timing(eph_nbody *h, int32_t on) {
 }
 
 int32_t eph_nbody_sync(eph_nbody *h) {
+    EPH_GUARD_BEGIN
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
+    if (const int st = h->settle()) return st;
     return h->p->sync();
+    EPH_GUARD_END
 }
 
 // ---- target-partitioned multi-GPU run (shard.cpp) -----------------------------------------------------
@@ -319,6 +331,7 @@ int32_t eph_prop_create(int32_t n, const double *pos, const double *vel, const d
     int st = NBodyPropagator::create(n, pos, vel, mu, t0, dt, direction, method, count, degree, &hnd->p);
     if (st) return st;
     hnd->view.p = hnd->p->integration();
+    hnd->view.owner = hnd->p.get();
     *out = hnd.release();
     return EPH_OK;
     EPH_GUARD_END
@@ -402,6 +415,7 @@ int32_t eph_prop_clone(eph_prop *p, eph_prop **out) {
     int st = p->p->clone(&c->p);
     if (st) return st;
     c->view.p = c->p->integration();
+    c->view.owner = c->p.get();
     *out = c.release();
     return EPH_OK;
     EPH_GUARD_END

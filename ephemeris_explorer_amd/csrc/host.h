@@ -365,6 +365,10 @@ private:
 struct eph_nbody {      // the C ABI's opaque Integration handle (a view when it belongs to a propagator)
     std::unique_ptr<eph::NBodyIntegration> own;
     eph::NBodyIntegration *p = nullptr;
+    // a view's propagator: eph_prop_step queues steps on the host (NBodyPropagator::step_deferred), so every eph_nbody_*
+    // call through the view runs that queue first -- the view never shows a state the propagator's callers have moved past
+    eph::NBodyPropagator *owner = nullptr;
+    int settle() const { return owner ? owner->flush() : 0; }
 };
 struct eph_solution {   // the C ABI's opaque Vec<UniformSpline<DVec3>>
     eph::Solution s;

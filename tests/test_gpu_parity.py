@@ -418,3 +418,36 @@ def test_single_steps_are_deferred_but_indistinguishable(gpu, name, direction):
     for b in range(s.n):
         assert sg.info(b) == so.info(b)
         assert_same_bits(sg.coeffs(b)[0], so.coeffs(b)[0], f"final body {b}")
+
+
+def test_borrowed_integration_view_sees_the_queued_steps(gpu):
+    """eph_prop_integrator hands out a view of the propagator's Integration; eph_prop_step only QUEUES steady-state steps.
+    Every eph_nbody_* call through the view runs the queue first: its state, its clone, and a bound set through it are
+    those of a propagator that executed every step when it was asked to."""
+    s = load_system("sun_earth_moon_2433282.5")
+    g = gpu.NBodyPropagator.from_system(s)
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    view = g.integration()
+    g.step_n(20)
+    for _ in range(7):
+        g.step()                                       # queued
+    for _ in range(27):
+        assert o.step() == 0
+    p, v, t, c = view.state()
+    po, vo, to, co = o.state()
+    assert (t, c) == (to, co) and c == 27
+    assert_same_bits(p, po, "view positions") and assert_same_bits(v, vo, "view velocities")
+    for _ in range(3):
+        g.step()
+    twin = view.clone()                                # an Integration clone taken through the view: 30 steps in
+    assert twin.state()[3] == 30
+    for _ in range(4):
+        g.step()                                       # 34 queued / run
+    view.set_bound(s.epoch + 35.5 * s.dt)              # the queued steps ran against the old bound first
+    g.step()                                           # 35
+    g.step()                                           # 36: t = 35 dt < bound
+    with pytest.raises(gpu.StepError) as e:
+        for _ in range(3):
+            g.step()                                   # t = 36 dt >= bound: BoundReached, reported by the step itself
+    assert e.value.status == gpu.BOUND_REACHED
+    assert view.state()[3] == 36
