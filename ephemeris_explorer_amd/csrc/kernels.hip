@@ -1476,6 +1476,11 @@ constexpr int kSmallRows = 3 * kSmallMaxN;
 #ifndef EPH_SMALL_ACCOUNT
 #define EPH_SMALL_ACCOUNT 0
 #endif
+// 1: ONE copy of the step, the history shifted through the registers every step (24 v_mov_b64) instead of twelve copies of
+// the step, one per ring rotation (45 KB of code; two CUs share an instruction cache)
+#ifndef EPH_SMALL_ROLLED
+#define EPH_SMALL_ROLLED 0
+#endif
 #define SMALL_TICK(k) do { if constexpr (EPH_SMALL_ACCOUNT) { const long long now_ = (long long)__builtin_readcyclecounter(); acct[k] += now_ - acct_t; acct_t = now_; } } while (0)
 // the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2] on both halves of the double)
 __device__ __forceinline__ double dpp_xor1(double x) {
@@ -1678,8 +1683,15 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
                 for (int j = 0; j < L; ++j) { al[j] = av[(R + j) % L]; cw[j] = a.cw[j]; }
                 v = lm_cowell<L>(anew, al, ynew, yv[R], cw, a.h, a.hc);
             }
-            yv[Rn] = ynew;
-            av[Rn] = anew;
+            if constexpr (EPH_SMALL_ROLLED) {              // one copy of the step: the history moves through the registers
+#pragma unroll
+                for (int j = L - 1; j > 0; --j) { yv[j] = yv[j - 1]; av[j] = av[j - 1]; }
+                yv[0] = ynew;
+                av[0] = anew;
+            } else {
+                yv[Rn] = ynew;
+                av[Rn] = anew;
+            }
             ynew = ynext;
         }
         if constexpr (EPH_SMALL_ACCOUNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1690,7 +1702,9 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
     int rot = 0;                                       // rotation after the steps taken so far
     const long long dbg_c0 = (wg_flags & 4) ? (long long)__builtin_readcyclecounter() : 0;
     const long long dbg_w0 = (wg_flags & 4) ? (long long)wall_clock64() : 0;
-    {
+    if constexpr (EPH_SMALL_ROLLED) {
+        for (long long s = 1; s <= nsteps; ++s) step(std::integral_constant<int, 0>{}, s);
+    } else {
         long long s = 1;
         bool more = nsteps >= 1;
         while (more) small_steps(step, s, nsteps, rot, more, std::make_integer_sequence<int, L>{});
