@@ -272,7 +272,9 @@ def sharded_4096(dist, world, rank, steps, backend_is_nccl):
         torch.cuda.synchronize()
 
     total = 0
-    for transport in (["peer", "rccl"] if backend_is_nccl else ["peer"]):
+    # RCCL first (when every rank has its own device), then the direct-write transport; EPH_BENCH_SHARDED=rccl|peer|0 narrows it
+    want = os.environ.get("EPH_BENCH_SHARDED", "rccl,peer").split(",")
+    for transport in [t for t in (["rccl", "peer"] if backend_is_nccl else ["peer"]) if t in want]:
         try:
             g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
             shard_nbody(g, dist, transport=transport, device="cuda" if backend_is_nccl else "cpu")
