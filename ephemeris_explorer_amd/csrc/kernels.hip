@@ -645,7 +645,7 @@ __device__ __forceinline__ void wg_pair_tile(const double (&xi)[NB], const doubl
 // waves produce tile t+2 into buffer (t+2)%3 while the chain wave sums tile t from buffer t%3; barrier.
 template <int NB, typename PosPtr>
 __device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles,
-                                             int tdiag, int dbg) {
+                                             int tdiag, int dbg, int wbuf = kWgBuf) {   // wbuf: doubles per LDS tile buffer
     double xi[NB], yi[NB], zi[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -663,7 +663,7 @@ __device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, 
     wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == 0, C, b0, lane);
     pj = pjn;
     pjn = load_src(2);
-    if (tiles > 1) wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == 1, C + kWgBuf, b0, lane);
+    if (tiles > 1) wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == 1, C + wbuf, b0, lane);
     __syncthreads();
     long long t_work = 0, t_bar = 0;
     for (int t = 0; t < tiles; ++t) {
@@ -672,7 +672,7 @@ __device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, 
             pj = pjn;
             pjn = load_src(t + 3);
             if (!(dbg & 2))
-                wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == t + 2, C + ((t + 2) % kWgBufs) * kWgBuf, b0, lane);
+                wg_pair_tile<NB>(xi, yi, zi, pj, tdiag == t + 2, C + ((t + 2) % kWgBufs) * wbuf, b0, lane);
         }
         const long long c1 = __builtin_readcyclecounter();
         __syncthreads();
@@ -830,6 +830,69 @@ __device__ __forceinline__ double chain_full_asm(const double *row, double acc) 
     return acc;
 }
 
+// -DEPH_WG_TILE_SPLIT=1: the 8- and 4-body workgroups (N <= 2048, where the step IS the chain wave's time) with TWO chain
+// waves taking ALTERNATE tiles: while one adds the 64 sources of tile t out of its registers, the other reads tile t + 1
+// into its own (a wave's ds_read_b128 and its dependent adds do not overlap; two waves' do), and the 3 * WB partial sums
+// change hands through LDS at every tile's barrier. Same number of LDS reads as one chain wave (the split by LANE doubled
+// them). One barrier per 64-source tile (three tile buffers), pair waves two tiles ahead.
+// MEASURED (bit-identical; us per step, split | default): N = 640 9.29 | 9.83, 1024 11.74 | 12.01, 1536 16.10 | 15.37,
+// 2048 19.58 | 18.34 -- a gain only where four bodies per workgroup leave the pair side idle anyway; with eight one-body
+// pair waves a barrier per tile makes the pair side (one interaction per wave and tile: a bare dependent chain) the
+// slower one. Producing the tiles in pairs in every other interval to get two interleaved interactions back: 10.4 / 13.0 /
+// 18.7 / 23.0, worse still (the reader waits out the double intervals). Kept as a switch, off.
+#ifndef EPH_WG_TILE_SPLIT
+#define EPH_WG_TILE_SPLIT 0
+#endif
+constexpr int wg_split_wave_b(int wb) { return wb == 8 ? 11 : 6; }   // an idle wave of another SIMD than the chain wave's
+template <int WB, typename PosPtr>
+__device__ __forceinline__ double wg_force_split(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg) {
+    constexpr int kRows = 3 * WB, kBuf = kRows * kRow;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tiles = (n + kTile - 1) / kTile;
+    const int tdiag = i0 / kTile;
+    double *H = C + 3 * kBuf;                           // hand-over: H[lane] = running sum, H[64 + lane] = closed lower sum
+    int body = -1;                                      // pair waves: one body each
+    if constexpr (WB == 8) {
+        switch (wave) { case 1: body = 0; break; case 2: body = 1; break; case 3: body = 2; break; case 5: body = 3; break;
+                        case 6: body = 4; break; case 7: body = 5; break; case 9: body = 6; break; case 10: body = 7; break; default: break; }
+    } else {
+        switch (wave) { case 1: body = 0; break; case 2: body = 1; break; case 3: body = 2; break; case 5: body = 3; break; default: break; }
+    }
+    if (body >= 0) { wg_pair_wave<1>(pos, n, i0, body, C, lane, tiles, tdiag, dbg & ~7, kBuf); return 0.0; }
+    const bool isA = wave == kWgPairWaves, isB = wave == wg_split_wave_b(WB);
+    if (!isA && !isB) { for (int t = 0; t <= tiles; ++t) __syncthreads(); return 0.0; }
+    const int ch = lane < kRows ? lane : kRows - 1;
+    const double *row = C + ch * kRow;
+    const int gself = (i0 % kTile) / WB;
+    const int li = (i0 % kTile) + ch / 3;
+    double acc = init, accL = 0.0;
+    double2 q[4][8];
+    auto plain = [&](int t) { return t < tiles && t != tdiag && min(kTile, n - t * kTile) == kTile; };
+    auto preload = [&](int t) {
+        const double *r = row + (t % 3) * kBuf;
+        load_chunk(r, 0, q[0]); load_chunk(r, 1, q[1]); load_chunk(r, 2, q[2]); load_chunk(r, 3, q[3]);
+    };
+    __syncthreads();                                    // B_0: tiles 0 and 1 ready
+    if (isA && plain(0)) preload(0);
+    for (int t = 0; t < tiles; ++t) {
+        const bool mine = ((t & 1) != 0) == isB;
+        if (mine) {
+            if (t > 0) { acc = H[lane]; accL = H[64 + lane]; }
+            if (plain(t)) {
+                acc = add_chunk(q[0], acc); acc = add_chunk(q[1], acc); acc = add_chunk(q[2], acc); acc = add_chunk(q[3], acc);
+            } else {
+                chain_masked<WB>(row + (t % 3) * kBuf, min(kTile, n - t * kTile), t == tdiag ? gself : -1, li, acc, accL);
+            }
+            H[lane] = acc;
+            H[64 + lane] = accL;
+        } else if (plain(t + 1)) {
+            preload(t + 1);                             // complete since the previous barrier
+        }
+        __syncthreads();
+    }
+    return isA ? H[64 + lane] + H[lane] : 0.0;
+}
+
 // (Round 3, for the 8- and 4-body workgroups where the step IS the chain wave's time: the chains split by LANE between two
 // chain waves -- wave 4 and an idle wave, first of the same SIMD, then of another -- each owning its chains from the first
 // tile to the last, no hand-over. Bit-identical and SLOWER: N = 2048 22.0 / 23.2 us against 18.4, N = 1024 13.9 / 13.6
@@ -847,6 +910,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // Workgroups of 8 / 4 bodies for target counts that would leave CUs without a 16-body workgroup (<= 2048 / <= 1024
     // targets): the chain wave's cost per tile does not depend on how many of its lanes carry a chain, so with one
     // workgroup per CU the step takes the chain wave's time; one body per pair wave, SIMD 0 left to the chain wave.
+    if constexpr (WB < kWgBodies && EPH_WG_TILE_SPLIT) return wg_force_split<WB>(pos, n, i0, init, C, tid, dbg);
     if constexpr (WB == 8) {
         switch (wave) {
             case 1: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
@@ -1100,7 +1164,11 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
             // 37.55 vs 37.2 us per step at N = 4096. The early arithmetic takes issue slots from the pair wave and the chain
             // wave of this SIMD when they are the critical path, and the tail's work was not on it; gpurun_out r03 A/B.)
             const int tiles = (a.n + kTile - 1) / kTile;
-            __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER();   // the idle wave's role: TB + 1 barriers
+            if constexpr (WB < kWgBodies && EPH_WG_TILE_SPLIT) {
+                for (int t = 0; t <= tiles; ++t) __syncthreads();                             // one barrier per tile there
+            } else {
+                __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER();   // the idle wave's role: TB + 1 barriers
+            }
             __syncthreads();                              // the chain wave's result is in LDS
             if (owner) finish(yv, av, C[lane]);
         } else {
