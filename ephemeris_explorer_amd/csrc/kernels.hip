@@ -839,10 +839,11 @@ __device__ __forceinline__ double chain_full_asm(const double *row, double acc) 
 // 2048 19.58 | 18.34 -- a gain only where four bodies per workgroup leave the pair side idle anyway; with eight one-body
 // pair waves a barrier per tile makes the pair side (one interaction per wave and tile: a bare dependent chain) the
 // slower one. Producing the tiles in pairs in every other interval to get two interleaved interactions back: 10.4 / 13.0 /
-// 18.7 / 23.0, worse still (the reader waits out the double intervals). Kept as a switch, off.
+// 18.7 / 23.0, worse still (the reader waits out the double intervals). Default: the 4-body workgroups only.
 #ifndef EPH_WG_TILE_SPLIT
-#define EPH_WG_TILE_SPLIT 0
+#define EPH_WG_TILE_SPLIT 2      // 0 off | 1 the 8- and 4-body workgroups | 2 (default) the 4-body workgroups only, where it wins
 #endif
+constexpr bool wg_tile_split(int wb) { return EPH_WG_TILE_SPLIT == 1 ? wb < 16 : (EPH_WG_TILE_SPLIT == 2 && wb == 4); }
 constexpr int wg_split_wave_b(int wb) { return wb == 8 ? 11 : 6; }   // an idle wave of another SIMD than the chain wave's
 template <int WB, typename PosPtr>
 __device__ __forceinline__ double wg_force_split(PosPtr pos, int n, int i0, double init, double *C, int tid, int dbg) {
@@ -910,7 +911,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // Workgroups of 8 / 4 bodies for target counts that would leave CUs without a 16-body workgroup (<= 2048 / <= 1024
     // targets): the chain wave's cost per tile does not depend on how many of its lanes carry a chain, so with one
     // workgroup per CU the step takes the chain wave's time; one body per pair wave, SIMD 0 left to the chain wave.
-    if constexpr (WB < kWgBodies && EPH_WG_TILE_SPLIT) return wg_force_split<WB>(pos, n, i0, init, C, tid, dbg);
+    if constexpr (wg_tile_split(WB)) return wg_force_split<WB>(pos, n, i0, init, C, tid, dbg);
     if constexpr (WB == 8) {
         switch (wave) {
             case 1: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, dbg, kBuf); return 0.0;
@@ -1164,7 +1165,7 @@ __global__ void __launch_bounds__(wg_threads(LAYOUT)) k_lm_step_wg(const LmArgs 
             // 37.55 vs 37.2 us per step at N = 4096. The early arithmetic takes issue slots from the pair wave and the chain
             // wave of this SIMD when they are the critical path, and the tail's work was not on it; gpurun_out r03 A/B.)
             const int tiles = (a.n + kTile - 1) / kTile;
-            if constexpr (WB < kWgBodies && EPH_WG_TILE_SPLIT) {
+            if constexpr (wg_tile_split(WB)) {
                 for (int t = 0; t <= tiles; ++t) __syncthreads();                             // one barrier per tile there
             } else {
                 __syncthreads(); for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER();   // the idle wave's role: TB + 1 barriers
