@@ -75,9 +75,13 @@ def test_gpus_flag_without_a_launcher_spawns_its_own_ranks():
     assert s4["ranks"] == 2 and s4["ms_per_step"] > 0 and s4["bit_identical_to_single_device"] is True
 
 
-def test_two_ranks_craft_sweep_with_result_gather():
-    d = _run(["--workload", "craft", "--craft", "4001", "--craft-days", "0.05", "--steps", "1", "--prewarm", "0"], 2)
+@pytest.mark.parametrize("population", ["transfer", "mixed"])
+def test_two_ranks_craft_sweep_with_result_gather(population):
+    d = _run(["--workload", "craft", "--craft", "4001", "--craft-days", "0.05", "--steps", "1", "--prewarm", "0",
+              "--population", population], 2)
     assert d["n_gpus"] == 2 and d["metric"] == "craft-steps/s" and "all-gather" in d["config"]["exchange"]
+    assert d["divergence"]["attempts_max_over_mean_per_wave"] >= 1.0
+    assert (population == "mixed") == ("population" in d["config"]["workload"])
 
 
 @pytest.mark.parametrize("transport", ["host", "peer"])
