@@ -685,6 +685,35 @@ __device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, 
 }
 
 // two 64-source tiles at once (layout 3): 2 x NB independent interactions for the scheduler to interleave
+// The in-range term of variant 0 for M interactions at once, STAGE by stage with the VALU order pinned (sched_barrier between
+// stages): the M operations of a stage are independent, so a wave covers part of the dependent latency on its own instead of
+// leaving all of it to the other waves of its SIMD. Same operations as pair_finish<true>, same bits. Measured at N = 4096 on one
+// box, two runs each: 36.91 / 36.93 us against 37.32 / 37.31 without (-DEPH_PAIR_STAGED=0); nothing at N <= 2048, where the
+// ordered sums are the critical path (profiles/r03_step_kernel_evidence.md section 6).
+#ifndef EPH_PAIR_STAGED
+#define EPH_PAIR_STAGED 1
+#endif
+template <int M>
+__device__ __forceinline__ void pair_finish_staged(const PairPre (&pre)[M], const double (&mu)[M], double (&c)[3 * M]) {
+    double x[M], g[M], h[M], r[M], d[M], p[M], q[M], e[M];
+#define EPH_STAGE(body) _Pragma("unroll") for (int k = 0; k < M; ++k) { body; } __builtin_amdgcn_sched_barrier(kSchedMask)
+    EPH_STAGE(x[k] = pre[k].n2; q[k] = __builtin_amdgcn_rsq(x[k]));
+    EPH_STAGE(g[k] = x[k] * q[k]; h[k] = q[k] * 0.5);
+    EPH_STAGE(r[k] = __builtin_fma(-h[k], g[k], 0.5));
+    EPH_STAGE(g[k] = __builtin_fma(g[k], r[k], g[k]); h[k] = __builtin_fma(h[k], r[k], h[k]));
+    EPH_STAGE(d[k] = __builtin_fma(-g[k], g[k], x[k]));
+    EPH_STAGE(g[k] = __builtin_fma(d[k], h[k], g[k]));
+    EPH_STAGE(d[k] = __builtin_fma(-g[k], g[k], x[k]); q[k] = h[k] * h[k]);
+    EPH_STAGE(g[k] = __builtin_fma(d[k], h[k], g[k]); q[k] = q[k] * h[k]);
+    EPH_STAGE(p[k] = x[k] * g[k]; q[k] = q[k] * 8.0);
+    EPH_STAGE(e[k] = __builtin_fma(-p[k], q[k], 1.0));
+    EPH_STAGE(q[k] = __builtin_fma(q[k], e[k], q[k]));
+    EPH_STAGE(e[k] = __builtin_fma(-p[k], q[k], 1.0));
+    EPH_STAGE(q[k] = __builtin_fma(e[k], q[k], q[k]));
+    EPH_STAGE(q[k] = mu[k] * q[k]);
+    EPH_STAGE(c[3 * k] = pre[k].dx * q[k]; c[3 * k + 1] = pre[k].dy * q[k]; c[3 * k + 2] = pre[k].dz * q[k]);
+#undef EPH_STAGE
+}
 template <int NB>
 __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const double (&yi)[NB], const double (&zi)[NB],
                                               const Body4 &pa, const Body4 &pb, bool ieee, double *tile_a, double *tile_b,
@@ -699,12 +728,18 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
     }
     double c[6 * NB];
     if (__builtin_amdgcn_ballot_w64(worst >= kRangeSpan) == 0) {
-        // (the same arithmetic written stage by stage across the 2 NB interactions, so that adjacent instructions are
-        // independent, was measured: 37.38 vs 37.04 us -- the three waves of a SIMD already fill each other's gaps)
+        // (round 2 wrote the stages out WITHOUT pinning the order and the scheduler put them back: 37.38 vs 37.04 us)
+        if constexpr (EPH_PAIR_STAGED && kPairVariant == 0 && EPH_RCP_SEED_FROM_RSQ) {
+            double mus[2 * NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { mus[b] = pa.mu; mus[NB + b] = pb.mu; }
+            pair_finish_staged<2 * NB>(pre, mus, c);
+        } else {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             pair_finish<true>(pre[b], pa.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
             pair_finish<true>(pre[NB + b], pb.mu, c[3 * (NB + b)], c[3 * (NB + b) + 1], c[3 * (NB + b) + 2]);
+        }
         }
         // (writing each interaction's three values as soon as they exist, instead of the burst below, was measured too:
         // 36.9 vs 37.0 us, although SQ_LDS_DATA_FIFO_FULL is raised 13 % of the time -- profiles/r02_pmc2.json)
