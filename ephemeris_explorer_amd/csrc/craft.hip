@@ -29,6 +29,8 @@ struct BodyEntry {            // one massive body's UniformSpline on the device
     long long npoly;
     long long coeff_off;      // index of polynomial 0 in the coefficient / ncoef arrays
     double span;              // interval * (double)npoly, the product UniformSpline::span() forms on every lookup
+    double rinv;              // rcp_refined(interval), filled on the device (k_body_reciprocals); +0.0 = the interval is out of
+    double pad_;              //   range for the wrapper-free division (device_math.h in_range_div): use the compiler's
 };
 struct SegmentDev {           // Segment<DVec3, ReferenceFrame>
     double start, end;
@@ -166,10 +168,17 @@ __device__ __forceinline__ bool spline_locate(const BodyEntry &b, double at, lon
 // UniformSpline::get_polynomial for the sweep kernels: the span product comes precomputed with the table entry and
 // the f64 <-> u64 conversions take the one-instruction 32-bit forms when every lane's segment count fits (always, in
 // practice); same values as spline_locate.
+__device__ __forceinline__ bool locate_quot_ok(double a) {   // numerator usable by div_refined: +-0 or in in_range_div
+    return a == 0.0 || in_range_div(a);
+}
 __device__ __forceinline__ bool spline_locate_fast(const BodyEntry &b, double at, long long &idx, double &tau) {
     const double local = at - b.start;
     if (__builtin_signbit(local) || local > b.span) return false;
-    const double c = ceil(local / b.interval);
+    // the two divisions by the interval share its refined reciprocal (table entry, wave-uniform) whenever the wrappers of the
+    // compiler's division would have been no-ops for every lane: the same quotients, 6 operations instead of 24 + two v_rcp_f64
+    const bool shared = __double_as_longlong(b.rinv) != 0;
+    const bool fast1 = shared && __builtin_amdgcn_ballot_w64(!locate_quot_ok(local)) == 0;
+    const double c = ceil(fast1 ? div_refined(local, b.interval, b.rinv) : local / b.interval);
     unsigned long long i;
     double fi;
     if (__builtin_amdgcn_ballot_w64(!(c < 2147483648.0)) == 0) {      // also false for NaN
@@ -184,10 +193,24 @@ __device__ __forceinline__ bool spline_locate_fast(const BodyEntry &b, double at
     }
     if (i >= (unsigned long long)b.npoly) return false;
     idx = (long long)i;
-    tau = (local - b.interval * fi) / b.interval;
+    const double rem = local - b.interval * fi;
+    const bool fast2 = shared && __builtin_amdgcn_ballot_w64(!locate_quot_ok(rem)) == 0;
+    tau = fast2 ? div_refined(rem, b.interval, b.rinv) : rem / b.interval;
     return true;
 }
 
+// the reciprocal of every body's spline interval, formed once where the sweep kernels would form it (same instructions as
+// LaneBody::r): the table entry carries it to spline_locate_fast
+__global__ void k_body_reciprocals(int n, BodyEntry *bodies) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const double iv = bodies[b].interval;
+    bodies[b].rinv = in_range_div(iv) ? rcp_refined(iv) : 0.0;
+}
+
+#ifndef EPH_CRAFT_SCALAR_ROWS
+#define EPH_CRAFT_SCALAR_ROWS 1
+#endif
 // One body's term of Bodies::acceleration (dynamics/spacecraft.rs:70-74,222-228): segment lookup, Horner, point mass.
 __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &be, double t, const V3 &pos, V3 &term) {
     long long idx;
@@ -196,16 +219,31 @@ __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &b
     // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so
     // the leading steps give 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no
     // ncoef load, no loop, and twelve 16-byte loads in flight at once
-    const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (be.coeff_off + idx) * kDiv * 3);
-    double c[kDiv * 3];
-#pragma unroll
-    for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
     V3 bp = {0.0, 0.0, 0.0};
+    const long long row = be.coeff_off + idx;         // (in the wave-per-craft form of > 64 bodies the lanes differ in be too)
+    const long long row0 = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)row) |
+                           ((long long)__builtin_amdgcn_readfirstlane((int)(row >> 32)) << 32);
+    if (EPH_CRAFT_SCALAR_ROWS && __builtin_amdgcn_ballot_w64(row != row0) == 0) {
+        // every lane of the wave is inside the SAME polynomial (craft of one sweep started together: the usual case): its 24
+        // coefficients come through the scalar cache into SGPRs instead of 64 lanes x 192 B through the vector L1
+        const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(a.coeffs + row0 * kDiv * 3);
 #pragma unroll
-    for (int k = kDiv - 1; k >= 0; --k) {
-        bp.x = bp.x * tau + c[k * 3 + 0];
-        bp.y = bp.y * tau + c[k * 3 + 1];
-        bp.z = bp.z * tau + c[k * 3 + 2];
+        for (int k = kDiv - 1; k >= 0; --k) {
+            bp.x = bp.x * tau + cs[k * 3 + 0];
+            bp.y = bp.y * tau + cs[k * 3 + 1];
+            bp.z = bp.z * tau + cs[k * 3 + 2];
+        }
+    } else {
+        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + row * kDiv * 3);
+        double c[kDiv * 3];
+#pragma unroll
+        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
+#pragma unroll
+        for (int k = kDiv - 1; k >= 0; --k) {
+            bp.x = bp.x * tau + c[k * 3 + 0];
+            bp.y = bp.y * tau + c[k * 3 + 1];
+            bp.z = bp.z * tau + c[k * 3 + 2];
+        }
     }
     const V3 d = sub(bp, pos);                        // acceleration_at::<false>: dir = body - at
     const double n2 = dot(d, d);
@@ -335,7 +373,7 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
             BodyEntry be;
             be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
-            be.coeff_off = bc->coeff_off; be.span = bc->span;
+            be.coeff_off = bc->coeff_off; be.span = bc->span; be.rinv = bc->rinv;
             V3 term;
             if (!body_term(a, be, t, pos, term)) return false;
             acc = add(acc, term);
@@ -1695,7 +1733,7 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
         for (int b = 0; b < nb; ++b) {
             const UniformSpline &u = s->s.splines[b];
             BodyEntry be{u.start, u.interval, mu[b], (long long)u.polynomials.size(), total,
-                         u.interval * (double)u.polynomials.size()};
+                         u.interval * (double)u.polynomials.size(), 0.0, 0.0};
             e->host_bodies.push_back(be);
             total += be.npoly;
         }
@@ -1711,7 +1749,12 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
             }
         if ((st = e->bodies.alloc(std::max(nb, 1))) || (st = e->coeffs.alloc(co.size())) || (st = e->ncoef.alloc(nc.size())))
             return st;
-        if (nb) EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * nb, hipMemcpyHostToDevice));
+        if (nb) {
+            EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * nb, hipMemcpyHostToDevice));
+            k_body_reciprocals<<<(nb + 63) / 64, 64>>>(nb, e->bodies.p);
+            EPH_HIP(hipGetLastError());
+            EPH_HIP(hipDeviceSynchronize());
+        }
         EPH_HIP(hipMemcpy(e->coeffs.p, co.data(), sizeof(double) * co.size(), hipMemcpyHostToDevice));
         EPH_HIP(hipMemcpy(e->ncoef.p, nc.data(), sizeof(int) * nc.size(), hipMemcpyHostToDevice));
         e->host_coeffs = std::move(co);
