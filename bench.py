@@ -225,6 +225,28 @@ def craft_main(args):
                                                  for f in sorted(set(family[lo:hi].tolist()))}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = craft_cpu_baseline(s, ship, pos, vel, t_end, args.craft_days)
+    if want_strong:
+        # The strong-scaling leg runs AFTER the main line is complete and under a watchdog: a transport that hangs on hardware
+        # it has never met (instead of raising) must not cost the run its number. On expiry rank 0 prints the line with the
+        # leg marked as timed out and every rank leaves without waiting for the others.
+        import threading
+        limit = float(os.environ.get("EPH_BENCH_SHARDED_TIMEOUT", "240"))
+
+        def expired():
+            if rank == 0:
+                out["sharded_4096"] = {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(limit + (0.0 if rank == 0 else 5.0), expired)
+        dog.daemon = True
+        dog.start()
+        strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+        dog.cancel()
+        if rank == 0:
+            strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
+            out["sharded_4096"] = strong
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -464,9 +486,8 @@ def main():
     _, t_min = reduce_timing(blocks[0], 0, dist, device="cuda")
     _, t_max = reduce_timing(blocks[-1], 0, dist, device="cuda")
     ms_kernel, launches = g.kernel_time()
-    strong = None
-    if world > 1 and not sharded and not fast and n == N_BODIES:
-        strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+    want_strong = world > 1 and not sharded and not fast and n == N_BODIES
+    out = None
 
     if rank == 0:
         value = units / elapsed
@@ -518,9 +539,6 @@ def main():
                      "unit": "TFLOP/s", "frac": flops / launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "flop_per_launch": flops},
         }
-        if strong is not None:
-            strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
-            out["sharded_4096"] = strong
         if valu_insts:
             # issue-slot view of the same launch: wave64 VALU instructions (SQ_INSTS_VALU of the committed profile) x 64
             # lanes / live launch time, against 256 CU x 4 SIMD x 16 f64 lanes per clock at 2.4 GHz
@@ -576,6 +594,28 @@ def main():
                 hz[str(k)] = float(np.abs(c.state()[0] - ref[f"pos_{k}"]).max())
             out.setdefault("parity", {})["horizon_max_abs_dpos"] = hz
             out["parity"]["horizon_vs"] = "oracle positions, tests/golden/plummer4096_horizon.npz (N-body units: length scale 1)"
+    if want_strong:
+        # The strong-scaling leg runs AFTER the main line is complete and under a watchdog: a transport that hangs on hardware
+        # it has never met (instead of raising) must not cost the run its number. On expiry rank 0 prints the line with the
+        # leg marked as timed out and every rank leaves without waiting for the others.
+        import threading
+        limit = float(os.environ.get("EPH_BENCH_SHARDED_TIMEOUT", "240"))
+
+        def expired():
+            if rank == 0:
+                out["sharded_4096"] = {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(limit + (0.0 if rank == 0 else 5.0), expired)
+        dog.daemon = True
+        dog.start()
+        strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+        dog.cancel()
+        if rank == 0:
+            strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
+            out["sharded_4096"] = strong
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

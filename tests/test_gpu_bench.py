@@ -75,6 +75,20 @@ def test_gpus_flag_without_a_launcher_spawns_its_own_ranks():
     assert s4["ranks"] == 2 and s4["ms_per_step"] > 0 and s4["bit_identical_to_single_device"] is True
 
 
+def test_a_strong_scaling_leg_that_never_returns_does_not_cost_the_line():
+    """The sharded_4096 leg runs after the main line is complete, under a watchdog: with the limit at zero it expires before
+    the leg can finish; rank 0 still prints the one line (the leg marked as timed out) and the job ends with status 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(EPH_BENCH_BACKEND="gloo", EPH_BENCH_SHARDED_TIMEOUT="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--prewarm", "0"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 1e6 and "no result within" in d["sharded_4096"]["error"]
+
+
 @pytest.mark.parametrize("population", ["transfer", "mixed"])
 def test_two_ranks_craft_sweep_with_result_gather(population):
     d = _run(["--workload", "craft", "--craft", "4001", "--craft-days", "0.05", "--steps", "1", "--prewarm", "0",
