@@ -241,7 +241,13 @@ def craft_main(args):
         dog = threading.Timer(limit + (0.0 if rank == 0 else 5.0), expired)
         dog.daemon = True
         dog.start()
-        strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+        try:
+            strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+        except BaseException as e:                       # (a peer gone, a collective torn down: the group is not usable any more)
+            if rank == 0:
+                out["sharded_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
         dog.cancel()
         if rank == 0:
             strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
@@ -610,7 +616,13 @@ def main():
         dog = threading.Timer(limit + (0.0 if rank == 0 else 5.0), expired)
         dog.daemon = True
         dog.start()
-        strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+        try:
+            strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+        except BaseException as e:                       # (a peer gone, a collective torn down: the group is not usable any more)
+            if rank == 0:
+                out["sharded_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
         dog.cancel()
         if rank == 0:
             strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
