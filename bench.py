@@ -225,34 +225,6 @@ def craft_main(args):
                                                  for f in sorted(set(family[lo:hi].tolist()))}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = craft_cpu_baseline(s, ship, pos, vel, t_end, args.craft_days)
-    if want_strong:
-        # The strong-scaling leg runs AFTER the main line is complete and under a watchdog: a transport that hangs on hardware
-        # it has never met (instead of raising) must not cost the run its number. On expiry rank 0 prints the line with the
-        # leg marked as timed out and every rank leaves without waiting for the others.
-        import threading
-        limit = float(os.environ.get("EPH_BENCH_SHARDED_TIMEOUT", "240"))
-
-        def expired():
-            if rank == 0:
-                out["sharded_4096"] = {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(limit + (0.0 if rank == 0 else 5.0), expired)
-        dog.daemon = True
-        dog.start()
-        try:
-            strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
-        except BaseException as e:                       # (a peer gone, a collective torn down: the group is not usable any more)
-            if rank == 0:
-                out["sharded_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        dog.cancel()
-        if rank == 0:
-            strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
-            out["sharded_4096"] = strong
-    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
