@@ -1053,8 +1053,11 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
             default: break;
         }
     }
-    if (dbg & 8) __builtin_amdgcn_s_setprio(3);        // tuning: chain wave ahead of the pair wave(s) on its SIMD
-    // chain wave (raising its priority with s_setprio was measured in layout 0: 4-5 us slower per evaluation)
+    // chain wave. Its dependent adds issue ahead of the one-body pair wave of its SIMD in the twelve-wave layout (s_setprio; the
+    // same library with and without, alternating on one box: 36.3 against 36.8 us per step at N = 4096 on two boxes of the pool,
+    // 36.2 either way on a third; nothing at the chain-bound sizes; layout 6 39.4 -> 37.9, still behind -- SIMD 0 has no room for
+    // a second body either way. In layout 0 the same priority was 4-5 us SLOWER per evaluation.)
+    if (LAYOUT == 5 || (dbg & 8)) __builtin_amdgcn_s_setprio(3);
     const int ch = lane < kRows ? lane : kRows - 1;
     const double *row = C + ch * kRow;
     const int gself = (i0 % kTile) / WB;
