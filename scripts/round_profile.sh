@@ -15,6 +15,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > 
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $OUT -o pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT -o pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
+if [ "${LITE:-0}" = "1" ]; then          # (usage: LITE=1 scripts/round_profile.sh r03 -- the default line and its counters only)
+  rm -f $OUT/*_agent_info.csv $OUT/*kernel_trace.csv.bak $OUT/*_kernel_trace.csv
+  cat $OUT/bench.json
+  exit 0
+fi
 # the other bench lines of the round + their kernel stats
 cd $GRAFT_REPO_ROOT
 python bench.py --path fast > $OUT/bench_fast.json 2> $OUT/bench_fast.err
