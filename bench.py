@@ -308,6 +308,43 @@ def sharded_4096(dist, world, rank, steps, backend_is_nccl):
     return out
 
 
+def other_configs():
+    """The default line's companions, taken AFTER the headline measurement is complete (N = 1 only) so that one driver command
+    records them too: BASELINE.json configs[1] -- the reference's shipping system, full_solar_system (32 bodies), 1e6 steps of the
+    propagator with its solout and every least-squares fit, in this process -- and configs[3], the massless sweep, as a child
+    process of this file (`--workload craft`) under a time limit. Neither can cost the headline: failures are recorded."""
+    import subprocess
+    out = {}
+    try:
+        import ephemeris_explorer_amd as ea
+        from ephemeris_explorer_amd.systems import load_system
+        s = load_system(ROOT / "tests/golden/systems/full_solar_system_2433282.5")
+        p = ea.NBodyPropagator.from_system(s)
+        p.step_n(20000)                                  # start-up + clock
+        t = time.perf_counter()
+        p.step_n(1_000_000)
+        w = time.perf_counter() - t
+        out["configs1_full_solar_system"] = {"bodies": int(s.n), "steps": 1000000, "seconds": w, "us_per_step": w / 1e6 * 1e6,
+                                             "body_steps_per_s": s.n * 1e6 / w,
+                                             "includes": "k_lm_small steps + solout sampling + every least-squares fit"}
+    except Exception as e:
+        out["configs1_full_solar_system"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--workload", "craft", "--steps", "3",
+                            "--no-cpu-baseline", "--no-other-configs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           text=True, timeout=float(os.environ.get("EPH_BENCH_CRAFT_TIMEOUT", "240")))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+        d = json.loads(line)
+        out["configs3_craft_sweep"] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                                       "workload": d["config"]["workload"], "kernel": d["roofline"]["kernel"],
+                                       "launch_us": d["roofline"]["launch_us"], "fp64_frac": d["fp64"]["frac"],
+                                       "divergence": d["divergence"]["attempts_max_over_mean_per_wave"]}
+    except Exception as e:
+        out["configs3_craft_sweep"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher environment: become the launcher -- one rank per GPU through
     torch.distributed.run on 127.0.0.1 with a free port -- and pass rank 0's single JSON line through."""
@@ -353,6 +390,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-steps", type=int, default=60, help="oracle steps timed for cpu_baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the companions of the default line (configs[1] in-process, the configs[3] sweep as a child process)")
     ap.add_argument("--bodies", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--workload", choices=["nbody", "craft", "nbody-sharded"], default="nbody",
                     help="nbody (default, the BASELINE metric: per-rank replicas) | craft: the massless sweep of "
@@ -599,6 +638,9 @@ def main():
         if rank == 0:
             strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
             out["sharded_4096"] = strong
+    if (rank == 0 and world == 1 and n == N_BODIES and not sharded and not fast and not args.no_cpu_baseline
+            and not args.no_other_configs):
+        out["other_configs"] = other_configs()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

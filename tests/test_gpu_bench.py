@@ -51,6 +51,10 @@ def test_default_line_single_gpu():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"]
     assert "plummer_4096_f64_qt12" in d["config"]["workload"]
+    # the companions of the default line: configs[1] in-process, the configs[3] sweep from a child process
+    oc = d["other_configs"]
+    assert oc["configs1_full_solar_system"]["bodies"] == 32 and 0.1 < oc["configs1_full_solar_system"]["us_per_step"] < 5.0
+    assert oc["configs3_craft_sweep"]["value"] > 1e7 and "craft" in oc["configs3_craft_sweep"]["workload"]
 
 
 def test_two_ranks_replicas():
