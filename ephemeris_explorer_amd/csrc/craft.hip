@@ -60,6 +60,8 @@ struct CraftArgs {
     double t_end;
     unsigned step_limit;      // accepted steps this call may take per craft (0 = until t_end)
     unsigned long long *queue;   // k_craft_propagate's work queue: the next craft nobody has started (set by craft_launch)
+    const int *perm;             // lane / queue position -> craft (null: identity). Heterogeneous batches: craft sorted by their
+                                 // dynamical time at creation, so that the lanes of a wave carry craft of similar step counts
 };
 
 struct V3 { double x, y, z; };
@@ -441,8 +443,9 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
 template <int S, bool FSAL, bool NYS = false, int OCC = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 k_craft_propagate(const CraftArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_craft) return;
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_craft) return;
+    const long long i = a.perm ? a.perm[slot] : slot;
     const long long n = a.n_craft;
     int status = a.status[i];
     if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
@@ -525,9 +528,9 @@ k_craft_propagate(const CraftArgs a) {
         steps += 1;
         taken += 1;
         // CubicHermiteSplineSolout::solout: push (t, r, v)
-        a.knot_t[(long long)nk * n + i] = time;
+        a.knot_t[(long long)nk * n + slot] = time;      // (knot slabs are in LANE order: coalesced whatever the deal)
 #pragma unroll
-        for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + i] = y[d];
+        for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + slot] = y[d];
         nk += 1;
         last_knot = time;
     }
@@ -564,7 +567,9 @@ template <int S, bool FSAL, bool NYS = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_craft_queue(const CraftArgs a) {
     const long long n = a.n_craft;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // queue position = the craft's column in the knot slabs
+    const bool first_in_range = col < n;
+    long long i = first_in_range && a.perm ? a.perm[col] : col;       // the craft at it
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
 
     // the craft this lane is integrating (registers); `have` = it still has work in this call
@@ -621,13 +626,14 @@ k_craft_queue(const CraftArgs a) {
         }
     };
 
-    bool have = i < n && load();
-    bool drained = i >= n;                              // this lane will get no more craft
+    bool have = first_in_range && load();
+    bool drained = !first_in_range;                     // this lane will get no more craft
     for (;;) {
         // ---- lanes without work take the next craft from the queue
         while (!have && !drained) {
-            i = (long long)atomicAdd(a.queue, 1ull);
-            if (i >= n) { drained = true; break; }
+            col = (long long)atomicAdd(a.queue, 1ull);
+            if (col >= n) { drained = true; break; }
+            i = a.perm ? a.perm[col] : col;
             have = load();
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0) break;          // every lane of the wave is out of work
@@ -692,9 +698,9 @@ k_craft_queue(const CraftArgs a) {
                 // accepted. CubicHermiteSplineSolout::solout: push (t, r, v)
                 steps += 1;
                 taken += 1;
-                a.knot_t[(long long)nk * n + i] = time;
+                a.knot_t[(long long)nk * n + col] = time;
 #pragma unroll
-                for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + i] = y[d];
+                for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + col] = y[d];
                 nk += 1;
                 last_knot = time;
                 in_step = false;
@@ -952,6 +958,7 @@ struct EventArgs {
     double *tr_time; int *tr_body;                              // [max_tr][n]
     double *ap_time, *ap_dist; int *ap_body, *ap_kind;          // [max_ap][n]
     int max_tr, max_ap;
+    const int *slot_of;           // craft -> its column in the knot slabs (null: identity)
 };
 struct Hermite { double b0; V3 a0, a1, a2, a3; };
 __device__ __forceinline__ V3 hermite_pos(const Hermite &h, double t) {      // CubicHermite::eval  trajectory.rs:681-688
@@ -1116,10 +1123,11 @@ __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
     int seg = a.ev_seg[i], ntr = a.ntr[i], nap = a.nap[i];
     const int nk = a.nknots[i];
     bool full = false;
-    auto knot = [&](int k, int d) { return a.knot_y[((long long)k * 6 + d) * n + i]; };
+    const long long col = a.slot_of ? a.slot_of[i] : i;
+    auto knot = [&](int k, int d) { return a.knot_y[((long long)k * 6 + d) * n + col]; };
     if (seg < 0) {                                    // new_solution :525-537: the sphere the craft starts in
-        const int cur = soi_at_except(a, a.knot_t[i], V3{knot(0, 0), knot(0, 1), knot(0, 2)}, -1);
-        if (cur >= 0) full = !tr_insert(a, i, ntr, a.knot_t[i], cur);
+        const int cur = soi_at_except(a, a.knot_t[col], V3{knot(0, 0), knot(0, 1), knot(0, 2)}, -1);
+        if (cur >= 0) full = !tr_insert(a, i, ntr, a.knot_t[col], cur);
         seg = 0;
     }
     for (; !full && seg + 1 < nk; ++seg) {            // solout :539-586 for the step that produced knot seg + 1
@@ -1127,7 +1135,7 @@ __global__ void __launch_bounds__(64) k_craft_events(const EventArgs a) {
         // (eph_craft_batch_reset_events) resumes exactly at a step; a step needing more than that (several
         // crossings at once into a nearly full slab) still reports EVENTS_FULL, from inside the step
         if (ntr + 2 > a.max_tr || nap + 2 > a.max_ap) { full = true; break; }
-        const double t0 = a.knot_t[(long long)seg * n + i], t1 = a.knot_t[(long long)(seg + 1) * n + i];
+        const double t0 = a.knot_t[(long long)seg * n + col], t1 = a.knot_t[(long long)(seg + 1) * n + col];
         const V3 p0 = {knot(seg, 0), knot(seg, 1), knot(seg, 2)}, d0 = {knot(seg, 3), knot(seg, 4), knot(seg, 5)};
         const V3 p1 = {knot(seg + 1, 0), knot(seg + 1, 1), knot(seg + 1, 2)};
         const V3 d1 = {knot(seg + 1, 3), knot(seg + 1, 4), knot(seg + 1, 5)};
@@ -1224,14 +1232,15 @@ __global__ void __launch_bounds__(256) k_craft_reset_events(long long n, int *nt
 // CubicHermiteSpline piece starts where the drained one ended), a KNOTS_FULL status is cleared, and the event
 // search's segment cursor moves with the knots.
 __global__ void __launch_bounds__(256) k_craft_reset_knots(long long n, int *nknots, int *status, double *knot_t,
-                                                           double *knot_y, int *ev_seg) {
+                                                           double *knot_y, int *ev_seg, const int *slot_of) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const long long col = slot_of ? slot_of[i] : i;
     const int nk = nknots[i];
     if (nk > 1) {
-        knot_t[i] = knot_t[(long long)(nk - 1) * n + i];
+        knot_t[col] = knot_t[(long long)(nk - 1) * n + col];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) knot_y[(long long)d * n + i] = knot_y[((long long)(nk - 1) * 6 + d) * n + i];
+        for (int d = 0; d < 6; ++d) knot_y[(long long)d * n + col] = knot_y[((long long)(nk - 1) * 6 + d) * n + col];
         nknots[i] = 1;
         if (ev_seg && ev_seg[i] >= 0) ev_seg[i] = max(ev_seg[i] - (nk - 1), 0);
     }
@@ -1548,7 +1557,8 @@ static int craft_launch(hipStream_t s, const CraftArgs &a, bool heterogeneous) {
     // the static form is the faster one (see k_craft_queue). `heterogeneous` is eph_craft_batch_create's estimate from the
     // initial states; EPH_CRAFT_QUEUE=0|1 overrides (tuning, tests).
     static const int forced_q = [] { const char *e = getenv("EPH_CRAFT_QUEUE"); return !e || !*e ? -1 : (e[0] == '0' ? 0 : 1); }();
-    const bool queue = forced_q >= 0 ? forced_q == 1 : (heterogeneous && waves > 2 * simds);
+    // (a batch whose craft were dealt to the lanes by dynamical time -- a.perm -- has waves of similar craft: the static form)
+    const bool queue = forced_q >= 0 ? forced_q == 1 : (heterogeneous && !a.perm && waves > 2 * simds);
     if (queue) {
         const long long resident = std::min(waves, 2 * simds);
         const dim3 grid((unsigned)resident), block(64);
@@ -1629,6 +1639,8 @@ struct eph_craft_batch {
     DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (allocated on first use)
     DevBuf<unsigned long long> queue;         // k_craft_queue's work queue (one counter)
     bool heterogeneous = false;               // the craft's dynamical time scales differ widely (craft_time_scales): queue form
+    DevBuf<int> perm, slot_of;                // heterogeneous batches: lane / queue position -> craft by dynamical time, and back
+    std::vector<int> h_slot;                  //   (craft_sort); the knot slabs' columns are lane positions
     // SpacecraftSolout events (optional)
     bool events = false;
     int max_tr = 0, max_ap = 0;
@@ -1654,6 +1666,112 @@ struct eph_craft_batch {
 // a heliocentric cruise 5e6 s. Families in contiguous blocks do NOT count (measured: the static kernel is then the
 // faster one, 183 against 213 ms -- the hardware's wave dispatch already is a queue of whole waves); craft_launch uses
 // the answer to pick k_craft_queue over the static kernel.
+// A work estimate per craft for the deal of craft to lanes: the time scale of its ORBIT about its dominant body (the body with
+// the smallest local dynamical time sqrt(d^3 / mu)) -- sqrt(a^3 / mu) with the semi-major axis a from the vis-viva energy of the
+// relative state when the orbit is bound, 16 x the local value when it is not (a fly-by leaves the body quickly). The LOCAL time
+// alone mixes families exactly where the work is: a transfer orbit at perigee and a departing lunar transfer look like a low
+// circular orbit (measured: dealing by it, 452 ms against the queue kernel's 347 on the mixed population).
+__global__ void __launch_bounds__(256) k_craft_tau(long long n, int n_bodies, const BodyEntry *__restrict__ bodies,
+                                                   const double *__restrict__ coeffs, const double *__restrict__ time,
+                                                   const double *__restrict__ y, float *__restrict__ tau) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = time[i], px = y[i], py = y[n + i], pz = y[2 * n + i];
+    const double vx = y[3 * n + i], vy = y[4 * n + i], vz = y[5 * n + i];
+    double best = INFINITY, orbit = INFINITY;
+    for (int b = 0; b < n_bodies; ++b) {
+        const BodyEntry be = bodies[b];
+        if (!(be.mu > 0.0) || be.npoly <= 0) continue;
+        long long idx;
+        double tq;
+        if (!spline_locate(be, t, idx, tq)) continue;
+        const double *c = coeffs + (be.coeff_off + idx) * kDiv * 3;
+        double bp[3] = {0.0, 0.0, 0.0}, bd[3] = {0.0, 0.0, 0.0};
+        for (int k = kDiv - 1; k >= 0; --k)
+            for (int d = 0; d < 3; ++d) {
+                bd[d] = bd[d] * tq + bp[d];               // derivative with respect to tau, then / interval
+                bp[d] = bp[d] * tq + c[k * 3 + d];
+            }
+        const double dx = px - bp[0], dy = py - bp[1], dz = pz - bp[2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        const double local = sqrt(d2 * sqrt(d2) / be.mu);
+        if (local < best) {
+            best = local;
+            const double ux = vx - bd[0] / be.interval, uy = vy - bd[1] / be.interval, uz = vz - bd[2] / be.interval;
+            const double energy = 0.5 * (ux * ux + uy * uy + uz * uz) - be.mu / sqrt(d2);
+            if (energy < 0.0) {
+                const double sma = -be.mu / (2.0 * energy);
+                orbit = sqrt(sma * sma * sma / be.mu);
+            } else {
+                orbit = 16.0 * local;
+            }
+        }
+    }
+    tau[i] = (float)orbit;
+}
+__global__ void __launch_bounds__(256) k_knot0_to_lanes(long long n, const int *__restrict__ perm, const double *__restrict__ time,
+                                                        const double *__restrict__ y, double *__restrict__ knot_t,
+                                                        double *__restrict__ knot_y) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const long long i = perm[q];
+    knot_t[q] = time[i];
+    for (int d = 0; d < 6; ++d) knot_y[(long long)d * n + q] = y[(long long)d * n + i];
+}
+// rows of a [rows][n] slab from lane order back to craft order (eph_craft_batch_knot_slabs of a sorted batch)
+__global__ void __launch_bounds__(256) k_rows_to_craft_order(long long rows, long long n, const int *__restrict__ slot_of,
+                                                             const double *__restrict__ src, double *__restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long col = slot_of[i];
+    for (long long r = 0; r < rows; ++r) dst[r * n + i] = src[r * n + col];
+}
+// Heterogeneous batches (craft_time_scales_differ): which craft a lane integrates is free (craft are independent, every craft's
+// operations are the reference's whoever runs them), so the craft are dealt to the lanes in the order of their dynamical time --
+// a counting sort of k_craft_tau's estimate into eighths of an octave, shortest first (most steps first). The lanes of a wave then carry craft of similar
+// step counts, which is what the families-in-blocks order had and the interleaved order lacked (184 against 343 ms for the same
+// population: profiles/r03_craft_queue.md). EPH_CRAFT_SORT=0 switches it off (tuning, tests).
+static int craft_sort(eph_craft_batch *b) {
+    static const bool on = [] { const char *e = getenv("EPH_CRAFT_SORT"); return !(e && e[0] == '0'); }();
+    const long long n = b->n;
+    if (!on || n < 128 || n > 0x7fffffffLL) return EPH_OK;
+    DevBuf<float> tau;
+    int st = tau.alloc((size_t)n);
+    if (st) return st;
+    hipLaunchKernelGGL(k_craft_tau, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, b->eph->n_bodies, b->eph->bodies.p,
+                       b->eph->coeffs.p, b->time.p, b->y.p, tau.p);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { set_last_error("k_craft_tau", he); return EPH_ERR_HIP; }
+    std::vector<float> h((size_t)n);
+    EPH_HIP(hipMemcpyAsync(h.data(), tau.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    EPH_HIP(hipStreamSynchronize(b->stream));
+    constexpr int kBuckets = 1024;                      // eighths of an octave from 2^-32 s to 2^96 s; the rest at the ends
+    auto bucket = [&](float v) {
+        if (!(v > 0.0f)) return 0;
+        if (!std::isfinite(v)) return kBuckets - 1;
+        const int q = (int)std::floor(8.0f * std::log2(v)) + 256;
+        return std::min(std::max(q, 0), kBuckets - 1);
+    };
+    std::vector<long long> start(kBuckets + 1, 0);
+    for (long long i = 0; i < n; ++i) start[bucket(h[(size_t)i]) + 1] += 1;
+    for (int q = 0; q < kBuckets; ++q) start[q + 1] += start[q];
+    std::vector<int> perm((size_t)n);
+    for (long long i = 0; i < n; ++i) perm[(size_t)start[bucket(h[(size_t)i])]++] = (int)i;   // stable: craft order inside a bucket
+    std::vector<int> slot((size_t)n);
+    for (long long q = 0; q < n; ++q) slot[(size_t)perm[(size_t)q]] = (int)q;
+    if ((st = b->perm.alloc((size_t)n)) || (st = b->slot_of.alloc((size_t)n))) return st;
+    EPH_HIP(hipMemcpy(b->perm.p, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    EPH_HIP(hipMemcpy(b->slot_of.p, slot.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    b->h_slot = std::move(slot);
+    // knot 0 (the initial state, uploaded in craft order) moves to the lanes' columns
+    hipLaunchKernelGGL(k_knot0_to_lanes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, b->perm.p, b->time.p, b->y.p,
+                       b->knot_t.p, b->knot_y.p);
+    he = hipGetLastError();
+    if (he != hipSuccess) { set_last_error("k_knot0_to_lanes", he); return EPH_ERR_HIP; }
+    EPH_HIP(hipStreamSynchronize(b->stream));
+    return EPH_OK;
+}
+
 static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const double *t0, const double *pos) {
     if (n < 128 || e.host_coeffs.empty()) return false;
     auto tau_of = [&](long long i) {
@@ -1891,6 +2009,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             EPH_HIP(hipMemcpy(b->knot_t.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
             EPH_HIP(hipMemcpy(b->knot_y.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
             b->heterogeneous = craft_time_scales_differ(*e, n, t0, pos);
+            if (b->heterogeneous && !craft_wave_form(n) && (st = craft_sort(b.get()))) return st;
         }
         *out = b.release();
         return EPH_OK;
@@ -1925,6 +2044,7 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
     a.t_end = t_end;
     a.step_limit = step_limit;
     a.queue = b->queue.p;
+    a.perm = b->perm.p;
     EPH_HIP(hipEventRecord(b->ev0, b->stream));
     int st = craft_launch(b->stream, a, b->heterogeneous);
     if (st) return st;
@@ -1937,6 +2057,7 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
         e.tr_time = b->tr_time.p; e.tr_body = b->tr_body.p;
         e.ap_time = b->ap_time.p; e.ap_dist = b->ap_dist.p; e.ap_body = b->ap_body.p; e.ap_kind = b->ap_kind.p;
         e.max_tr = b->max_tr; e.max_ap = b->max_ap;
+        e.slot_of = b->slot_of.p;
         if (craft_wave_form(b->n)) hipLaunchKernelGGL(k_craft_events<true>, dim3((unsigned)b->n), dim3(64), 0, b->stream, e);
         else hipLaunchKernelGGL(k_craft_events<false>, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, b->stream, e);
         hipError_t he = hipGetLastError();
@@ -2020,12 +2141,13 @@ int32_t eph_craft_batch_knots(eph_craft_batch *b, int64_t craft, double *t, doub
     int nk = 0;
     EPH_HIP(hipMemcpy(&nk, b->nknots.p + craft, sizeof(int), hipMemcpyDeviceToHost));
     const long long n = b->n;
-    // strided gather: knot k of craft i sits at [k*n + i]
-    if (t) EPH_HIP(hipMemcpy2D(t, sizeof(double), b->knot_t.p + craft, sizeof(double) * n, sizeof(double), nk,
+    const long long col = b->h_slot.empty() ? craft : b->h_slot[(size_t)craft];
+    // strided gather: knot k of craft i sits at [k*n + col(i)] (col = i unless the batch was dealt to the lanes by craft_sort)
+    if (t) EPH_HIP(hipMemcpy2D(t, sizeof(double), b->knot_t.p + col, sizeof(double) * n, sizeof(double), nk,
                                hipMemcpyDeviceToHost));
     if (pos || vel) {
         std::vector<double> y((size_t)nk * 6);
-        EPH_HIP(hipMemcpy2D(y.data(), sizeof(double), b->knot_y.p + craft, sizeof(double) * n, sizeof(double),
+        EPH_HIP(hipMemcpy2D(y.data(), sizeof(double), b->knot_y.p + col, sizeof(double) * n, sizeof(double),
                             (size_t)nk * 6, hipMemcpyDeviceToHost));
         for (int k = 0; k < nk; ++k)
             for (int d = 0; d < 3; ++d) {
@@ -2133,7 +2255,7 @@ int32_t eph_craft_batch_reset_knots(eph_craft_batch *b) {
     if (b->n == 0) return EPH_OK;
     EPH_HIP(hipSetDevice(b->device));
     hipLaunchKernelGGL(k_craft_reset_knots, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->stream, b->n,
-                       b->nknots.p, b->status.p, b->knot_t.p, b->knot_y.p, b->events ? b->ev_seg.p : nullptr);
+                       b->nknots.p, b->status.p, b->knot_t.p, b->knot_y.p, b->events ? b->ev_seg.p : nullptr, b->slot_of.p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("k_craft_reset_knots", e); return EPH_ERR_HIP; }
     EPH_HIP(hipStreamSynchronize(b->stream));
@@ -2170,8 +2292,9 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
             (st = clone_buf(b->ntr, c->ntr, s)) || (st = clone_buf(b->nap, c->nap, s)) ||
             (st = clone_buf(b->ev_status, c->ev_status, s)) || (st = clone_buf(b->tr_body, c->tr_body, s)) ||
             (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)) ||
-            (st = c->queue.alloc(1)))
+            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = c->queue.alloc(1)))
             return st;
+        c->h_slot = b->h_slot;
         EPH_HIP(hipStreamSynchronize(s));
         *out = c.release();
         return EPH_OK;
@@ -2184,6 +2307,24 @@ int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32
     if (b->n == 0 || n_knots == 0) return EPH_OK;
     EPH_HIP(hipSetDevice(b->device));
     const size_t n = (size_t)b->n;
+    if (!b->h_slot.empty()) {                           // lane order -> craft order on the device, then one copy each
+        for (int part = 0; part < 2; ++part) {
+            double *dst = part == 0 ? knot_t : knot_y;
+            if (!dst) continue;
+            const long long rows = (long long)n_knots * (part == 0 ? 1 : 6);
+            const double *src = part == 0 ? b->knot_t.p + (size_t)first_knot * n : b->knot_y.p + (size_t)first_knot * 6 * n;
+            DevBuf<double> tmp;
+            int st = tmp.alloc((size_t)rows * n);
+            if (st) return st;
+            hipLaunchKernelGGL(k_rows_to_craft_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, rows, (long long)n,
+                               b->slot_of.p, src, tmp.p);
+            hipError_t he = hipGetLastError();
+            if (he != hipSuccess) { set_last_error("k_rows_to_craft_order", he); return EPH_ERR_HIP; }
+            EPH_HIP(hipMemcpyAsync(dst, tmp.p, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToHost, b->stream));
+            EPH_HIP(hipStreamSynchronize(b->stream));
+        }
+        return EPH_OK;
+    }
     if (knot_t)
         EPH_HIP(hipMemcpy(knot_t, b->knot_t.p + (size_t)first_knot * n, sizeof(double) * n * n_knots, hipMemcpyDeviceToHost));
     if (knot_y)
