@@ -325,7 +325,9 @@ int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_tim
 int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out);
 /* Bulk read of the knot slabs for sweeps (one copy instead of one strided gather per craft): knots first_knot ..
  * first_knot + n_knots - 1 of EVERY craft in the device layout, knot_t[k][craft] and knot_y[k][d][craft] (d = x, y, z,
- * vx, vy, vz); entries at or beyond a craft's nknots are unspecified. Either pointer may be NULL. */
+ * vx, vy, vz); entries at or beyond a craft's nknots are unspecified. Either pointer may be NULL. (A heterogeneous batch
+ * keeps its slabs in the order its craft were dealt to the lanes at creation; this call returns craft order all the same,
+ * through a temporary of the requested size on the device.) */
 int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32_t n_knots, double *knot_t,
                                    double *knot_y);
 /* Flight-plan restart (ephemeris_explorer/src/flight_plan.rs:263-303): Timeline::divergence_time_before
