@@ -546,7 +546,9 @@ n = 6000
 pos, vel, fam = craft_population("mixed", n, s, ship)
 earth = s.names.index("Earth")
 burns = [[(ship.start + 3000.0, ship.start + 3090.0, [2e-4, 1e-4, 0.0], earth)] if i % 7 == 0 else [] for i in range(n)]
+from ephemeris_explorer_amd.systems import soi_radii
 b = ea.SpacecraftBatch(eph, ship.start, pos, vel, sys.argv[3], max_knots=4000, burns=burns)
+b.enable_events(soi_radii(s), max_transitions=16, max_apsides=256)   # the app's solout reads the knot slabs on the device
 b.propagate(ship.start + 0.6 * 86400.0)           # two legs: the second resumes craft from stored state
 b.propagate(ship.start + 1.5 * 86400.0)
 rec = b.summary()
@@ -554,7 +556,24 @@ kt, ky = b.knot_slabs(0, int(rec["nknots"].max()))
 for i in range(n):                                 # entries beyond a craft's knots are unspecified
     kt[rec["nknots"][i]:, i] = 0.0
     ky[rec["nknots"][i]:, :, i] = 0.0
-np.savez(sys.argv[2], rec=rec, kt=kt, ky=ky, pos=pos, vel=vel)
+counts = b.event_counts()
+ev = [np.concatenate([np.asarray(x, dtype=np.float64) for pair in b.events(i, counts) for x in pair]) for i in range(0, n, 37)]
+# a clone taken here, the slab drained on the original, both resumed: single-craft read-out and the newest knots must agree
+c = b.clone()
+b.reset_knots()
+b.propagate(ship.start + 1.6 * 86400.0)
+c.propagate(ship.start + 1.6 * 86400.0)
+rec2, rec2c = b.summary(), c.summary()
+assert rec2["status"].tobytes() == rec2c["status"].tobytes() and rec2["steps"].tobytes() == rec2c["steps"].tobytes()
+tails = []
+for i in range(0, n, 53):
+    tb, pb, vb = b.knots(i)
+    tc, pc, vc = c.knots(i)
+    m = len(tb)
+    assert m >= 1 and np.array_equal(tb, tc[-m:]) and np.array_equal(pb, pc[-m:]) and np.array_equal(vb, vc[-m:]), i
+    tails.append(np.concatenate([tb[-1:], pb[-1], vb[-1]]))
+np.savez(sys.argv[2], rec=rec, kt=kt, ky=ky, pos=pos, vel=vel, ntr=counts[0], nap=counts[1], ev=np.concatenate(ev),
+         tails=np.array(tails))
 '''
 
 
@@ -583,6 +602,9 @@ def test_queue_and_static_sweeps_give_the_same_bits(gpu, tmp_path, method):
     for other in outs[1:]:
         assert a["rec"].tobytes() == other["rec"].tobytes()
         assert np.array_equal(a["kt"], other["kt"]) and np.array_equal(a["ky"], other["ky"])
+        assert np.array_equal(a["ntr"], other["ntr"]) and np.array_equal(a["nap"], other["nap"])
+        assert a["ev"].tobytes() == other["ev"].tobytes() and a["tails"].tobytes() == other["tails"].tobytes()
+    assert a["nap"].sum() > 1000                               # (the low orbits pass many apsides: the search ran)
     steps = a["rec"]["steps"]
     assert steps.max() > 8 * steps.min()                       # the population is what it claims to be
     s = load_system("full_solar_system_2433282.5")
