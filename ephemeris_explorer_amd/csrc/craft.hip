@@ -439,7 +439,9 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
 // slower, 1.03e8 / 1.12e8: every k[][] element then stays live across the loop and the allocator spills more.)
 // The sweep, STATIC form: craft i on thread i for the whole call. The right form when every craft takes about the same
 // number of attempts (the north star's sweep: one transfer arc +- 100 km, max / mean attempts per wave 1.09) or when the
-// batch fits the chip at once; k_craft_queue below is the form for heterogeneous batches (craft_launch chooses).
+// batch fits the chip at once -- which a heterogeneous batch becomes, wave by wave, once its craft are dealt to the lanes by the
+// time scale of their orbits (craft_sort: a.perm; the knot slabs keep lane columns). k_craft_queue below is the form for
+// heterogeneous batches that were not dealt (craft_launch chooses).
 template <int S, bool FSAL, bool NYS = false, int OCC = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 k_craft_propagate(const CraftArgs a) {
