@@ -28,7 +28,9 @@ python bench.py --path f32-pairs > $OUT/bench_f32pairs_4096.json 2> $OUT/bench_f
 python bench.py --bodies 65536 --path f32-pairs --steps 20 --warmup 3 > $OUT/bench_f32pairs.json 2> $OUT/bench_f32pairs.err
 python bench.py --workload craft --steps 3 > $OUT/bench_craft.json 2> $OUT/bench_craft.err
 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 > $OUT/bench_craft_mixed.json 2> $OUT/bench_craft_mixed.err
-EPH_CRAFT_QUEUE=0 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 --no-cpu-baseline > $OUT/bench_craft_mixed_static.json 2> $OUT/bench_craft_mixed_static.err
+# the same population with craft i on lane / queue position i: the work-queue kernel, and round 2's static form
+EPH_CRAFT_SORT=0 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 --no-cpu-baseline > $OUT/bench_craft_mixed_queue.json 2> $OUT/bench_craft_mixed_queue.err
+EPH_CRAFT_SORT=0 EPH_CRAFT_QUEUE=0 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 --no-cpu-baseline > $OUT/bench_craft_mixed_static.json 2> $OUT/bench_craft_mixed_static.err
 python bench.py --workload nbody-sharded --steps 20 --warmup 3 > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
 # N > 1 flows on this one-GPU box: bench.py launches its own ranks; they share the device (gloo for the timing reductions),
 # the sharded_4096 figure uses the direct-write transport between the two processes
