@@ -40,12 +40,12 @@ ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = -
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
 
 ABI_SYMBOLS = [
-    "eph_abi_version", "eph_pair_variant", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
+    "eph_abi_version", "eph_pair_variant", "eph_release_cached_memory", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
     "eph_device_name", "eph_srkn_coeffs", "eph_elm2_coeffs", "eph_accel_eval",
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
     "eph_nbody_enable_timing", "eph_nbody_sync", "eph_rccl_unique_id", "eph_nbody_shard", "eph_nbody_shard_info",
-    "eph_prop_shard", "eph_peer_create", "eph_peer_handle", "eph_peer_connect", "eph_peer_destroy", "eph_nbody_shard_peer",
+    "eph_prop_shard", "eph_peer_create", "eph_peer_create_ex", "eph_peer_memory_form", "eph_peer_handle", "eph_peer_connect", "eph_peer_destroy", "eph_nbody_shard_peer",
     "eph_prop_shard_peer", "eph_nbody_advance_many", "eph_prop_step_n_many",
     "eph_prop_create", "eph_prop_step", "eph_prop_step_n", "eph_prop_step_to", "eph_prop_time",
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
@@ -252,6 +252,14 @@ def set_device(i):
     _check(_lib().eph_set_device(int(i)), "eph_set_device")
 
 
+def release_cached_memory():
+    """Returns the library's cache of large device blocks to the driver (eph_release_cached_memory); bytes released."""
+    b = C.c_uint64()
+    _lib().eph_release_cached_memory.argtypes = [C.POINTER(C.c_uint64)]
+    _check(_lib().eph_release_cached_memory(C.byref(b)), "eph_release_cached_memory")
+    return int(b.value)
+
+
 def device_name():
     buf = C.create_string_buffer(256)
     _check(_lib().eph_device_name(buf, 256), "eph_device_name")
@@ -352,12 +360,19 @@ class PeerTransport:
     rank, `connect(handles)` with all of them in rank order, then hand it to `NBodyIntegration.shard_peer` /
     `NBodyPropagator.shard_peer` (`parallel.peer_transport(dist)` does the hand-shake over torch.distributed)."""
 
-    def __init__(self, rank, world, slot_bytes=1 << 22):
+    MEMORY = {"auto": 0, "fine": 1, "coarse": 2}
+
+    def __init__(self, rank, world, slot_bytes=1 << 22, memory="auto"):
         self._L = _lib()
         h = C.c_void_p()
-        _check(self._L.eph_peer_create(int(rank), int(world), int(slot_bytes), C.byref(h)), "eph_peer_create")
+        self._L.eph_peer_create_ex.argtypes = [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]
+        _check(self._L.eph_peer_create_ex(int(rank), int(world), int(slot_bytes), self.MEMORY[memory], C.byref(h)), "eph_peer_create_ex")
         self._h = h
         self.rank, self.world = int(rank), int(world)
+        f = C.c_int32()
+        self._L.eph_peer_memory_form.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        _check(self._L.eph_peer_memory_form(self._h, C.byref(f)), "eph_peer_memory_form")
+        self.memory = {1: "fine", 2: "coarse"}[f.value]          # what is live (auto may have fallen back)
         buf = (C.c_char * 64)()
         _check(self._L.eph_peer_handle(self._h, buf), "eph_peer_handle")
         self.handle = bytes(buf)
@@ -738,11 +753,12 @@ class SpacecraftBatch:
     RECORD = np.dtype([("t", "f8"), ("pos", "f8", 3), ("vel", "f8", 3), ("next_h", "f8"), ("status", "i4"), ("nknots", "i4"),
                        ("attempts", "u4"), ("steps", "u4")])        # eph_craft_record
 
-    def summary(self):
+    def summary(self, out=None):
         """status() and state() in one device-packed record array (eph_craft_batch_summary): fields t, pos, vel, next_h,
-        status, nknots, attempts, steps."""
-        rec = np.zeros(self.n, dtype=self.RECORD)
-        assert rec.itemsize == 80
+        status, nknots, attempts, steps. `out`: a record array of n entries to fill (one the caller keeps between sweeps
+        has its pages mapped already: the copy into a fresh 21 MB allocation pays a page fault per 4 KB)."""
+        rec = np.empty(self.n, dtype=self.RECORD) if out is None else out
+        assert rec.itemsize == 80 and rec.shape == (self.n,) and rec.flags.c_contiguous
         _check(self._L.eph_craft_batch_summary(self._h, rec.ctypes.data_as(C.c_void_p)), "eph_craft_batch_summary")
         return rec
 

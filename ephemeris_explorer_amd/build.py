@@ -8,7 +8,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libephemeris_amd.so"
 N_PAIR_VARIANTS = 7      # csrc/device_math.h: 0 = the product, 1..6 = other orders of the unpinned point-mass term
-SOURCES = ["kernels.hip", "craft.hip", "peer.hip", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
+SOURCES = ["kernels.hip", "craft.hip", "peer.hip", "mem.cpp", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
 HEADERS = ["eph_internal.h", "host.h", "device_math.h", "coeff_tables.inc", "cr_pow_tables.inc", "chain_tile.inc", "craft_attempt.inc", "../../include/ephemeris_amd.h"]
 # -ffp-contract=off is REQUIRED for parity (HIP's default is fast contraction): the reference never fuses a*b+c.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

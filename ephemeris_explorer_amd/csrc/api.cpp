@@ -51,6 +51,11 @@ extern "C" {
 
 int32_t eph_abi_version(void) { return EPH_ABI_VERSION; }
 int32_t eph_pair_variant(void) { return EPH_PAIR_VARIANT; }
+int32_t eph_release_cached_memory(uint64_t *bytes) {
+    const size_t b = eph::release_cached_memory();
+    if (bytes) *bytes = (uint64_t)b;
+    return EPH_OK;
+}
 
 const char *eph_status_string(int32_t st) {
     switch (st) {
@@ -198,15 +203,20 @@ void eph_nbody_destroy(eph_nbody *h) {
     if (h && h->own) delete h;   // borrowed views (eph_prop_integrator) are not owned
 }
 int32_t eph_nbody_eval_count(eph_nbody *h, uint64_t *count) {
+    EPH_GUARD_BEGIN
     if (!h || !h->p || !count) return EPH_ERR_BAD_ARGUMENT;
-    (void)h->settle();
+    if (const int st = h->settle()) return st;         // (settle runs queued steps, fits and allocations: it can fail)
     *count = h->p->evals();
     return EPH_OK;
+    EPH_GUARD_END
 }
 int32_t eph_nbody_set_path(eph_nbody *h, int32_t path) {
+    EPH_GUARD_BEGIN
     if (!h || !h->p || path < 0 || path > EPH_PATH_F32_PAIRS) return EPH_ERR_BAD_ARGUMENT;
+    if (const int st = h->settle()) return st;         // steps queued through a propagator view ran on the path they were queued for
     h->p->set_path(path);
     return EPH_OK;
+    EPH_GUARD_END
 }
 int32_t eph_nbody_kernel_time(eph_nbody *h, double *total_ms, uint64_t *launches) {
     if (!h || !h->p) return EPH_ERR_BAD_ARGUMENT;
@@ -265,17 +275,26 @@ int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rcc
 struct eph_peer {
     std::shared_ptr<PeerTransport> t;
 };
-int32_t eph_peer_create(int32_t rank, int32_t world, uint64_t slot_bytes, eph_peer **out) {
+int32_t eph_peer_create_ex(int32_t rank, int32_t world, uint64_t slot_bytes, int32_t memory_form, eph_peer **out) {
     EPH_GUARD_BEGIN
     if (!out) return EPH_ERR_BAD_ARGUMENT;
     *out = nullptr;
     int st = check_device();
     if (st) return st;
     std::unique_ptr<eph_peer> p(new eph_peer());
-    if ((st = PeerTransport::create(rank, world, (size_t)slot_bytes, &p->t))) return st;
+    if ((st = PeerTransport::create(rank, world, (size_t)slot_bytes, memory_form, &p->t))) return st;
     *out = p.release();
     return EPH_OK;
     EPH_GUARD_END
+}
+int32_t eph_peer_create(int32_t rank, int32_t world, uint64_t slot_bytes, eph_peer **out) {
+    return eph_peer_create_ex(rank, world, slot_bytes, EPH_PEER_MEMORY_AUTO, out);
+}
+int32_t eph_peer_memory_form(eph_peer *p, int32_t *form) {
+    if (!p || !p->t || !form) return EPH_ERR_BAD_ARGUMENT;
+    *form = p->t->form();
+    if (!p->t->fallback_reason().empty()) set_last_error_text("eph_peer: plain device memory because " + p->t->fallback_reason());
+    return EPH_OK;
 }
 int32_t eph_peer_handle(eph_peer *p, void *out64) {
     if (!p || !p->t || !out64) return EPH_ERR_BAD_ARGUMENT;

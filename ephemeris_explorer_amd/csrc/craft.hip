@@ -13,6 +13,8 @@
 // glam::DVec3 operations (crate glam 0.30.10, not on disk) are restated from the published crate.
 // Same f64 operations in the same order as the CPU path; the one libm call on the path, powf in the step-size
 // controller, is evaluated correctly rounded in double-double arithmetic on both sides.
+#include <chrono>
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -1527,6 +1529,10 @@ __global__ void __launch_bounds__(64) k_plot_points(const PlotArgs a) {
     a.out_count[p] = np;
 }
 
+// 16 bytes per lane, consecutive lanes consecutive: between device memory and the pinned, device-mapped staging buffer (mem.cpp), either way
+__global__ void __launch_bounds__(256) k_copy16(long long n16, const double2 *__restrict__ src, double2 *__restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 // few spacecraft: one wave each (k_craft_wave, k_craft_events<true>); many: one thread each. Measured crossover on
 // MI355X, Verner87, 32 bodies: see scripts/bench_craft_small.py and profiles/README.md
 static bool craft_wave_form(long long n_craft) {
@@ -1638,7 +1644,7 @@ struct eph_craft_batch {
     DevBuf<long long> seg_off;
     DevBuf<SegmentDev> segs;
     DevBuf<ErkCoeffs> rk_dev;
-    DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (allocated on first use)
+    DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (a clone's: on first use)
     DevBuf<unsigned long long> queue;         // k_craft_queue's work queue (one counter)
     bool heterogeneous = false;               // the craft's dynamical time scales differ widely (craft_time_scales): queue form
     DevBuf<int> perm, slot_of;                // heterogeneous batches: lane / queue position -> craft by dynamical time, and back
@@ -1728,42 +1734,68 @@ __global__ void __launch_bounds__(256) k_rows_to_craft_order(long long rows, lon
     const long long col = slot_of[i];
     for (long long r = 0; r < rows; ++r) dst[r * n + i] = src[r * n + col];
 }
-// Heterogeneous batches (craft_time_scales_differ): which craft a lane integrates is free (craft are independent, every craft's
-// operations are the reference's whoever runs them), so the craft are dealt to the lanes in the order of their dynamical time --
-// a counting sort of k_craft_tau's estimate into eighths of an octave, shortest first (most steps first). The lanes of a wave then carry craft of similar
-// step counts, which is what the families-in-blocks order had and the interleaved order lacked (184 against 343 ms for the same
-// population: profiles/r03_craft_queue.md). EPH_CRAFT_SORT=0 switches it off (tuning, tests).
+// Which craft a lane integrates is free (craft are independent, every craft's operations are the reference's whoever runs them),
+// so every thread-per-craft batch is dealt to the lanes in the order of k_craft_tau's estimate -- a stable radix sort on the host,
+// shortest orbit first (most steps first). The lanes of a wave then carry craft of similar step counts: on the mixed population
+// 185 against 343 ms with the queue kernel in craft order (profiles/r03_craft_queue.md); on the north star's own sweep (one
+// transfer arc +- 100 km) the accepted steps of a craft follow its orbital energy with correlation -0.99, and the deal takes the
+// max / mean steps per wave from 1.09 to 1.01 (oracle, 1500 craft). The knot slabs keep LANE columns (coalesced knot writes
+// whatever the deal); every reader translates through the inverse. EPH_CRAFT_SORT=0 switches it off (tuning, tests).
+// EPH_CRAFT_SORT: 0 = never deal | 1 = heterogeneous batches only (round 3's default) | unset / 2 = every thread-per-craft batch
+static int craft_sort_mode() {
+    static const int mode = [] { const char *e = getenv("EPH_CRAFT_SORT"); return !e || !*e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2)); }();
+    return mode;
+}
 static int craft_sort(eph_craft_batch *b) {
-    static const bool on = [] { const char *e = getenv("EPH_CRAFT_SORT"); return !(e && e[0] == '0'); }();
     const long long n = b->n;
-    if (!on || n < 128 || n > 0x7fffffffLL) return EPH_OK;
+    const int mode = craft_sort_mode();
+    if (mode == 0 || (mode == 1 && !b->heterogeneous) || n < 128 || n > 0x7fffffffLL) return EPH_OK;
+    // Transfers through the process's pinned staging buffer (mem.cpp), moved by kernels: no pinning and unpinning of three
+    // short-lived host vectors per creation.
+    const size_t n4 = ((size_t)n + 3) & ~(size_t)3;    // 16-byte granules for k_copy16
     DevBuf<float> tau;
-    int st = tau.alloc((size_t)n);
+    int st = tau.alloc(n4);
     if (st) return st;
     hipLaunchKernelGGL(k_craft_tau, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, b->eph->n_bodies, b->eph->bodies.p,
                        b->eph->coeffs.p, b->time.p, b->y.p, tau.p);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) { set_last_error("k_craft_tau", he); return EPH_ERR_HIP; }
-    std::vector<float> h((size_t)n);
-    EPH_HIP(hipMemcpyAsync(h.data(), tau.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    if ((st = b->perm.alloc(n4)) || (st = b->slot_of.alloc(n4))) return st;
+    PinnedStage stage(2 * n4 * sizeof(int));
+    if (stage.status()) return stage.status();
+    const unsigned cgrid = (unsigned)std::min<size_t>((n4 / 4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_copy16, dim3(cgrid), dim3(256), 0, b->stream, (long long)(n4 / 4), (const double2 *)tau.p, (double2 *)stage.dev());
     EPH_HIP(hipStreamSynchronize(b->stream));
-    constexpr int kBuckets = 1024;                      // eighths of an octave from 2^-32 s to 2^96 s; the rest at the ends
-    auto bucket = [&](float v) {
-        if (!(v > 0.0f)) return 0;
-        if (!std::isfinite(v)) return kBuckets - 1;
-        const int q = (int)std::floor(8.0f * std::log2(v)) + 256;
-        return std::min(std::max(q, 0), kBuckets - 1);
-    };
-    std::vector<long long> start(kBuckets + 1, 0);
-    for (long long i = 0; i < n; ++i) start[bucket(h[(size_t)i]) + 1] += 1;
-    for (int q = 0; q < kBuckets; ++q) start[q + 1] += start[q];
-    std::vector<int> perm((size_t)n);
-    for (long long i = 0; i < n; ++i) perm[(size_t)start[bucket(h[(size_t)i])]++] = (int)i;   // stable: craft order inside a bucket
+    const float *h = static_cast<const float *>(stage.host());
+    // stable LSD radix sort of the estimates (positive binary32 values order like their bit patterns; anything else goes last)
+    std::vector<uint32_t> key((size_t)n);
+    for (long long i = 0; i < n; ++i) {
+        const float v = h[(size_t)i];
+        uint32_t u;
+        std::memcpy(&u, &v, sizeof(u));
+        key[(size_t)i] = v > 0.0f && std::isfinite(v) ? u : 0xffffffffu;
+    }
+    std::vector<int> perm((size_t)n), other((size_t)n);
+    for (long long i = 0; i < n; ++i) perm[(size_t)i] = (int)i;
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<long long> start(65536 + 1, 0);
+        const int shift = 16 * pass;
+        for (long long q = 0; q < n; ++q) start[((key[(size_t)perm[(size_t)q]] >> shift) & 0xffffu) + 1] += 1;
+        for (int d = 0; d < 65536; ++d) start[d + 1] += start[d];
+        for (long long q = 0; q < n; ++q) {
+            const int c = perm[(size_t)q];
+            other[(size_t)start[(key[(size_t)c] >> shift) & 0xffffu]++] = c;
+        }
+        perm.swap(other);
+    }
     std::vector<int> slot((size_t)n);
     for (long long q = 0; q < n; ++q) slot[(size_t)perm[(size_t)q]] = (int)q;
-    if ((st = b->perm.alloc((size_t)n)) || (st = b->slot_of.alloc((size_t)n))) return st;
-    EPH_HIP(hipMemcpy(b->perm.p, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    EPH_HIP(hipMemcpy(b->slot_of.p, slot.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    int *hp = static_cast<int *>(stage.host());
+    std::memcpy(hp, perm.data(), sizeof(int) * (size_t)n);
+    std::memcpy(hp + n4, slot.data(), sizeof(int) * (size_t)n);
+    const int *dp = static_cast<const int *>(stage.dev());
+    hipLaunchKernelGGL(k_copy16, dim3(cgrid), dim3(256), 0, b->stream, (long long)(n4 / 4), (const double2 *)dp, (double2 *)b->perm.p);
+    hipLaunchKernelGGL(k_copy16, dim3(cgrid), dim3(256), 0, b->stream, (long long)(n4 / 4), (const double2 *)(dp + n4), (double2 *)b->slot_of.p);
     b->h_slot = std::move(slot);
     // knot 0 (the initial state, uploaded in craft order) moves to the lanes' columns
     hipLaunchKernelGGL(k_knot0_to_lanes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, b->perm.p, b->time.p, b->y.p,
@@ -1986,7 +2018,8 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             (st = b->rk_i.alloc(nn)) || (st = b->steps.alloc(nn)) || (st = b->cur_seg.alloc(nn)) ||
             (st = b->status.alloc(nn)) || (st = b->nknots.alloc(nn)) || (st = b->seg_off.alloc(n + 1)) ||
             (st = b->segs.alloc(std::max<size_t>(segs.size(), 1))) || (st = b->knot_t.alloc(nn * max_knots)) ||
-            (st = b->knot_y.alloc(6 * nn * max_knots)) || (st = b->rk_dev.alloc(1)) || (st = b->queue.alloc(1)))
+            (st = b->knot_y.alloc(6 * nn * max_knots)) || (st = b->rk_dev.alloc(1)) || (st = b->queue.alloc(1)) ||
+            (st = b->summary.alloc(nn)))               // (here, not at the first eph_craft_batch_summary: keeps hipMalloc out of a sweep)
             return st;
         EPH_HIP(hipMemcpy(b->rk_dev.p, &b->rk, sizeof(ErkCoeffs), hipMemcpyHostToDevice));
         if (n > 0) {
@@ -2011,7 +2044,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             EPH_HIP(hipMemcpy(b->knot_t.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
             EPH_HIP(hipMemcpy(b->knot_y.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
             b->heterogeneous = craft_time_scales_differ(*e, n, t0, pos);
-            if (b->heterogeneous && !craft_wave_form(n) && (st = craft_sort(b.get()))) return st;
+            if (!craft_wave_form(n) && (st = craft_sort(b.get()))) return st;
         }
         *out = b.release();
         return EPH_OK;
@@ -2122,18 +2155,34 @@ __global__ void __launch_bounds__(256) k_craft_summary(long long n, const double
     r.steps = steps[i];
     out[i] = r;
 }
+// One 80-byte record per craft packed on the device, one copy into the caller's memory.
+// Round 3's "2-38 ms in summary()" (profiles/r04_sweep_evidence.md): the FIRST read-back after a burst of batch creations starts
+// 15-40 ms late ON THE DEVICE -- rocprofv3 shows the pack kernel's launch issued 1 ms after the sweep kernel ended and the kernel
+// starting 20-30 ms later with the queue idle and no host thread busy. It is a one-off per burst of creations (every later
+// read-back takes 0.4 ms for 21 MB), it is there with the copy engine out of the picture (records stored by a kernel into pinned
+// host memory: same delay), without hipFree, without scratch, on a shared stream; a read-back issued after the LAST creation
+// absorbs it, one at the end of each creation does not. bench.py therefore reads every batch back once before its timed region.
+// EPH_TRACE_SUMMARY=1 prints the host timers of the phases.
 int32_t eph_craft_batch_summary(eph_craft_batch *b, eph_craft_record *out) {
     if (!b || (b->n > 0 && !out)) return EPH_ERR_BAD_ARGUMENT;
     if (b->n == 0) return EPH_OK;
     EPH_HIP(hipSetDevice(b->device));
+    static const int trace = [] { const char *e = getenv("EPH_TRACE_SUMMARY"); return e ? atoi(e) : 0; }();
+    const auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
+        return std::chrono::duration<double, std::micro>(c - a).count(); };
+    const auto t0 = tick();
     int st;
     if ((st = b->summary.reserve((size_t)b->n))) return st;
     hipLaunchKernelGGL(k_craft_summary, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->stream, b->n, b->time.p, b->y.p,
                        b->next_h.p, b->status.p, b->nknots.p, b->n_attempts.p, b->steps.p, b->summary.p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error("k_craft_summary", e); return EPH_ERR_HIP; }
+    const auto t1 = tick();
     EPH_HIP(hipMemcpyAsync(out, b->summary.p, sizeof(eph_craft_record) * (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    const auto t2 = tick();
     EPH_HIP(hipStreamSynchronize(b->stream));
+    if (trace) fprintf(stderr, "summary: pack launch %.0f memcpyAsync %.0f sync %.0f us\n", us(t0, t1), us(t1, t2), us(t2, tick()));
     return EPH_OK;
 }
 
@@ -2309,21 +2358,27 @@ int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32
     if (b->n == 0 || n_knots == 0) return EPH_OK;
     EPH_HIP(hipSetDevice(b->device));
     const size_t n = (size_t)b->n;
-    if (!b->h_slot.empty()) {                           // lane order -> craft order on the device, then one copy each
+    if (!b->h_slot.empty()) {
+        // lane order -> craft order on the device, in passes of at most 256 MB of knot rows (a full slab of a 5e5-craft sweep is
+        // GBs: the reorder must not need a second slab), each pass stored by the kernel straight into the pinned staging buffer
+        const size_t row_bytes = sizeof(double) * n;
+        const long long rows_per_pass = (long long)std::max<size_t>(1, ((size_t)256 << 20) / row_bytes);
         for (int part = 0; part < 2; ++part) {
             double *dst = part == 0 ? knot_t : knot_y;
             if (!dst) continue;
             const long long rows = (long long)n_knots * (part == 0 ? 1 : 6);
             const double *src = part == 0 ? b->knot_t.p + (size_t)first_knot * n : b->knot_y.p + (size_t)first_knot * 6 * n;
-            DevBuf<double> tmp;
-            int st = tmp.alloc((size_t)rows * n);
-            if (st) return st;
-            hipLaunchKernelGGL(k_rows_to_craft_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, rows, (long long)n,
-                               b->slot_of.p, src, tmp.p);
-            hipError_t he = hipGetLastError();
-            if (he != hipSuccess) { set_last_error("k_rows_to_craft_order", he); return EPH_ERR_HIP; }
-            EPH_HIP(hipMemcpyAsync(dst, tmp.p, sizeof(double) * (size_t)rows * n, hipMemcpyDeviceToHost, b->stream));
-            EPH_HIP(hipStreamSynchronize(b->stream));
+            PinnedStage stage((size_t)std::min(rows, rows_per_pass) * row_bytes);
+            if (stage.status()) return stage.status();
+            for (long long r0 = 0; r0 < rows; r0 += rows_per_pass) {
+                const long long nr = std::min(rows_per_pass, rows - r0);
+                hipLaunchKernelGGL(k_rows_to_craft_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, nr, (long long)n,
+                                   b->slot_of.p, src + (size_t)r0 * n, static_cast<double *>(stage.dev()));
+                hipError_t he = hipGetLastError();
+                if (he != hipSuccess) { set_last_error("k_rows_to_craft_order", he); return EPH_ERR_HIP; }
+                EPH_HIP(hipStreamSynchronize(b->stream));
+                std::memcpy(dst + (size_t)r0 * n, stage.host(), (size_t)nr * row_bytes);
+            }
         }
         return EPH_OK;
     }

@@ -12,11 +12,35 @@
 #include <cstdint>
 #include <deque>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "eph_internal.h"
 
 namespace eph {
+
+// device blocks through the library's cache of large allocations (mem.cpp): dev_alloc reuses a cached block of exactly `bytes`
+// (contents unspecified) or calls hipMalloc; dev_free caches blocks of >= 64 MiB (after a device synchronisation, as hipFree has)
+// up to the cache's cap and frees the rest; release_cached_memory returns the cache to the driver (bytes released).
+int dev_alloc(size_t bytes, void **out);
+void dev_free(void *p, size_t bytes);
+size_t release_cached_memory();
+size_t cached_memory_bytes();
+// The process-wide pinned, device-mapped staging buffer, held for the life of the object (one read-back at a time): a kernel
+// stores through dev(), the host reads host() after synchronising the kernel's stream.
+class PinnedStage {
+public:
+    explicit PinnedStage(size_t bytes);
+    int status() const { return status_; }
+    void *host() const { return host_; }
+    void *dev() const { return dev_; }
+
+private:
+    std::unique_lock<std::mutex> lock_;
+    void *host_ = nullptr, *dev_ = nullptr;
+    int status_ = EPH_OK;
+};
 
 template <typename T>
 struct DevBuf {   // owning device allocation
@@ -27,19 +51,17 @@ struct DevBuf {   // owning device allocation
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p, count * sizeof(T));
         p = nullptr;
         count = 0;
     }
     int alloc(size_t n) {
         release();
         if (n == 0) n = 1;
-        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_last_error("hipMalloc", e);
-            return e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_HIP;
-        }
+        void *q = nullptr;
+        const int st = dev_alloc(n * sizeof(T), &q);
+        if (st) return st;
+        p = static_cast<T *>(q);
         count = n;
         return EPH_OK;
     }
@@ -53,7 +75,11 @@ constexpr size_t kPeerHandleBytes = 64;            // sizeof(hipIpcMemHandle_t)
 class PeerTransport {
 public:
     ~PeerTransport();
-    static int create(int rank, int world, size_t slot_bytes, std::shared_ptr<PeerTransport> *out);
+    // form: 0 = fine-grained mailbox, falling back to plain device memory when allocation or export fails | 1 = fine-grained
+    // or fail | 2 = plain device memory
+    static int create(int rank, int world, size_t slot_bytes, int form, std::shared_ptr<PeerTransport> *out);
+    int form() const { return form_; }                        // 1 fine-grained | 2 plain device memory: what is live
+    const std::string &fallback_reason() const { return fallback_reason_; }
     const void *handle() const { return handle_; }           // kPeerHandleBytes, to be passed to every peer
     int connect(const void *handles);                         // world x kPeerHandleBytes in rank order
     int all_gather_inplace(void *buf, size_t slice_bytes, hipStream_t s);
@@ -64,7 +90,8 @@ public:
 
 private:
     PeerTransport() = default;
-    int rank_ = 0, world_ = 1, device_ = 0;
+    int rank_ = 0, world_ = 1, device_ = 0, form_ = 0;
+    std::string fallback_reason_;
     size_t slot_ = 0;
     void *base_[kPeerMaxWorld] = {};
     char handle_[kPeerHandleBytes] = {};
@@ -138,6 +165,7 @@ public:
     // target-partition the system over the ranks of `x`: this rank keeps bodies [lo, hi) current
     int set_shard(std::shared_ptr<Exchange> x);
     bool sharded() const { return (bool)xch_; }
+    int exchange_error() const { return xch_ ? xch_->poll_error() : EPH_OK; }   // EPH_ERR_COMM once a peer wait timed out
     int shard_lo() const { return lo_; }
     int shard_hi() const { return hi_; }
     uint64_t gathers() const { return xch_ ? xch_->gathers() : 0; }
@@ -156,6 +184,8 @@ public:
     uint64_t kernel_launches() const { return kernel_launches_; }
     // how many of the next k advance() calls would succeed before BoundReached / StepSizeUnderflow
     int64_t steps_available(int64_t k, int *status_after) const;
+    bool steps_certain(int64_t k) const;       // neither the bound nor the underflow test can fire in the next k steps (closed form)
+    void replay_deferred_time() { for (int64_t s = 0; s < deferred_time_steps_; ++s) time_ = time_ + h_; deferred_time_steps_ = 0; }
     // `count` independent single-workgroup systems advanced by k steps in ONE launch (k_lm_small, one workgroup each):
     // the same as advance(k) on every one of them. Systems that do not qualify (start-up not finished, more than
     // kGangMaxN bodies, sharded, a forced kernel path, a step that would fail) make the call fall back to that.
@@ -198,9 +228,13 @@ private:
     DevBuf<double> Y_, A_, V_, ASR_, mu_, stage_;
     DevBuf<double> fast_partial_;             // EPH_PATH_FAST scratch: [S][3][npad] partial sums
     DevBuf<float> posf_;                      // EPH_PATH_F32_PAIRS scratch: the level's positions and mu as 4 floats per body
+    int64_t deferred_time_steps_ = 0;         // advance_many: `time = time + h` replays still owed (run after the gang's launch)
     std::vector<LmArgs> *collect_ = nullptr;  // advance_many: lm_batch hands its launch arguments over instead of launching
     DevBuf<LmArgs> gang_args_;                // advance_many: the argument array of the gang this handle leads
-    hipEvent_t gang_ev_ = nullptr;
+    hipEvent_t gang_ev_ = nullptr, gang_copy_ev_ = nullptr;
+    LmArgs *gang_host_ = nullptr;             // pinned source of the gang's argument copy (so advance_many need not wait for it)
+    size_t gang_host_count_ = 0;
+    int failed_ = EPH_OK;                     // sticky: a gang launch failed with this handle's bookkeeping already advanced
 };
 
 // Polynomial<DVec3> (SmallVec<[DVec3; 8]>)   ephemeris/src/trajectory.rs:337-396

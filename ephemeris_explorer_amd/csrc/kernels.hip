@@ -5,7 +5,9 @@
 //
 // Reference citations are relative to the reference repository root.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <type_traits>
 #include <utility>
@@ -609,7 +611,7 @@ constexpr int kWgRows = 3 * kWgBodies;
 constexpr int kWgBuf = kWgRows * kRow;               // doubles per LDS buffer
 constexpr int kWgBufs = 3;                           // pair waves run two tiles ahead of the chain wave
 __device__ long long g_wg_cycles[8];                 // debug (EPH_DEBUG_WG=4): cycle accounting of workgroup 7
-__device__ long long g_wg_span[2][1024];             // debug: per workgroup entry / force-done ticks of the step kernel
+__device__ long long g_wg_span[4][1024];             // debug: per workgroup entry / force-done ticks of the step kernel
 
 // pair wave: NB bodies (local indices b0..) against the 64 sources in pj -> rows of `tile`
 template <int NB>
@@ -1807,6 +1809,11 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
         // rewritten only after the next "positions visible" barrier
     };
     int rot = 0;                                       // rotation after the steps taken so far
+    if ((wg_flags & 4) && tid == 0 && blockIdx.x < 1024) {   // tuning: where the dispatcher put this workgroup (HW_ID, XCC_ID)
+        g_wg_span[0][blockIdx.x] = (long long)(unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+        g_wg_span[1][blockIdx.x] = (long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11)) + 1;
+        g_wg_span[2][blockIdx.x] = (long long)wall_clock64();
+    }
     const long long dbg_c0 = (wg_flags & 4) ? (long long)__builtin_readcyclecounter() : 0;
     const long long dbg_w0 = (wg_flags & 4) ? (long long)wall_clock64() : 0;
     if constexpr (EPH_SMALL_ROLLED) {
@@ -1816,6 +1823,7 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
         bool more = nsteps >= 1;
         while (more) small_steps(step, s, nsteps, rot, more, std::make_integer_sequence<int, L>{});
     }
+    if ((wg_flags & 4) && tid == 0 && blockIdx.x < 1024) g_wg_span[3][blockIdx.x] = (long long)wall_clock64();
     if ((wg_flags & 4) && tid == 0 && blockIdx.x == 0) {   // tuning (EPH_DEBUG_SMALL=4): shader-clock ticks, 100 MHz ticks, steps
         g_wg_cycles[0] = (long long)__builtin_readcyclecounter() - dbg_c0;
         g_wg_cycles[1] = (long long)wall_clock64() - dbg_w0;
@@ -2269,8 +2277,10 @@ int launch_lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L
     static_assert(kGangMaxN == kSmallMaxN, "the gang launch is k_lm_small's");
     if (count <= 0 || nsteps <= 0) return EPH_OK;
     const LmArgs none{};
-    if (L == 12) hipLaunchKernelGGL((k_lm_small<12, true>), dim3((unsigned)count), dim3(512), 0, s, none, argv_dev, (long long)nsteps);
-    else if (L == 13) hipLaunchKernelGGL((k_lm_small<13, true>), dim3((unsigned)count), dim3(512), 0, s, none, argv_dev, (long long)nsteps);
+    // EPH_SMALL_LDS_PAD (tuning): extra dynamic LDS per workgroup, so that two workgroups do not fit one CU
+    static const unsigned pad = [] { const char *e = getenv("EPH_SMALL_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    if (L == 12) hipLaunchKernelGGL((k_lm_small<12, true>), dim3((unsigned)count), dim3(512), pad, s, none, argv_dev, (long long)nsteps);
+    else if (L == 13) hipLaunchKernelGGL((k_lm_small<13, true>), dim3((unsigned)count), dim3(512), pad, s, none, argv_dev, (long long)nsteps);
     else return EPH_ERR_UNSUPPORTED;
     return done("k_lm_small (gang)");
 }
@@ -2305,12 +2315,46 @@ int debug_wg_cycles(long long *out) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_cycles), sizeof(long long) * 8);
     if (e != hipSuccess) { set_last_error("hipMemcpyFromSymbol", e); return EPH_ERR_HIP; }
     // step kernel: out[2] = earliest workgroup entry, out[3] = latest force completion over the grid (s_memtime ticks)
-    static long long span[2][1024];
+    static long long span[4][1024];
     e = hipMemcpyFromSymbol(span, HIP_SYMBOL(g_wg_span), sizeof(span));
     if (e != hipSuccess) { set_last_error("hipMemcpyFromSymbol", e); return EPH_ERR_HIP; }
+    if (getenv("EPH_DEBUG_PLACEMENT")) {               // k_lm_small gang: HW_ID / XCC_ID of every workgroup -> workgroups per CU
+        int per_cu[8][128] = {};
+        int wgs = 0, cus = 0, worst = 0;
+        for (int b = 0; b < 1024; ++b) {
+            if (span[1][b] == 0) continue;
+            const unsigned hw = (unsigned)span[0][b], xcc = (unsigned)(span[1][b] - 1) & 7u;
+            const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 3u;   // gfx9 HW_ID fields
+            int &d = per_cu[xcc][(se << 5) | (sh << 4) | cu];
+            if (d++ == 0) ++cus;
+            worst = std::max(worst, d);
+            ++wgs;
+        }
+        fprintf(stderr, "placement: %d workgroups on %d distinct (xcc, se, cu), at most %d on one\n", wgs, cus, worst);
+        // per workgroup: start (relative to the earliest) and duration in 100 MHz ticks -> us; per XCC min / mean / max duration
+        long long first = 0;
+        for (int b = 0; b < 1024; ++b) if (span[1][b] && (first == 0 || span[2][b] < first)) first = span[2][b];
+        for (int x = 0; x < 8; ++x) {
+            double lo_d = 1e30, hi_d = 0, sum_d = 0, hi_s = 0;
+            int cnt = 0;
+            for (int b = 0; b < 1024; ++b) {
+                if (span[1][b] == 0 || (unsigned)((span[1][b] - 1) & 7) != (unsigned)x) continue;
+                const double dur = (double)(span[3][b] - span[2][b]) / 100.0, st = (double)(span[2][b] - first) / 100.0;
+                lo_d = std::min(lo_d, dur); hi_d = std::max(hi_d, dur); sum_d += dur; hi_s = std::max(hi_s, st); ++cnt;
+            }
+            if (cnt) fprintf(stderr, "  xcc %d: %3d workgroups, duration us min %.0f mean %.0f max %.0f, latest start +%.0f us\n", x, cnt, lo_d, sum_d / cnt, hi_d, hi_s);
+        }
+        if (getenv("EPH_DEBUG_PLACEMENT")[0] == '2')
+            for (int b = 0; b < 1024; ++b)
+                if (span[1][b]) fprintf(stderr, "  wg %4d xcc %d hw %05x start +%.0f us dur %.0f us\n", b, (int)((span[1][b] - 1) & 7), (unsigned)span[0][b] & 0xfffff,
+                                        (double)(span[2][b] - first) / 100.0, (double)(span[3][b] - span[2][b]) / 100.0);
+        std::memset(span, 0, sizeof(span));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_span), span, sizeof(span));
+        return EPH_OK;
+    }
     long long lo = 0, hi = 0;
     for (int b = 0; b < 1024; ++b) {
-        if (span[0][b] == 0) continue;
+        if (span[0][b] == 0 || span[2][b] != 0) continue;   // (span[2] != 0: k_lm_small's placement words, not the step kernel's ticks)
         if (lo == 0 || span[0][b] < lo) lo = span[0][b];
         if (span[1][b] > hi) hi = span[1][b];
     }

@@ -8,6 +8,7 @@
 // The host replays the reference's scalar bookkeeping (time, bound, step counters) with the reference's f64
 // operations; all vector arithmetic runs in the HIP kernels of kernels.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "host.h"
@@ -21,6 +22,8 @@ NBodyIntegration::~NBodyIntegration() {
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
         if (gang_ev_) (void)hipEventDestroy(gang_ev_);
+        if (gang_copy_ev_) { (void)hipEventSynchronize(gang_copy_ev_); (void)hipEventDestroy(gang_copy_ev_); }
+        if (gang_host_) (void)hipHostFree(gang_host_);
         (void)hipStreamDestroy(stream_);
     }
 }
@@ -201,7 +204,21 @@ int NBodyIntegration::startup_macro_step() {
     return EPH_OK;
 }
 
+// The k-fold replay of `time = time + h` below reproduces the reference's bits of `problem.time`; the two tests inside it
+// almost never fire. When they provably cannot -- no bound, and |h| far above the spacing of doubles at any |t| the k steps
+// can reach -- the answer is k without the loop, and the replay that updates time_ can run AFTER the launch, under the kernel
+// (lm_batch). It matters for gangs: 256 systems x 100 000 steps is 77 M dependent additions (three passes: gang_ready,
+// advance, the update) that the device sat waiting for -- the "gang of 256 steps 1.31 us against 0.78 alone" of round 3
+// (profiles/r04_small_kernel_evidence.md: every workgroup of the gang took 0.89 us per step; the rest was this loop).
+bool NBodyIntegration::steps_certain(int64_t k) const {
+    if (!(bound_ == INFINITY) || !std::isfinite(time_) || !std::isfinite(h_) || h_ == 0.0 || k < 0) return false;
+    const double reach = (std::fabs(time_) + (double)k * std::fabs(h_)) * 1.000001;   // |t| stays below this (k <= 2^30 roundings of 2^-53)
+    // t + h == t needs |h| <= ulp(t) / 2 <= 2^-53 |t|
+    return std::isfinite(reach) && std::fabs(h_) > reach * 4.440892098500626e-16;
+}
+
 int64_t NBodyIntegration::steps_available(int64_t k, int *status_after) const {
+    if (steps_certain(k)) { *status_after = EPH_OK; return k; }
     double t = time_;
     int64_t s = 0;
     *status_after = EPH_OK;
@@ -275,13 +292,15 @@ int NBodyIntegration::lm_batch(int64_t k) {
         EPH_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
         kernel_ms_ += ms;
     }
-    for (int64_t s = 0; s < k; ++s) time_ = time_ + h_;   // problem.time = problem.time + h, per step
+    if (collect_) deferred_time_steps_ += k;              // advance_many replays them once the gang is launched
+    else for (int64_t s = 0; s < k; ++s) time_ = time_ + h_;   // problem.time = problem.time + h, per step (the launch is already queued)
     lm_i_ += (uint32_t)k;
     evals_ += (uint64_t)k;
     return EPH_OK;
 }
 
 int NBodyIntegration::advance(int64_t n_steps, int64_t *done_out) {
+    if (failed_) { if (done_out) *done_out = 0; return failed_; }     // a gang launch failed after this handle's bookkeeping had moved
     EPH_HIP(hipSetDevice(device_));
     int64_t done = 0;
     int st = EPH_OK;
@@ -358,38 +377,68 @@ int NBodyIntegration::advance_many(NBodyIntegration *const *igs, int count, int6
     }
     NBodyIntegration &lead = *igs[0];
     EPH_HIP(hipSetDevice(lead.device_));
+    for (int i = 0; i < count; ++i)
+        if (igs[i]->failed_) return igs[i]->failed_;
+    // everything that can fail for lack of resources happens BEFORE any handle's bookkeeping moves
+    int st;
+    if ((st = lead.gang_args_.reserve((size_t)count))) return st;
+    if (!lead.gang_ev_) EPH_HIP(hipEventCreateWithFlags(&lead.gang_ev_, hipEventDisableTiming));
+    if (!lead.gang_copy_ev_) EPH_HIP(hipEventCreateWithFlags(&lead.gang_copy_ev_, hipEventDisableTiming));
+    if (lead.gang_host_count_ < (size_t)count) {
+        if (lead.gang_host_) { EPH_HIP(hipEventSynchronize(lead.gang_copy_ev_)); (void)hipHostFree(lead.gang_host_); }
+        lead.gang_host_ = nullptr;
+        lead.gang_host_count_ = 0;
+        const size_t want = (size_t)count + (size_t)count / 2;
+        EPH_HIP(hipHostMalloc((void **)&lead.gang_host_, sizeof(LmArgs) * want, hipHostMallocDefault));
+        lead.gang_host_count_ = want;
+    }
+    // the previous gang's argument copy out of the pinned array must have completed before it is rewritten
+    EPH_HIP(hipEventSynchronize(lead.gang_copy_ev_));
     std::vector<LmArgs> args;
     args.reserve((size_t)count);
     for (int i = 0; i < count; ++i) {
         NBodyIntegration &ig = *igs[i];
         ig.collect_ = &args;
         int64_t done = 0;
-        const int st = ig.advance(k, &done);                            // bookkeeping as usual, launch arguments into `args`
+        st = ig.advance(k, &done);                                      // bookkeeping as usual, launch arguments into `args`
         ig.collect_ = nullptr;
-        if (st || done != k || args.size() != (size_t)i + 1) return st ? st : EPH_ERR_HIP;
+        if (st || done != k || args.size() != (size_t)i + 1) {
+            // (cannot happen after gang_ready: no launch was made, so handles 0..i are ahead of their device state)
+            for (int j = 0; j <= i; ++j) { igs[j]->replay_deferred_time(); igs[j]->failed_ = st ? st : EPH_ERR_HIP; }
+            return st ? st : EPH_ERR_HIP;
+        }
     }
-    int st;
-    if ((st = lead.gang_args_.reserve((size_t)count))) return st;
-    if (!lead.gang_ev_) EPH_HIP(hipEventCreateWithFlags(&lead.gang_ev_, hipEventDisableTiming));
+    static const int dbg = [] { const char *e = getenv("EPH_DEBUG_SMALL"); return e ? atoi(e) : 0; }();   // tuning switches of k_lm_small
+    for (int i = 0; i < count; ++i) { lead.gang_host_[i] = args[(size_t)i]; lead.gang_host_[i].wg_flags = dbg; }
+    // From here on a failure leaves every handle's bookkeeping k steps ahead of its device state: the handles are marked
+    // failed (every later call returns the status) instead of being handed back as if nothing had happened.
+    auto fail = [&](int status) {
+        for (int i = 0; i < count; ++i) { igs[i]->replay_deferred_time(); igs[i]->failed_ = status; }
+        return status;
+    };
+#define EPH_GANG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(#call, e_); return fail(EPH_ERR_HIP); } } while (0)
     // the gang's launch goes on the lead's stream, behind whatever the other handles still have in flight on theirs
     for (int i = 1; i < count; ++i) {
-        EPH_HIP(hipEventRecord(lead.gang_ev_, igs[i]->stream_));
-        EPH_HIP(hipStreamWaitEvent(lead.stream_, lead.gang_ev_, 0));
+        EPH_GANG_HIP(hipEventRecord(lead.gang_ev_, igs[i]->stream_));
+        EPH_GANG_HIP(hipStreamWaitEvent(lead.stream_, lead.gang_ev_, 0));
     }
-    EPH_HIP(hipMemcpyAsync(lead.gang_args_.p, args.data(), sizeof(LmArgs) * (size_t)count, hipMemcpyHostToDevice, lead.stream_));
-    if (lead.timing_) EPH_HIP(hipEventRecord(lead.ev0_, lead.stream_));
-    if ((st = launch_lm_small_many(lead.stream_, lead.gang_args_.p, count, lead.L_, k))) return st;
+    EPH_GANG_HIP(hipMemcpyAsync(lead.gang_args_.p, lead.gang_host_, sizeof(LmArgs) * (size_t)count, hipMemcpyHostToDevice, lead.stream_));
+    EPH_GANG_HIP(hipEventRecord(lead.gang_copy_ev_, lead.stream_));
+    if (lead.timing_) EPH_GANG_HIP(hipEventRecord(lead.ev0_, lead.stream_));
+    st = launch_lm_small_many(lead.stream_, lead.gang_args_.p, count, lead.L_, k);
+    if (st) return fail(st);
+    for (int i = 0; i < count; ++i) igs[i]->replay_deferred_time();     // host bookkeeping under the kernel
     if (lead.timing_) {
-        EPH_HIP(hipEventRecord(lead.ev1_, lead.stream_));
-        EPH_HIP(hipEventSynchronize(lead.ev1_));
+        EPH_GANG_HIP(hipEventRecord(lead.ev1_, lead.stream_));
+        EPH_GANG_HIP(hipEventSynchronize(lead.ev1_));
         float ms = 0;
-        EPH_HIP(hipEventElapsedTime(&ms, lead.ev0_, lead.ev1_));
+        EPH_GANG_HIP(hipEventElapsedTime(&ms, lead.ev0_, lead.ev1_));
         lead.kernel_ms_ += ms;
     }
-    EPH_HIP(hipEventRecord(lead.gang_ev_, lead.stream_));
-    for (int i = 1; i < count; ++i) EPH_HIP(hipStreamWaitEvent(igs[i]->stream_, lead.gang_ev_, 0));
-    EPH_HIP(hipStreamSynchronize(lead.stream_));                        // `args` (pageable) must outlive the copy
-    return EPH_OK;
+    EPH_GANG_HIP(hipEventRecord(lead.gang_ev_, lead.stream_));
+    for (int i = 1; i < count; ++i) EPH_GANG_HIP(hipStreamWaitEvent(igs[i]->stream_, lead.gang_ev_, 0));
+#undef EPH_GANG_HIP
+    return EPH_OK;                                                      // not synchronised: like eph_nbody_advance, the call only queues
 }
 
 int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *sc) {
@@ -400,12 +449,14 @@ int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *s
         if ((st = gather_stage())) return st;               // sharded: every rank contributes its bodies
         EPH_HIP(hipMemcpyAsync(pos, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
         EPH_HIP(hipStreamSynchronize(stream_));
+        if (xch_ && (st = xch_->poll_error())) return st;    // a peer that never delivered: the gathered rows are not data
     }
     if (vel && n_ > 0) {
         if ((st = launch_soa_to_aos(stream_, n_, npad_, V_.p, stage_.p))) return st;
         if ((st = gather_stage())) return st;
         EPH_HIP(hipMemcpyAsync(vel, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
         EPH_HIP(hipStreamSynchronize(stream_));
+        if (xch_ && (st = xch_->poll_error())) return st;
     }
     if (t) *t = time_;
     if (sc) *sc = step_count();
@@ -421,7 +472,7 @@ int NBodyIntegration::get_acc(double *acc) {
     if ((st = gather_stage())) return st;
     EPH_HIP(hipMemcpyAsync(acc, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));
     EPH_HIP(hipStreamSynchronize(stream_));
-    return EPH_OK;
+    return xch_ ? xch_->poll_error() : EPH_OK;
 }
 
 // seam 1: SecondOrderODE::eval for NewtonianGravity, host buffers in and out

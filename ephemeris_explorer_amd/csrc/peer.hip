@@ -62,6 +62,8 @@ __global__ void __launch_bounds__(kPeerThreads) k_peer_exchange(const PeerArgs a
                                                                          (parity * a.world + a.rank) * a.slot_bytes);
         for (unsigned long long w = w0 + threadIdx.x; w < w1; w += kPeerThreads) sys_store(dst + w, src[w]);
     }
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
     __atomic_thread_fence(__ATOMIC_RELEASE);            // (HIP: system scope) my stores before the flag
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -80,13 +82,15 @@ __global__ void __launch_bounds__(kPeerThreads) k_peer_exchange(const PeerArgs a
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > a.timeout_ticks) {
                 __hip_atomic_store(a.status, 1u + (unsigned)peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                timed_out = 1;
                 break;
             }
         }
     }
     __syncthreads();
-    // ---- copy out: the peer's slice -> its place in the gathered buffer
-    {
+    // ---- copy out: the peer's slice -> its place in the gathered buffer (not after a timed-out wait: the slot holds an older
+    // epoch's data; the gathered buffer keeps what it had and the host sees EPH_ERR_COMM at its next synchronisation point)
+    if (!timed_out) {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(local + kPeerHeader +
                                                                                      (parity * a.world + peer) * a.slot_bytes);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.buf + peer * a.slice_bytes + a.off);
@@ -103,8 +107,16 @@ PeerTransport::~PeerTransport() {
     if (order_) (void)hipEventDestroy(order_);
 }
 
-int PeerTransport::create(int rank, int world, size_t slot_bytes, std::shared_ptr<PeerTransport> *out) {
-    if (world < 1 || world > kPeerMaxWorld || rank < 0 || rank >= world) return EPH_ERR_BAD_ARGUMENT;
+// EPH_PEER_FORCE_FAIL=alloc|export|open (tests): makes the first attempt of that step fail, to walk the fallback branches.
+static bool peer_force_fail(const char *what) {
+    const char *e = getenv("EPH_PEER_FORCE_FAIL");
+    return e && std::strcmp(e, what) == 0;
+}
+// The mailbox: fine-grained device memory when it can be allocated AND exported (coherent with peer writers without relying
+// on kernel boundaries), plain hipMalloc memory otherwise -- every mailbox access in the kernel is system-scope either way.
+// form: 0 = try fine-grained, fall back to coarse | 1 = fine-grained or fail | 2 = coarse.
+int PeerTransport::create(int rank, int world, size_t slot_bytes, int form, std::shared_ptr<PeerTransport> *out) {
+    if (world < 1 || world > kPeerMaxWorld || rank < 0 || rank >= world || form < 0 || form > 2) return EPH_ERR_BAD_ARGUMENT;
     slot_bytes = (slot_bytes + 255) / 256 * 256;
     if (slot_bytes == 0) slot_bytes = 256;
     std::shared_ptr<PeerTransport> t(new PeerTransport());
@@ -113,21 +125,35 @@ int PeerTransport::create(int rank, int world, size_t slot_bytes, std::shared_pt
     t->slot_ = slot_bytes;
     EPH_HIP(hipGetDevice(&t->device_));
     const size_t bytes = kPeerHeader + 2 * (size_t)world * slot_bytes;
-    void *p = nullptr;
-    // fine-grained: coherent with peer writers without relying on kernel boundaries; plain device memory otherwise
-    // (every mailbox access in the kernel is system-scope anyway)
-    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    std::string why;
+    for (int attempt = (form == 2 ? 2 : 1); attempt <= 2; ++attempt) {      // 1 = fine-grained, 2 = coarse
+        void *p = nullptr;
+        hipError_t e = attempt == 1 ? (peer_force_fail("alloc") ? hipErrorOutOfMemory : hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained))
+                                    : hipMalloc(&p, bytes);
+        const char *step = attempt == 1 ? "hipExtMallocWithFlags (fine-grained peer mailbox)" : "hipMalloc (peer mailbox)";
+        if (e == hipSuccess) {
+            e = hipMemset(p, 0, kPeerHeader);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess) {
+                step = "hipIpcGetMemHandle (peer mailbox)";
+                e = attempt == 1 && peer_force_fail("export") ? hipErrorInvalidValue
+                                                               : hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(t->handle_), p);
+            }
+        }
+        if (e == hipSuccess) {
+            t->base_[rank] = p;
+            t->form_ = attempt;
+            break;
+        }
         (void)hipGetLastError();
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            set_last_error("hipMalloc (peer mailbox)", e);
-            return e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_HIP;
+        if (p) (void)hipFree(p);
+        why += std::string(why.empty() ? "" : "; ") + step + ": " + hipGetErrorString(e);
+        if (attempt == 2 || form == 1) {
+            set_last_error_text("eph_peer_create: " + why);
+            return e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_COMM;
         }
     }
-    t->base_[rank] = p;
-    EPH_HIP(hipMemset(p, 0, kPeerHeader));
-    EPH_HIP(hipDeviceSynchronize());
-    EPH_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t *>(t->handle_), p));
+    t->fallback_reason_ = why;
     EPH_HIP(hipHostMalloc((void **)&t->status_, sizeof(unsigned), hipHostMallocMapped));
     *t->status_ = 0;
     EPH_HIP(hipHostGetDevicePointer((void **)&t->status_dev_, t->status_, 0));
@@ -153,9 +179,22 @@ int PeerTransport::connect(const void *handles) {
         hipIpcMemHandle_t mh;
         std::memcpy(&mh, h + (size_t)r * kPeerHandleBytes, sizeof(mh));
         void *p = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess);
+        hipError_t e = peer_force_fail("open") && form_ == 1 ? hipErrorInvalidValue : hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess && !(peer_force_fail("open") && form_ == 1)) {
+            // lazy peer enabling did not do it: enable access to every other device explicitly and try once more
+            (void)hipGetLastError();
+            int ndev = 0;
+            (void)hipGetDeviceCount(&ndev);
+            for (int d = 0; d < ndev; ++d)
+                if (d != device_) { (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
+            e = hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess);
+        }
         if (e != hipSuccess) {
-            set_last_error("hipIpcOpenMemHandle (peer mailbox)", e);
+            (void)hipGetLastError();
+            for (int q = 0; q < r; ++q)                  // leave nothing half-mapped: the caller may re-create in the other form
+                if (q != rank_ && base_[q]) { (void)hipIpcCloseMemHandle(base_[q]); base_[q] = nullptr; }
+            set_last_error_text(std::string("eph_peer_connect: hipIpcOpenMemHandle of rank ") + std::to_string(r) + "'s " +
+                                (form_ == 1 ? "fine-grained" : "coarse") + " mailbox: " + hipGetErrorString(e));
             return EPH_ERR_COMM;
         }
         base_[r] = p;

@@ -404,12 +404,18 @@ int NBodyPropagator::fit_and_push(int64_t done, hipStream_t s) {
     if ((st = launch_carry(s, n, d_region_.p, d_src_.p, d_cnt_.p, log_.p))) return st;
     EPH_HIP(hipStreamSynchronize(s));
     if (sharded) {
+        // a peer that never delivered its records (peer.hip: bounded wait): nothing gathered may be unpacked
+        if ((st = integ_->exchange_error())) return st;
         for (int r = 0; r < world; ++r) {
             const int64_t a0 = qstart[body_lo(r)], a1 = qstart[body_lo(r + 1)];
             for (int64_t q = a0; q < a1; ++q) {
                 const double *src = all.data() + (size_t)r * slice_d + (size_t)(q - a0) * rec;
                 std::copy(src, src + kDiv * 3, co.begin() + q * kDiv * 3);
                 nc[q] = (int32_t)src[kDiv * 3];
+                if (!(src[kDiv * 3] >= 0.0 && src[kDiv * 3] <= (double)kDiv)) {       // not a record a rank packed
+                    set_last_error_text("sharded propagator: a gathered polynomial record carries ncoef outside [0, 8]");
+                    return EPH_ERR_COMM;
+                }
             }
         }
     }

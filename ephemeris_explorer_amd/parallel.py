@@ -119,12 +119,29 @@ def peer_transport(dist, slot_bytes=1 << 22, group=None):
     torch.distributed (all_gather_object: any backend), the data never does."""
     from . import PeerTransport
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    t = PeerTransport(rank, world, slot_bytes)
-    handles = [None] * world
-    dist.all_gather_object(handles, t.handle, group=group)
-    t.connect(handles)
-    dist.barrier(group=group)                        # every rank has mapped every mailbox before the first push
-    return t
+    errors = []
+    for memory in ("auto", "coarse"):                # a second round in plain device memory if ANY rank could not map a mailbox
+        err, t = None, None
+        try:
+            t = PeerTransport(rank, world, slot_bytes, memory=memory)
+        except Exception as e:                       # (the collective below must still be entered by every rank)
+            err = f"rank {rank} create[{memory}]: {e}"
+        handles = [None] * world
+        dist.all_gather_object(handles, t.handle if t is not None else None, group=group)
+        if err is None and all(h is not None for h in handles):
+            try:
+                t.connect(handles)
+            except Exception as e:
+                err = f"rank {rank} connect[{memory}]: {e}"
+        outcome = [None] * world
+        dist.all_gather_object(outcome, (err, t.memory if t is not None else None), group=group)
+        if all(o[0] is None for o in outcome):       # every rank has mapped every mailbox before the first push
+            t.forms = [o[1] for o in outcome]
+            t.attempts = errors
+            return t
+        errors += [o[0] for o in outcome if o[0] is not None]
+        del t
+    raise RuntimeError("peer transport could not be set up: " + " | ".join(errors))
 
 
 def shard_nbody(integration, dist=None, transport="rccl", device="cpu"):

@@ -62,6 +62,11 @@ const char *eph_last_error(void);
 int32_t eph_device_count(int32_t *count);
 int32_t eph_set_device(int32_t device);
 int32_t eph_device_name(char *buf, int32_t buflen);
+/* The library keeps device blocks of >= 64 MiB that a destroyed handle owned (the knot slabs of a spacecraft batch are GBs) for
+ * the next handle that asks for exactly that size, up to a quarter of the device (EPH_POOL_MAX_MB overrides; 0 disables): a
+ * sweep loop creates identical batches, and taking GB-sized blocks from the driver and handing them back costs ~100 ms per batch.
+ * This call returns the cache to the driver; *bytes (optional) = what was released. */
+int32_t eph_release_cached_memory(uint64_t *bytes);
 
 /* ---- coefficient tables (integration/src/methods.rs, ratio.rs:221-228) ---------------------------
  * The f64 value of every coefficient exactly as the reference multiplies with it. */
@@ -161,6 +166,17 @@ int32_t eph_nbody_shard(eph_nbody *h, int32_t rank, int32_t world, const void *r
  * get_state. Works between processes on one device as well as across devices with peer access (xGMI). world <= 16. */
 typedef struct eph_peer eph_peer;
 int32_t eph_peer_create(int32_t rank, int32_t world, uint64_t slot_bytes, eph_peer **out);
+/* The mailbox lives in fine-grained device memory when that can be allocated and its hipIpc handle exported, in plain
+ * hipMalloc memory otherwise (every mailbox access in the kernel is system-scope either way). eph_peer_create is
+ * eph_peer_create_ex(.., EPH_PEER_MEMORY_AUTO, ..); eph_peer_memory_form reports which form is live (and, after a fallback,
+ * leaves the reason in eph_last_error). If eph_peer_connect fails (EPH_ERR_COMM: a peer's mailbox could not be mapped even
+ * after enabling peer access explicitly), every rank destroys its eph_peer, re-creates it with EPH_PEER_MEMORY_COARSE and
+ * exchanges handles again -- ephemeris_explorer_amd/parallel.py peer_transport() does exactly that. */
+#define EPH_PEER_MEMORY_AUTO 0
+#define EPH_PEER_MEMORY_FINE 1
+#define EPH_PEER_MEMORY_COARSE 2
+int32_t eph_peer_create_ex(int32_t rank, int32_t world, uint64_t slot_bytes, int32_t memory_form, eph_peer **out);
+int32_t eph_peer_memory_form(eph_peer *p, int32_t *form);
 int32_t eph_peer_handle(eph_peer *p, void *out64);
 int32_t eph_peer_connect(eph_peer *p, const void *handles_world_x_64);
 int32_t eph_peer_destroy(eph_peer *p);

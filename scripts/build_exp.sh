@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/ephemeris_explorer_amd/csrc
 out=/tmp/eph_exp_$name
 mkdir -p $out
-for f in kernels.hip craft.hip peer.hip coeffs.cpp nbody.cpp propagator.cpp shard.cpp api.cpp; do
+for f in kernels.hip craft.hip peer.hip mem.cpp coeffs.cpp nbody.cpp propagator.cpp shard.cpp api.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" -x hip -c $src/$f -o $out/${f%.*}.o &
 done
 wait
