@@ -20,10 +20,8 @@ from . import systems  # noqa: F401  (state.json / ephemeris.json / ships reader
 _HERE = Path(__file__).resolve().parent
 import os as _os
 
-# EPH_AMD_PAIR_VARIANT=k (1..6) loads libephemeris_amd_pv<k>.so: the same library built with another evaluation order
-# of the (unpinned) point-mass term -- csrc/device_math.h. Default: the product library.
-_PV = int(_os.environ.get("EPH_AMD_PAIR_VARIANT", "0") or 0)
-LIB_PATH = _HERE / ("libephemeris_amd.so" if _PV == 0 else f"libephemeris_amd_pv{_PV}.so")
+# (the evaluation order of the point-mass term is a run-time choice now: set_pair_variant(k) / EPH_PAIR_VARIANT=k)
+LIB_PATH = _HERE / "libephemeris_amd.so"
 if _os.environ.get("EPH_AMD_LIBRARY"):            # tuning builds (scripts/): another build of the same sources
     LIB_PATH = Path(_os.environ["EPH_AMD_LIBRARY"])
 
@@ -40,7 +38,7 @@ ERR_BAD_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY = -
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
 
 ABI_SYMBOLS = [
-    "eph_abi_version", "eph_pair_variant", "eph_release_cached_memory", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
+    "eph_abi_version", "eph_pair_variant", "eph_set_pair_variant", "eph_release_cached_memory", "eph_status_string", "eph_last_error", "eph_device_count", "eph_set_device",
     "eph_device_name", "eph_srkn_coeffs", "eph_elm2_coeffs", "eph_accel_eval",
     "eph_nbody_create", "eph_nbody_advance", "eph_nbody_get_state", "eph_nbody_get_acc", "eph_nbody_set_bound",
     "eph_nbody_clone", "eph_nbody_destroy", "eph_nbody_eval_count", "eph_nbody_set_path", "eph_nbody_kernel_time",
@@ -51,7 +49,7 @@ ABI_SYMBOLS = [
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
-    "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_inv_r3_sweep", "eph_debug_wg_cycles",
+    "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_quot", "eph_debug_inv_r3_sweep", "eph_debug_wg_cycles",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_summary", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
@@ -125,8 +123,7 @@ def _lib():
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.eph_abi_version.restype = i32
     L.eph_pair_variant.restype = i32
-    if L.eph_pair_variant() != _PV:
-        raise ImportError(f"{LIB_PATH} was built with EPH_PAIR_VARIANT={L.eph_pair_variant()}, expected {_PV}")
+    L.eph_set_pair_variant.argtypes = [i32]
     L.eph_status_string.restype = C.c_char_p
     L.eph_status_string.argtypes = [i32]
     L.eph_last_error.restype = C.c_char_p
@@ -301,6 +298,25 @@ def least_squares_fit(degree, samples, backward=False):
     _check(_lib().eph_least_squares_fit(int(degree), int(bool(backward)), nwin, _p(samples), _p(co), _p(nc, _i32p)),
            "eph_least_squares_fit")
     return co, nc
+
+
+def pair_variant():
+    """the evaluation order of the point-mass term new handles take (eph_pair_variant)"""
+    return int(_lib().eph_pair_variant())
+
+
+def set_pair_variant(k):
+    """eph_set_pair_variant: the order (0..6, csrc/pair_term.h) for every handle created afterwards"""
+    _check(_lib().eph_set_pair_variant(int(k)), "eph_set_pair_variant")
+
+
+def debug_quot(x, a):
+    """test hook: (fast, ieee) device evaluations of a / (x * sqrt(x)) -- the division forms' shared-reciprocal quotient"""
+    x, a = _f64(x), _f64(a)
+    fast, ieee = np.zeros_like(x), np.zeros_like(x)
+    _lib().eph_debug_quot.argtypes = [C.c_int64, _dp, _dp, _dp, _dp]
+    _check(_lib().eph_debug_quot(x.size, _p(x), _p(a), _p(fast), _p(ieee)), "eph_debug_quot")
+    return fast, ieee
 
 
 def debug_inv_r3(n2):

@@ -7,9 +7,13 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libephemeris_amd.so"
-N_PAIR_VARIANTS = 7      # csrc/device_math.h: 0 = the product, 1..6 = other orders of the unpinned point-mass term
-SOURCES = ["kernels.hip", "craft.hip", "peer.hip", "mem.cpp", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
-HEADERS = ["eph_internal.h", "host.h", "device_math.h", "coeff_tables.inc", "cr_pow_tables.inc", "chain_tile.inc", "craft_attempt.inc", "../../include/ephemeris_amd.h"]
+N_PAIR_VARIANTS = 7      # csrc/pair_term.h: the evaluation orders of the unpinned point-mass term, all in the one library
+# compiled once per evaluation order (-DEPH_PAIR_VARIANT=k, every symbol in namespace eph::pv<k>; csrc/pair_ns.h)
+PAIR_SOURCES = ["step_wg.hip", "step_wave.hip", "step_small.hip", "fast.hip", "craft_sweep.hip"]
+# compiled once
+SOURCES = ["solout.hip", "craft.hip", "peer.hip", "dispatch.cpp", "mem.cpp", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
+HEADERS = ["eph_internal.h", "host.h", "ieee_seq.h", "pair_term.h", "pair_ns.h", "pair_launchers.h", "force_common.h", "craft_device.h",
+           "coeff_tables.inc", "cr_pow_tables.inc", "craft_attempt.inc", "../../include/ephemeris_amd.h"]
 # -ffp-contract=off is REQUIRED for parity (HIP's default is fast contraction): the reference never fuses a*b+c.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -23,56 +27,67 @@ def hipcc():
     return "hipcc"
 
 
-def lib_path(pair_variant=0):
-    return LIB if pair_variant == 0 else HERE / f"libephemeris_amd_pv{pair_variant}.so"
+def units():
+    """(source, object, extra flags) of every translation unit of the library"""
+    out = [(src, CSRC / (src.rsplit(".", 1)[0] + ".o"), []) for src in SOURCES]
+    for k in range(N_PAIR_VARIANTS):
+        out += [(src, CSRC / (src.rsplit(".", 1)[0] + f".pv{k}.o"), [f"-DEPH_PAIR_VARIANT={k}"]) for src in PAIR_SOURCES]
+    return out
 
 
-def needs_build(pair_variant=0):
-    lib = lib_path(pair_variant)
+def needs_build(lib=LIB):
     if not lib.exists():
         return True
     t = lib.stat().st_mtime
-    return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS) or Path(__file__).stat().st_mtime > t
+    return any((CSRC / f).stat().st_mtime > t for f in SOURCES + PAIR_SOURCES + HEADERS) or Path(__file__).stat().st_mtime > t
 
 
-def build(force=False, verbose=False, pair_variant=0):
-    """pair_variant 0 = the product library; 1..6 = the same sources with -DEPH_PAIR_VARIANT=k (another evaluation
-    order of the point-mass term whose reference source is absent, csrc/device_math.h) -> libephemeris_amd_pv<k>.so."""
-    LIB = lib_path(pair_variant)
-    if not force and not needs_build(pair_variant):
-        return LIB
-    objs = []
-    procs = []
-    suffix = "" if pair_variant == 0 else f".pv{pair_variant}"
-    flags = FLAGS + ([] if pair_variant == 0 else [f"-DEPH_PAIR_VARIANT={pair_variant}"])
-    for src in SOURCES:
-        obj = CSRC / (src.rsplit(".", 1)[0] + suffix + ".o")
-        cmd = [hipcc(), *flags, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+def build(force=False, verbose=False, lib=LIB, extra_flags=(), obj_dir=None, jobs=None):
+    """Compiles every translation unit (objects whose source and headers are older than the object are kept) and links
+    libephemeris_amd.so. `lib` / `extra_flags` / `obj_dir`: an experimental build beside the product one (scripts/build_exp.sh)."""
+    if not force and not extra_flags and not needs_build(lib):
+        return lib
+    from concurrent.futures import ThreadPoolExecutor
+    newest_header = max((CSRC / h).stat().st_mtime for h in HEADERS)
+    newest_header = max(newest_header, Path(__file__).stat().st_mtime)
+    todo, objs = [], []
+    for src, obj, fl in units():
+        if obj_dir is not None:
+            obj = Path(obj_dir) / obj.name
+        objs.append(str(obj))
+        if force or extra_flags or not obj.exists() or obj.stat().st_mtime < max((CSRC / src).stat().st_mtime, newest_header):
+            todo.append((src, obj, fl))
+
+    def compile_one(job):
+        src, obj, fl = job
+        cmd = [hipcc(), *FLAGS, *fl, *extra_flags, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(str(obj))
-    for src, p in procs:
-        out, _ = p.communicate()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if p.returncode:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-        if verbose and out:
-            print(out.decode(), file=sys.stderr)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs]
-    subprocess.check_call(cmd)
-    return LIB
+            raise RuntimeError(f"hipcc failed on {src} {' '.join(fl)}:\n{p.stdout.decode()}")
+        if verbose and p.stdout:
+            print(p.stdout.decode(), file=sys.stderr)
+
+    # the largest units first, so that the tail of the build is short
+    todo.sort(key=lambda j: -(CSRC / j[0]).stat().st_size)
+    with ThreadPoolExecutor(jobs or max(2, (os.cpu_count() or 4))) as ex:
+        list(ex.map(compile_one, todo))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
+    return lib
 
 
 def build_all(force=False, verbose=False):
-    """The product library and the six pair-variant builds, compiled concurrently."""
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(4) as ex:
-        return list(ex.map(lambda k: build(force, verbose, k), range(N_PAIR_VARIANTS)))
+    """(round 3 built one library per evaluation order; they are all in the one library now)"""
+    return [build(force, verbose)]
 
 
 if __name__ == "__main__":
-    pv = int(sys.argv[sys.argv.index("--pair-variant") + 1]) if "--pair-variant" in sys.argv else 0
-    if "--all" in sys.argv:
-        print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--exp" in sys.argv:          # python -m ephemeris_explorer_amd.build --exp NAME [-DFLAG ...]
+        i = sys.argv.index("--exp")
+        name, flags = sys.argv[i + 1], sys.argv[i + 2:]
+        od = Path("/tmp") / f"eph_exp_{name}"
+        od.mkdir(parents=True, exist_ok=True)
+        print(build(force=True, verbose=False, lib=HERE / f"libephemeris_amd_exp_{name}.so", extra_flags=flags, obj_dir=od))
     else:
-        print(build(force="--force" in sys.argv, verbose=True, pair_variant=pv))
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -50,7 +50,8 @@ struct eph_prop {
 extern "C" {
 
 int32_t eph_abi_version(void) { return EPH_ABI_VERSION; }
-int32_t eph_pair_variant(void) { return EPH_PAIR_VARIANT; }
+int32_t eph_pair_variant(void) { return eph::default_pair_variant(); }
+int32_t eph_set_pair_variant(int32_t k) { return eph::set_default_pair_variant(k); }
 int32_t eph_release_cached_memory(uint64_t *bytes) {
     const size_t b = eph::release_cached_memory();
     if (bytes) *bytes = (uint64_t)b;
@@ -572,7 +573,25 @@ int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee
     DevBuf<double> a, b, c;
     if ((st = a.alloc(n)) || (st = b.alloc(n)) || (st = c.alloc(n))) return st;
     EPH_HIP(hipMemcpy(a.p, n2, sizeof(double) * n, hipMemcpyHostToDevice));
-    if ((st = launch_debug_inv_r3(nullptr, n, a.p, b.p, c.p))) return st;
+    if ((st = launch_debug_inv_r3(default_pair_variant(), nullptr, n, a.p, b.p, c.p))) return st;
+    EPH_HIP(hipMemcpy(fast, b.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    EPH_HIP(hipMemcpy(ieee, c.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return EPH_OK;
+    EPH_GUARD_END
+}
+
+// a / (x * sqrt(x)) through the division forms' seeded reciprocal + Markstein step, and through the compiler's IEEE expansions
+int32_t eph_debug_quot(int64_t n, const double *x, const double *a, double *fast, double *ieee) {
+    EPH_GUARD_BEGIN
+    if (n < 0 || (n > 0 && (!x || !a || !fast || !ieee))) return EPH_ERR_BAD_ARGUMENT;
+    int st = check_device();
+    if (st) return st;
+    if (n == 0) return EPH_OK;
+    DevBuf<double> dx, da, b, c;
+    if ((st = dx.alloc(n)) || (st = da.alloc(n)) || (st = b.alloc(n)) || (st = c.alloc(n))) return st;
+    EPH_HIP(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    EPH_HIP(hipMemcpy(da.p, a, sizeof(double) * n, hipMemcpyHostToDevice));
+    if ((st = launch_debug_quot(default_pair_variant(), nullptr, n, dx.p, da.p, b.p, c.p))) return st;
     EPH_HIP(hipMemcpy(fast, b.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     EPH_HIP(hipMemcpy(ieee, c.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     return EPH_OK;
@@ -587,7 +606,7 @@ int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, u
     DevBuf<unsigned long long> out;
     if ((st = out.alloc(2))) return st;
     EPH_HIP(hipMemset(out.p, 0, 2 * sizeof(unsigned long long)));
-    if ((st = launch_debug_inv_r3_sweep(nullptr, seed, n, out.p))) return st;
+    if ((st = launch_debug_inv_r3_sweep(default_pair_variant(), nullptr, seed, n, out.p))) return st;
     unsigned long long h[2];
     EPH_HIP(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
     *mismatches = h[0];
@@ -598,7 +617,7 @@ int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, u
 
 int32_t eph_debug_wg_cycles(int64_t *out8) {
     if (!out8) return EPH_ERR_BAD_ARGUMENT;
-    return debug_wg_cycles((long long *)out8);
+    return debug_wg_cycles(default_pair_variant(), (long long *)out8);
 }
 
 // SpacecraftPropagator::join  spacecraft.rs:558-561 = CubicHermiteSpline::clear_after (trajectory.rs:842-845) + extend

@@ -1,0 +1,791 @@
+// craft_sweep.hip -- the massless sweep's kernels: one device thread (k_craft_propagate, k_craft_queue) or one wave
+// (k_craft_wave) per spacecraft runs the whole adaptive embedded Runge-Kutta loop against the massive bodies' piecewise-polynomial
+// ephemeris. Compiled once per evaluation order of the point-mass term (pair_ns.h); the host side of the batch, the event
+// search and the evaluators are in craft.hip. Mirrors (paths relative to the reference repository root):
+//   SpacecraftPropagator::{new, step, reset_integrator}, SpacecraftModel, Timeline, CubicHermiteSplineSolout
+//                                                       ephemeris/src/propagators/spacecraft.rs:58-332,415-695
+//   AdaptiveRungeKuttaIntegrator::advance, IController::step, PreviousStep
+//                                                       integration/src/runge_kutta/mod.rs:188-285,396-440
+//   ERK::{advance, error, undo_step}                    integration/src/runge_kutta/explicit.rs:54-141
+//   Bodies::acceleration, GravitationalBody::acceleration_at, TNB, ReferenceFrame, AbsTol
+//                                                       ephemeris_explorer/src/dynamics/spacecraft.rs:70-74,218-293,609-641
+// Same f64 operations in the same order as the CPU path (-ffp-contract=off).
+#include <algorithm>
+
+#include "pair_ns.h"
+#include "craft_device.h"
+
+namespace eph {
+namespace EPH_PV_NS {
+
+#ifndef EPH_CRAFT_SCALAR_ROWS
+#define EPH_CRAFT_SCALAR_ROWS 1
+#endif
+// One body's term of Bodies::acceleration (dynamics/spacecraft.rs:70-74,222-228): segment lookup, Horner, point mass.
+__device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &be, double t, const V3 &pos, V3 &term) {
+    long long idx;
+    double tau;
+    if (!spline_locate_fast(be, t, idx, tau)) return false;
+    // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so
+    // the leading steps give 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no
+    // ncoef load, no loop, and twelve 16-byte loads in flight at once
+    V3 bp = {0.0, 0.0, 0.0};
+    const long long row = be.coeff_off + idx;         // (in the wave-per-craft form of > 64 bodies the lanes differ in be too)
+    const long long row0 = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)row) |
+                           ((long long)__builtin_amdgcn_readfirstlane((int)(row >> 32)) << 32);
+    if (EPH_CRAFT_SCALAR_ROWS && __builtin_amdgcn_ballot_w64(row != row0) == 0) {
+        // every lane of the wave is inside the SAME polynomial (craft of one sweep started together: the usual case): its 24
+        // coefficients come through the scalar cache into SGPRs instead of 64 lanes x 192 B through the vector L1
+        const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(a.coeffs + row0 * kDiv * 3);
+#pragma unroll
+        for (int k = kDiv - 1; k >= 0; --k) {
+            bp.x = bp.x * tau + cs[k * 3 + 0];
+            bp.y = bp.y * tau + cs[k * 3 + 1];
+            bp.z = bp.z * tau + cs[k * 3 + 2];
+        }
+    } else {
+        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + row * kDiv * 3);
+        double c[kDiv * 3];
+#pragma unroll
+        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
+#pragma unroll
+        for (int k = kDiv - 1; k >= 0; --k) {
+            bp.x = bp.x * tau + c[k * 3 + 0];
+            bp.y = bp.y * tau + c[k * 3 + 1];
+            bp.z = bp.z * tau + c[k * 3 + 2];
+        }
+    }
+    const V3 d = sub(bp, pos);                        // acceleration_at::<false>: dir = body - at
+    const double n2 = dot(d, d);
+    // the point-mass term in the build's evaluation order, IEEE sqrt and divide (device_math.h)
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) pair_apply<true>(pair_den<true>(n2), d.x, d.y, d.z, be.mu, term.x, term.y, term.z);
+    else pair_apply<false>(pair_den<false>(n2), d.x, d.y, d.z, be.mu, term.x, term.y, term.z);
+    return true;
+}
+// k_craft_wave: lane b always evaluates body b, so the body's table entry, the refined reciprocal of its spline
+// interval and the coefficients of the polynomial it is currently in stay in the lane's registers; the polynomial is
+// reloaded only when the segment index changes (every few hundred steps). Used when n_bodies <= 64.
+struct LaneBody {
+    BodyEntry be;
+    double r;                 // rcp_refined(be.interval)
+    bool b_ok;                // interval in range for the wrapper-free division
+    long long idx;            // segment whose coefficients are in c (-1: none)
+    double c[kDiv * 3];
+};
+__device__ __forceinline__ bool body_term_cached(const CraftArgs &a, LaneBody &lb, double t, const V3 &pos, V3 &term) {
+    // UniformSpline::get_polynomial, the two divisions by the interval through the shared reciprocal (same quotients)
+    const BodyEntry &b = lb.be;
+    const double local = t - b.start;
+    if (__builtin_signbit(local) || local > b.span) return false;
+    const double cq = ceil(div_shared(local, b.interval, lb.r, lb.b_ok));
+    unsigned long long i;
+    double fi;
+    if (__builtin_amdgcn_ballot_w64(!(cq < 2147483648.0)) == 0) {
+        const unsigned ci = cq <= 0.0 ? 0u : (unsigned)cq;
+        const unsigned i32 = ci == 0 ? 0u : ci - 1u;
+        i = i32;
+        fi = (double)i32;
+    } else {
+        const unsigned long long ci = cq <= 0.0 ? 0ull : (cq >= 18446744073709551616.0 ? ~0ull : (unsigned long long)cq);
+        i = ci == 0 ? 0 : ci - 1;
+        fi = (double)i;
+    }
+    if (i >= (unsigned long long)b.npoly) return false;
+    const long long idx = (long long)i;
+    const double tau = div_shared(local - b.interval * fi, b.interval, lb.r, lb.b_ok);
+    if (idx != lb.idx) {
+        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (b.coeff_off + idx) * kDiv * 3);
+#pragma unroll
+        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; lb.c[2 * q] = v.x; lb.c[2 * q + 1] = v.y; }
+        lb.idx = idx;
+    }
+    V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + lb.c[k * 3 + 0];
+        bp.y = bp.y * tau + lb.c[k * 3 + 1];
+        bp.z = bp.z * tau + lb.c[k * 3 + 2];
+    }
+    const V3 d = sub(bp, pos);
+    const double n2 = dot(d, d);
+    if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) pair_apply<true>(pair_den<true>(n2), d.x, d.y, d.z, b.mu, term.x, term.y, term.z);
+    else pair_apply<false>(pair_den<false>(n2), d.x, d.y, d.z, b.mu, term.x, term.y, term.z);
+    return true;
+}
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kRedRow = kTile + 2;                    // LDS row of the wave variant's contribution tile
+
+// FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.
+// WAVE = false: one thread per spacecraft, the bodies in a loop. WAVE = true: one WAVE per spacecraft (every lane
+// carries the same craft state): lane b evaluates body b, the terms go through LDS and lanes 0..2 add them in body
+// order -- the same chain of f64 additions -- then the sum is broadcast. `red` = 3 x kRedRow doubles of LDS.
+template <bool WAVE>
+__device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &sg, double t, const double (&y)[6],
+                                          double (&dy)[6], double *red, LaneBody *lb = nullptr) {
+    const V3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
+    V3 acc = {0.0, 0.0, 0.0};
+    if (WAVE) {
+        const int lane = threadIdx.x;
+        for (int b0 = 0; b0 < a.n_bodies; b0 += kTile) {
+            const int b = b0 + lane;
+            V3 term = {0.0, 0.0, 0.0};
+            bool located = true;
+            if (b < a.n_bodies) {
+                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);
+                else {
+                    const BodyEntry be = a.bodies[b];
+                    located = body_term(a, be, t, pos, term);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!located)) return false;
+            red[lane] = term.x;                       // lanes past the last body contribute +0.0 (exact to add)
+            red[kRedRow + lane] = term.y;
+            red[2 * kRedRow + lane] = term.z;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int left = a.n_bodies - b0;
+            const int cnt = ((left < kTile ? left : kTile) + 15) & ~15;
+            double sum = lane == 0 ? acc.x : (lane == 1 ? acc.y : acc.z);
+            if (lane < 3) {
+                const double *row = red + lane * kRedRow;
+                for (int c = 0; c < cnt; c += 16) {
+                    double2 r[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const double2 *>(row + c + 2 * k);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        sum = sum + r[k].x;
+                        sum = sum + r[k].y;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            acc.x = lane_bcast(sum, 0);
+            acc.y = lane_bcast(sum, 1);
+            acc.z = lane_bcast(sum, 2);
+        }
+    } else {
+        for (int b = 0; b < a.n_bodies; ++b) {        // Bodies::acceleration: index order
+            // the body's table entry is the same for every lane: scalar loads through the constant address space
+            const int bu = __builtin_amdgcn_readfirstlane(b);
+            const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
+            BodyEntry be;
+            be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
+            be.coeff_off = bc->coeff_off; be.span = bc->span; be.rinv = bc->rinv;
+            V3 term;
+            if (!body_term(a, be, t, pos, term)) return false;
+            acc = add(acc, term);
+        }
+    }
+    V3 man = {0.0, 0.0, 0.0};
+    if (sg.is_burn) {
+        const V3 thrust = {sg.ax, sg.ay, sg.az};
+        if (sg.ref >= 0) {                            // ReferenceFrame::Relative -> TNB::try_new(sv - ref.state_vector(t))
+            const BodyEntry be = a.bodies[sg.ref];
+            long long idx;
+            double tau;
+            if (!spline_locate(be, t, idx, tau)) return false;
+            const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
+            const int nc = a.ncoef[be.coeff_off + idx];
+            double rp[3], rv[3];
+            for (int c = 0; c < 3; ++c) {             // Polynomial::eval_and_deriv
+                const double first = nc ? co[c] : 0.0;
+                const double last = nc ? co[(nc - 1) * 3 + c] : 0.0;
+                double e = last, d = last;
+                for (int k = nc - 2; k >= 1; --k) {
+                    e = e * tau + co[k * 3 + c];
+                    d = d * tau + e;
+                }
+                e = e * tau + first;
+                rp[c] = e;
+                rv[c] = d / be.interval;
+            }
+            const V3 rel_p = sub(pos, V3{rp[0], rp[1], rp[2]}), rel_v = sub(vel, V3{rv[0], rv[1], rv[2]});
+            V3 x, yv;
+            if (!try_normalize(rel_v, x)) return false;
+            if (!try_normalize(cross(rel_p, rel_v), yv)) return false;
+            const V3 xy = cross(x, yv);
+            const V3 z = scale(xy, length_recip(xy));
+            V3 r = scale(x, thrust.x);                // DMat3::from_cols(x, z, y).mul_vec3(thrust)
+            r = add(r, scale(z, thrust.y));
+            r = add(r, scale(yv, thrust.z));
+            man = r;
+        } else {                                      // TNB::IDENTITY.mul_vec3(thrust)
+            V3 r = scale(V3{1.0, 0.0, 0.0}, thrust.x);
+            r = add(r, scale(V3{0.0, 1.0, 0.0}, thrust.y));
+            r = add(r, scale(V3{0.0, 0.0, 1.0}, thrust.z));
+            man = r;
+        }
+    }
+    const V3 tot = add(acc, man);
+    dy[0] = vel.x; dy[1] = vel.y; dy[2] = vel.z;
+    dy[3] = tot.x; dy[4] = tot.y; dy[5] = tot.z;
+    return true;
+}
+
+// NYS = false: ERK pair on the 6-vector (explicit.rs).  NYS = true: ERKNG pair on SecondOrderState<[DVec3; 1]>
+// (nystrom/explicit_generalized.rs:97-170, the app's Fine45): k[s][0..2] hold dk[s].
+// Register budget (OCC = waves per SIMD the allocation is held to): the 13- and 16-stage pairs need > 256 registers
+// for the stage derivatives, which leaves ONE wave per SIMD and every L1 hit of the coefficient loads exposed
+// (measured, rocprofv3: 48 % of wave time parked on s_waitcnt, 46 % issuing). With more than one wave of craft per
+// SIMD, two resident waves with the surplus k[][] spilled to scratch are faster (262144 craft: 1.96e8 vs 1.2e8
+// craft-steps/s); with fewer, the unconstrained allocation is (65536 craft: 1.14e8 vs 1.01e8). craft_launch picks
+// by batch size. (Also measured: a runtime stage loop around ONE copy of the right-hand side, stage combinations
+// selected by a uniform switch -- 4x less code than this unrolled form, which exceeds the instruction cache -- is
+// slower, 1.03e8 / 1.12e8: every k[][] element then stays live across the loop and the allocator spills more.)
+// The sweep, STATIC form: craft i on thread i for the whole call. The right form when every craft takes about the same
+// number of attempts (the north star's sweep: one transfer arc +- 100 km, max / mean attempts per wave 1.09) or when the
+// batch fits the chip at once -- which a heterogeneous batch becomes, wave by wave, once its craft are dealt to the lanes by the
+// time scale of their orbits (craft_sort: a.perm; the knot slabs keep lane columns). k_craft_queue below is the form for
+// heterogeneous batches that were not dealt (craft_launch chooses).
+template <int S, bool FSAL, bool NYS = false, int OCC = 1>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+k_craft_propagate(const CraftArgs a) {
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_craft) return;
+    const long long i = a.perm ? a.perm[slot] : slot;
+    const long long n = a.n_craft;
+    int status = a.status[i];
+    if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
+    status = EPH_OK;
+
+    double time = a.time[i], y[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) y[d] = a.y[d * n + i];
+    double next_h = a.next_h[i];
+    unsigned n_att = a.n_attempts[i], rk_i = a.rk_i[i], steps = a.steps[i];
+    int cur = a.cur_seg[i], nk = a.nknots[i];
+    double last_knot = a.last_knot_t[i];
+    const SegmentDev *segs = a.segs + a.seg_off[i];
+    SegmentDev sg = segs[cur];
+    double bound = sg.end;
+    double k[S][6];
+    if (FSAL) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) k[S - 1][d] = a.klast[d * n + i];
+    }
+    const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+
+    unsigned taken = 0;
+    while (!(last_knot >= a.t_end) && !(a.step_limit && taken >= a.step_limit)) {   // has_reached: solution.end() >= time
+        if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
+        // SpacecraftPropagator::step: advance_timeline + reset_integrator  spacecraft.rs:606-609
+        if (time >= sg.end) {
+            cur += 1;
+            sg = segs[cur];
+            bound = sg.end;
+            next_h = a.h_init;
+            n_att = 0;
+            rk_i = 0;
+        }
+        // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439
+        const double prev_t = time;
+        double prev_y[6], prev_klast[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? k[S - 1][d] : 0.0; }
+        const unsigned prev_i = rk_i;
+        bool failed = false;
+        for (;;) {
+            if (n_att > a.n_max) { status = EPH_MAX_ITERATIONS_REACHED; failed = true; break; }
+            if (time + next_h > bound) next_h = bound - time;
+            const double h = next_h;
+            if (time >= bound) { status = EPH_BOUND_REACHED; failed = true; break; }
+            if (time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; break; }
+#define EPH_RK a.rk
+#define EPH_ATTEMPT_PART 1
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+            if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
+#define EPH_ATTEMPT_PART 2
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+#undef EPH_RK
+            time = time + h;
+            rk_i += 1;
+            n_att += 1;
+            // AbsTol::err_over_tol
+            const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
+            const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
+            const double err = fmax(pm, vm);
+            // IController::step  mod.rs:225-243
+            const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
+            const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
+            const double nh = next_h * c;
+            next_h = nh > a.h_max ? a.h_max : nh;
+            if (err <= 1.0) break;
+            time = prev_t;                            // PreviousStep::restore
+#pragma unroll
+            for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+            rk_i = prev_i;
+            if (FSAL) {
+#pragma unroll
+                for (int d = 0; d < 6; ++d) k[S - 1][d] = prev_klast[d];
+            }
+        }
+        if (failed) break;
+        steps += 1;
+        taken += 1;
+        // CubicHermiteSplineSolout::solout: push (t, r, v)
+        a.knot_t[(long long)nk * n + slot] = time;      // (knot slabs are in LANE order: coalesced whatever the deal)
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + slot] = y[d];
+        nk += 1;
+        last_knot = time;
+    }
+
+    a.time[i] = time;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a.y[d * n + i] = y[d];
+    a.next_h[i] = next_h;
+    a.n_attempts[i] = n_att;
+    a.rk_i[i] = rk_i;
+    a.steps[i] = steps;
+    a.cur_seg[i] = cur;
+    a.nknots[i] = nk;
+    a.last_knot_t[i] = last_knot;
+    a.status[i] = status;
+    if (FSAL) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+    }
+}
+
+// The sweep, QUEUE form, for batches whose craft need very different numbers of attempts (adaptive step counts differ by
+// more than 10x between a low orbit and a heliocentric cruise: bench.py --population mixed, max / mean attempts per wave
+// 2.9). A PERSISTENT grid (craft_launch sizes it to what the chip holds) and a work queue: lane L starts with craft L; a
+// lane whose craft is finished (reached t_end, took its steps, failed, or filled its knot slab) stores it and takes the
+// next unstarted craft from an atomic counter (a.queue), so a wave does not idle 63 lanes waiting for its slowest craft.
+// For the same reason the loop is FLAT: one iteration = one ATTEMPT of every active lane; accepting (knot) or rejecting
+// (restore) is lane-local bookkeeping after it, so an accepted lane does not sit through its neighbours' retries.
+// Measured (MI355X, Verner87, 524 288 mixed craft x 2 d): static 605 ms, queue with whole steps per iteration 492 ms, this
+// form 370 ms; on the homogeneous sweep it is 10 % slower than the static kernel (42.6 vs 38.7 ms) -- hence two kernels.
+// Craft are independent and every craft's operations are the reference's in the reference's order, so which lane
+// integrates a craft, and when, does not touch a bit of its result (tests/test_gpu_craft.py runs both forms).
+template <int S, bool FSAL, bool NYS = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_craft_queue(const CraftArgs a) {
+    const long long n = a.n_craft;
+    long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // queue position = the craft's column in the knot slabs
+    const bool first_in_range = col < n;
+    long long i = first_in_range && a.perm ? a.perm[col] : col;       // the craft at it
+    const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+
+    // the craft this lane is integrating (registers); `have` = it still has work in this call
+    int status = EPH_OK;
+    double time = 0.0, y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, next_h = 0.0, last_knot = 0.0, bound = 0.0;
+    unsigned n_att = 0, rk_i = 0, steps = 0, taken = 0;
+    int cur = 0, nk = 0;
+    const SegmentDev *segs = a.segs;
+    SegmentDev sg{};
+    double k[S][6];
+    double prev_t = 0.0, prev_y[6], prev_klast[6];
+    unsigned prev_i = 0;
+    bool in_step = false;                               // between a step's prologue and its acceptance
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { prev_y[d] = 0.0; prev_klast[d] = 0.0; }
+
+    auto load = [&]() -> bool {                         // craft i -> registers; false: nothing to do for it
+        status = a.status[i];
+        if (status != EPH_OK && status != EPH_KNOTS_FULL) return false;    // a failed craft stays failed
+        status = EPH_OK;
+        time = a.time[i];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) y[d] = a.y[d * n + i];
+        next_h = a.next_h[i];
+        n_att = a.n_attempts[i]; rk_i = a.rk_i[i]; steps = a.steps[i];
+        cur = a.cur_seg[i]; nk = a.nknots[i];
+        last_knot = a.last_knot_t[i];
+        segs = a.segs + a.seg_off[i];
+        sg = segs[cur];
+        bound = sg.end;
+        if (FSAL) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) k[S - 1][d] = a.klast[d * n + i];
+        }
+        taken = 0;
+        in_step = false;
+        return true;
+    };
+    auto store = [&]() {
+        a.time[i] = time;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.y[d * n + i] = y[d];
+        a.next_h[i] = next_h;
+        a.n_attempts[i] = n_att;
+        a.rk_i[i] = rk_i;
+        a.steps[i] = steps;
+        a.cur_seg[i] = cur;
+        a.nknots[i] = nk;
+        a.last_knot_t[i] = last_knot;
+        a.status[i] = status;
+        if (FSAL) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+        }
+    };
+
+    bool have = first_in_range && load();
+    bool drained = !first_in_range;                     // this lane will get no more craft
+    for (;;) {
+        // ---- lanes without work take the next craft from the queue
+        while (!have && !drained) {
+            col = (long long)atomicAdd(a.queue, 1ull);
+            if (col >= n) { drained = true; break; }
+            i = a.perm ? a.perm[col] : col;
+            have = load();
+        }
+        if (__builtin_amdgcn_ballot_w64(have) == 0) break;          // every lane of the wave is out of work
+        if (have) {
+            // ---- between steps: is this craft done?  (has_reached: solution.end() >= time; the step budget; the slab)
+            if (!in_step) {
+                bool done = last_knot >= a.t_end || (a.step_limit && taken >= a.step_limit);
+                if (!done && nk >= a.max_knots) { status = EPH_KNOTS_FULL; done = true; }
+                if (done) { store(); have = false; continue; }
+                // SpacecraftPropagator::step: advance_timeline + reset_integrator  spacecraft.rs:606-609
+                if (time >= sg.end) {
+                    cur += 1;
+                    sg = segs[cur];
+                    bound = sg.end;
+                    next_h = a.h_init;
+                    n_att = 0;
+                    rk_i = 0;
+                }
+                // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439: PreviousStep
+                prev_t = time;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? k[S - 1][d] : 0.0; }
+                prev_i = rk_i;
+                in_step = true;
+            }
+            // ---- one attempt. The method table through a pointer the optimiser cannot see through: hoisted out of the
+            // persistent loop, the kernel-argument copy (a.rk) pins ~130 coefficients in SGPRs and spills 268 of them to
+            // VGPR lanes; re-read per attempt they are scalar-cache hits
+            const ErkCoeffs *rkp = a.rkd;
+            asm volatile("" : "+s"(rkp));
+#define EPH_RK (*rkp)
+            bool failed = false;
+            if (n_att > a.n_max) { status = EPH_MAX_ITERATIONS_REACHED; failed = true; }
+            if (!failed && time + next_h > bound) next_h = bound - time;
+            const double h = next_h;
+            if (!failed && time >= bound) { status = EPH_BOUND_REACHED; failed = true; }
+            if (!failed && time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; }
+            if (!failed) {
+#define EPH_ATTEMPT_PART 1
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+                if (!ok) { status = EPH_EVAL_FAILED; failed = true; }
+            }
+            if (failed) { store(); have = false; continue; }   // a StepError ends the craft (state as the reference leaves it)
+#define EPH_ATTEMPT_PART 2
+#include "craft_attempt.inc"
+#undef EPH_ATTEMPT_PART
+#undef EPH_RK
+            time = time + h;
+            rk_i += 1;
+            n_att += 1;
+            // AbsTol::err_over_tol
+            const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
+            const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
+            const double err = fmax(pm, vm);
+            // IController::step  mod.rs:225-243
+            const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
+            const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
+            const double nh = next_h * c;
+            next_h = nh > a.h_max ? a.h_max : nh;
+            if (err <= 1.0) {
+                // accepted. CubicHermiteSplineSolout::solout: push (t, r, v)
+                steps += 1;
+                taken += 1;
+                a.knot_t[(long long)nk * n + col] = time;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + col] = y[d];
+                nk += 1;
+                last_knot = time;
+                in_step = false;
+            } else {
+                time = prev_t;                            // PreviousStep::restore
+#pragma unroll
+                for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+                rk_i = prev_i;
+                if (FSAL) {
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) k[S - 1][d] = prev_klast[d];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_craft_wave: ONE WAVE per spacecraft -- the form for few spacecraft (the app's handful of ships), where the
+// thread form leaves the chip empty and needs ~0.27 ms per step of a craft (13 stages x 32 body terms in sequence).
+// Every lane carries the same craft state; in the right-hand side lane b evaluates body b and lanes 0..2 add the
+// terms in body order (craft_rhs<true>). The stage derivatives live in LDS (uniform, read back as broadcasts), so
+// the stage loop is a run-time loop around one copy of the right-hand side: the code fits the instruction cache
+// (with stages unrolled a single wave spends its time fetching ~100 KB of instructions per attempt: measured
+// 50 us per step) and one kernel serves every method. Same operations in the same order as k_craft_propagate.
+// ------------------------------------------------------------------------------------------------------
+template <bool NYS>
+__global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
+    __shared__ __attribute__((aligned(16))) double K[16 * 6];          // k[s][d] (ERK) / dk[s][0..2] (ERKNG)
+    __shared__ __attribute__((aligned(16))) double red[3 * kRedRow];
+    const long long i = blockIdx.x, n = a.n_craft;
+    const int lane = threadIdx.x;
+    int status = a.status[i];
+    if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
+    status = EPH_OK;
+    const auto *rc = (const __attribute__((address_space(4))) ErkCoeffs *)(unsigned long long)a.rkd;
+    const int S = a.rk.stages;
+    const bool FSAL = a.rk.fsal != 0;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto put_k = [&](int s, const double (&v)[6]) {                // lane 0 writes row s
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) K[s * 6 + d] = v[d];
+        }
+        wave_sync();
+    };
+
+    double time = a.time[i], y[6];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) y[d] = a.y[d * n + i];
+    double next_h = a.next_h[i];
+    unsigned n_att = a.n_attempts[i], rk_i = a.rk_i[i], steps = a.steps[i];
+    int cur = a.cur_seg[i], nk = a.nknots[i];
+    double last_knot = a.last_knot_t[i];
+    const SegmentDev *segs = a.segs + a.seg_off[i];
+    SegmentDev sg = segs[cur];
+    double bound = sg.end;
+    if (FSAL) {
+        double kl[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) kl[d] = a.klast[d * n + i];
+        put_k(S - 1, kl);
+    }
+    const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
+    LaneBody lb;
+    lb.be = a.bodies[lane < a.n_bodies ? lane : 0];
+    lb.r = rcp_refined(lb.be.interval);
+    lb.b_ok = in_range_div(lb.be.interval);
+    lb.idx = -1;
+#pragma unroll
+    for (int q = 0; q < kDiv * 3; ++q) lb.c[q] = 0.0;
+
+    unsigned taken = 0;
+    while (!(last_knot >= a.t_end) && !(a.step_limit && taken >= a.step_limit)) {   // has_reached: solution.end() >= time
+        if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
+        if (time >= sg.end) {                         // advance_timeline + reset_integrator  spacecraft.rs:606-609
+            cur += 1;
+            sg = segs[cur];
+            bound = sg.end;
+            next_h = a.h_init;
+            n_att = 0;
+            rk_i = 0;
+        }
+        // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439
+        const double prev_t = time;
+        double prev_y[6], prev_klast[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? K[(S - 1) * 6 + d] : 0.0; }
+        const unsigned prev_i = rk_i;
+        bool failed = false;
+        for (;;) {
+            if (n_att > a.n_max) { status = EPH_MAX_ITERATIONS_REACHED; failed = true; break; }
+            if (time + next_h > bound) next_h = bound - time;
+            const double h = next_h;
+            if (time >= bound) { status = EPH_BOUND_REACHED; failed = true; break; }
+            if (time + h == time) { status = EPH_STEP_SIZE_UNDERFLOW; failed = true; break; }
+            bool ok = true;
+            for (int sv = 0; sv < S; ++sv) {          // ERK::advance explicit.rs:72-106 / ERKNG::advance :97-143
+                const int s = __builtin_amdgcn_readfirstlane(sv);
+                if (FSAL && s == 0 && rk_i > 0) {     // self.k.swap(0, STAGES - 1); continue
+                    double k0[6], kl[6];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) { k0[d] = K[d]; kl[d] = K[(S - 1) * 6 + d]; }
+                    wave_sync();
+                    put_k(0, kl);
+                    put_k(S - 1, k0);
+                    continue;
+                }
+                if (!ok) continue;
+                const double ti = time + h * rc->C[s];
+                double yi[6], out[6];
+                if (NYS) {
+                    const double hc = h * rc->C[s];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { yi[d] = y[d] + y[3 + d] * hc; yi[3 + d] = y[3 + d]; }
+                    for (int jv = 0; jv < s; ++jv) {
+                        const int j = __builtin_amdgcn_readfirstlane(jv);
+                        const double hhap = h * h * rc->A[s][j], hav = h * rc->A2[s & 7][j & 7];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const double kj = K[j * 6 + d];
+                            yi[d] = yi[d] + kj * hhap;
+                            yi[3 + d] = yi[3 + d] + kj * hav;
+                        }
+                    }
+                    ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
+                    const double dk[6] = {out[3], out[4], out[5], 0.0, 0.0, 0.0};
+                    put_k(s, dk);
+                    continue;
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) yi[d] = y[d];
+                for (int jv = 0; jv < s; ++jv) {
+                    const int j = __builtin_amdgcn_readfirstlane(jv);
+                    const double ha = h * rc->A[s][j];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) yi[d] = yi[d] + K[j * 6 + d] * ha;
+                }
+                ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
+                put_k(s, out);
+            }
+            if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
+            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (NYS) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) y[d] = y[d] + y[3 + d] * h;
+                for (int sv = 0; sv < S; ++sv) {
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double hhbp = h * h * rc->B[s], hbv = h * rc->B2[s & 7];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const double ks = K[s * 6 + d];
+                        y[d] = y[d] + ks * hhbp;
+                        y[3 + d] = y[3 + d] + ks * hbv;
+                    }
+                }
+                for (int sv = 0; sv < S; ++sv) {
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double hhep = h * h * rc->E[s], hev = h * rc->E2[s & 7];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const double ks = K[s * 6 + d];
+                        e[d] = e[d] + ks * hhep;
+                        e[3 + d] = e[3 + d] + ks * hev;
+                    }
+                }
+            } else {
+                for (int sv = 0; sv < S; ++sv) {
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double hb = h * rc->B[s];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) y[d] = y[d] + K[s * 6 + d] * hb;
+                }
+                for (int sv = 0; sv < S; ++sv) {      // RKEmbedded::error
+                    const int s = __builtin_amdgcn_readfirstlane(sv);
+                    const double he = h * rc->E[s];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) e[d] = e[d] + K[s * 6 + d] * he;
+                }
+            }
+            time = time + h;
+            rk_i += 1;
+            n_att += 1;
+            // AbsTol::err_over_tol
+            const double pm = fmax(fabs(e[0] / a.tol_pos), fmax(fabs(e[1] / a.tol_pos), fabs(e[2] / a.tol_pos)));
+            const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
+            const double err = fmax(pm, vm);
+            // IController::step  mod.rs:225-243
+            const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
+            const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
+            const double nh = next_h * c;
+            next_h = nh > a.h_max ? a.h_max : nh;
+            if (err <= 1.0) break;
+            time = prev_t;                            // PreviousStep::restore
+#pragma unroll
+            for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+            rk_i = prev_i;
+            if (FSAL) {
+                wave_sync();
+                put_k(S - 1, prev_klast);
+            }
+        }
+        if (failed) break;
+        steps += 1;
+        taken += 1;
+        if (lane == 0) {                              // CubicHermiteSplineSolout::solout: push (t, r, v)
+            a.knot_t[(long long)nk * n + i] = time;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) a.knot_y[((long long)nk * 6 + d) * n + i] = y[d];
+        }
+        nk += 1;
+        last_knot = time;
+    }
+
+    if (lane == 0) {
+        a.time[i] = time;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) a.y[d * n + i] = y[d];
+        a.next_h[i] = next_h;
+        a.n_attempts[i] = n_att;
+        a.rk_i[i] = rk_i;
+        a.steps[i] = steps;
+        a.cur_seg[i] = cur;
+        a.nknots[i] = nk;
+        a.last_knot_t[i] = last_knot;
+        a.status[i] = status;
+        if (FSAL) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) a.klast[d * n + i] = K[(S - 1) * 6 + d];
+        }
+    }
+}
+
+
+// ---- launch: the form (wave per craft | thread per craft, static or work queue, one or two waves per SIMD) is the host's
+// choice (craft.hip craft_launch_plan); this picks the instantiation for the method's stage count
+int craft_launch(hipStream_t s, const CraftArgs &a, const CraftLaunch &how) {
+    if (how.wave_form) {
+        const dim3 grid((unsigned)a.n_craft), block(64);
+        if (a.rk.nystrom) hipLaunchKernelGGL(k_craft_wave<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(k_craft_wave<false>, grid, block, 0, s, a);
+        return launched("k_craft_wave");
+    }
+    const long long waves = (a.n_craft + 63) / 64;
+    const int S = a.rk.stages;
+    const bool F = a.rk.fsal != 0;
+    if (how.queue) {
+        const dim3 grid((unsigned)how.resident_waves), block(64);
+        if (a.rk.nystrom) {
+            if (S == 7 && F) hipLaunchKernelGGL((k_craft_queue<7, true, true>), grid, block, 0, s, a);
+            else return EPH_ERR_UNSUPPORTED;
+        } else if (S == 6 && !F) hipLaunchKernelGGL((k_craft_queue<6, false>), grid, block, 0, s, a);
+        else if (S == 7 && F) hipLaunchKernelGGL((k_craft_queue<7, true>), grid, block, 0, s, a);
+        else if (S == 7 && !F) hipLaunchKernelGGL((k_craft_queue<7, false>), grid, block, 0, s, a);
+        else if (S == 9 && !F) hipLaunchKernelGGL((k_craft_queue<9, false>), grid, block, 0, s, a);
+        else if (S == 13 && !F) hipLaunchKernelGGL((k_craft_queue<13, false>), grid, block, 0, s, a);
+        else if (S == 16 && !F) hipLaunchKernelGGL((k_craft_queue<16, false>), grid, block, 0, s, a);
+        else return EPH_ERR_UNSUPPORTED;
+        return launched("k_craft_queue");
+    }
+    const dim3 grid((unsigned)waves), block(64);
+    const bool occ2 = how.occ2;
+#define EPH_CRAFT_CASE(S_, F_)                                                                     \
+    do {                                                                                           \
+        if (occ2) hipLaunchKernelGGL((k_craft_propagate<S_, F_, false, 2>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((k_craft_propagate<S_, F_, false, 1>), grid, block, 0, s, a);      \
+    } while (0)
+    if (a.rk.nystrom) {
+        if (S == 7 && F) hipLaunchKernelGGL((k_craft_propagate<7, true, true, 2>), grid, block, 0, s, a);
+        else return EPH_ERR_UNSUPPORTED;
+    } else if (S == 6 && !F) EPH_CRAFT_CASE(6, false);
+    else if (S == 7 && F) EPH_CRAFT_CASE(7, true);
+    else if (S == 7 && !F) EPH_CRAFT_CASE(7, false);
+    else if (S == 9 && !F) EPH_CRAFT_CASE(9, false);
+    else if (S == 13 && !F) EPH_CRAFT_CASE(13, false);
+    else if (S == 16 && !F) EPH_CRAFT_CASE(16, false);
+    else return EPH_ERR_UNSUPPORTED;
+#undef EPH_CRAFT_CASE
+    return launched("k_craft_propagate");
+}
+
+}  // namespace EPH_PV_NS
+}  // namespace eph

@@ -17,11 +17,6 @@
 
 #include "../../include/ephemeris_amd.h"
 
-// evaluation order of the point-mass term (device_math.h); a build flag, see eph_pair_variant()
-#ifndef EPH_PAIR_VARIANT
-#define EPH_PAIR_VARIANT 0
-#endif
-
 namespace eph {
 
 constexpr int kMaxOrder = 16;   // ELM2 orders: 12 (QT12), 13 (Stormer13)
@@ -90,37 +85,65 @@ struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm
     SampleArgs samp;
 };
 
-// ---- launchers (kernels.hip) --------------------------------------------------------------------
+// ---- launchers -------------------------------------------------------------------------------------------------------------------
+// The kernels that contain the point-mass term exist once per evaluation order of that term (pair_term.h, pair_ns.h): `pv` (0..6)
+// says whose. A handle fixes it at creation (eph_set_pair_variant / EPH_PAIR_VARIANT); dispatch.cpp chooses the kernel form
+// (wave / workgroup / single workgroup, bodies per wave or workgroup) and routes to that order's table.
+constexpr int kPairVariants = 7;
+int default_pair_variant();                 // what new handles take: eph_set_pair_variant, else EPH_PAIR_VARIANT, else 0
+int set_default_pair_variant(int pv);       // EPH_ERR_BAD_ARGUMENT outside 0..6
 // a[b] = acc_init[b] (or 0) + sum over the other bodies in the reference order; SoA [3][npad] output
-// kind: 0 = auto by n, 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
+// kind: 0 = auto by the number of targets, 1 = one wave per block (wave_force), 2 = workgroup-specialised (wg_force)
 // lo, hi: target bodies [lo, hi) (hi < 0: n); lo must be a multiple of 16
 // kd (optional): the SRKN stage update fused behind the evaluation, per (body, component) of the launch's targets:
 //   v += a * hb ; y += v * ha ; pos_out = y      (symplectic.rs:90-97) -- one launch per stage instead of two
 struct KickDrift { double *v, *y; double hb, ha; Body4 *pos_out; };
-int launch_accel(hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out,
+int launch_accel(int pv, hipStream_t s, int n, int npad, const Body4 *pos, const double *acc_init, double *acc_out,
                  int kind = 0, int lo = 0, int hi = -1, const KickDrift *kd = nullptr);
+int launch_lm_step(int pv, hipStream_t s, const LmArgs &a);                 // one fused step, all CUs
+int launch_lm_persistent(int pv, hipStream_t s, const LmArgs &a, int64_t nsteps);
+// `count` single-workgroup systems (n <= kGangMaxN each, same L), one workgroup each, argv in device memory
+constexpr int kGangMaxN = 32;
+int launch_lm_small_many(int pv, hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);
+// opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
+int fast_slices(int npad);                                          // S
+int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr);   // posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body
+// the massless sweep (craft_sweep.hip); CraftArgs: craft_device.h
+struct CraftArgs;
+struct CraftLaunch { bool wave_form, queue, occ2; long long resident_waves; };
+int launch_craft(int pv, hipStream_t s, const CraftArgs &a, const CraftLaunch &how);
+// test hooks: 1/(x*sqrt(x)) and a/(x*sqrt(x)) through the in-range sequences and through the compiler's IEEE expansions
+int launch_debug_inv_r3(int pv, hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee);
+int launch_debug_inv_r3_sweep(int pv, hipStream_t s, uint64_t seed, int64_t n, unsigned long long *out2);   // rounds n up to 2^20
+int launch_debug_quot(int pv, hipStream_t s, int64_t n, const double *x, const double *a, double *fast, double *ieee);
+int debug_wg_cycles(int pv, long long *out);   // tuning builds (-DEPH_EXPERIMENTS): cycle accounting of the workgroup / small kernels
+struct PairKernels {                        // one evaluation order's launchers (pair_launchers.h), filled in step_wave.hip
+    int (*accel_wave)(hipStream_t, int, int, int, const Body4 *, const double *, double *, int, int, const KickDrift &);
+    int (*accel_wg)(hipStream_t, int, int, int, const Body4 *, const double *, double *, int, int, const KickDrift &);
+    int (*lm_step_wave)(hipStream_t, int, const LmArgs &);
+    int (*lm_step_wg)(hipStream_t, int, const LmArgs &);
+    int (*lm_persistent)(hipStream_t, const LmArgs &, int64_t);
+    int (*lm_small)(hipStream_t, const LmArgs &, int64_t);
+    int (*lm_small_many)(hipStream_t, const LmArgs *, int, int, int64_t);
+    int (*lm_step_fast)(hipStream_t, const LmArgs &, double *, int, int, bool, float *);
+    int (*craft_launch)(hipStream_t, const CraftArgs &, const CraftLaunch &);
+    int (*debug_inv_r3)(hipStream_t, int64_t, const double *, double *, double *);
+    int (*debug_inv_r3_sweep)(hipStream_t, uint64_t, int64_t, unsigned long long *);
+    int (*debug_quot)(hipStream_t, int64_t, const double *, const double *, double *, double *);
+    int (*debug_wg_cycles)(long long *);
+    int variant;
+};
+// ---- launchers of the kernels without a point-mass term (solout.hip) --------------------------------------------------------------
 int launch_pack(hipStream_t s, int n, int npad, const double *Yslot, const double *mu, Body4 *pos);
 int launch_copy3(hipStream_t s, int n, int npad, const double *src, double *dst);
 // SRKN stage update: v += a*hb ; y += v*ha ; also publishes packed positions   (symplectic.rs:90-97)
 int launch_kick_drift(hipStream_t s, int n, int npad, const double *a, double *v, double *y, double hb, double ha,
                       const double *mu, Body4 *pos_out);
 int launch_lm_predict(hipStream_t s, const LmArgs &a);              // y_{m+1} from the ring (no force)
-int launch_lm_step(hipStream_t s, const LmArgs &a);                 // one fused step, all CUs
-int launch_lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps);
-// `count` single-workgroup systems (n <= kGangMaxN each, same L), one workgroup each, argv in device memory
-constexpr int kGangMaxN = 32;
-int launch_lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);
-// opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
-int fast_slices(int npad);                                          // S
-int launch_lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr);   // posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body
 int lm_bodies_per_wave(int n);
 int launch_sample(hipStream_t s, int n, int npad, const double *Yslot, const SampleArgs &sa, uint32_t step);
 // carry: samples [src[b], src[b]+cnt[b]) of body b's region move to its front (src[b] == 0: nothing to do)
 int launch_carry(hipStream_t s, int n, const uint64_t *region, const uint32_t *src, const uint32_t *cnt, double *log);
-// test hook: 1/(x*sqrt(x)) through the in-range fast sequences and through the compiler's IEEE expansions
-int launch_debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee);
-int launch_debug_inv_r3_sweep(hipStream_t s, uint64_t seed, int64_t n, unsigned long long *out2);   // rounds n up to 2^20
-int debug_wg_cycles(long long *out);   // EPH_DEBUG_WG=3 cycle accounting of the workgroup force kernel
 // AoS <-> SoA staging
 int launch_aos_to_soa(hipStream_t s, int n, int npad, const double *aos, double *soa);
 int launch_soa_to_aos(hipStream_t s, int n, int npad, const double *soa, double *aos);

@@ -157,6 +157,7 @@ public:
     uint64_t evals() const { return evals_; }
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
+    int pair_variant() const { return pv_; }
     void set_path(int p) { path_ = p; }
     int path() const { return path_; }
     // path 1 -> per-step launches with the one-wave-per-block force, 3 -> with the workgroup-specialised force
@@ -234,6 +235,7 @@ private:
     hipEvent_t gang_ev_ = nullptr, gang_copy_ev_ = nullptr;
     LmArgs *gang_host_ = nullptr;             // pinned source of the gang's argument copy (so advance_many need not wait for it)
     size_t gang_host_count_ = 0;
+    int pv_ = 0;                              // evaluation order of the point-mass term, fixed at creation (dispatch.cpp)
     int failed_ = EPH_OK;                     // sticky: a gang launch failed with this handle's bookkeeping already advanced
 };
 

@@ -75,6 +75,7 @@ int NBodyIntegration::create(int n, const double *pos, const double *vel, const 
     o->h_ = h;
     o->time_ = t0;
     o->bound_ = INFINITY;   // nbody.rs:111
+    o->pv_ = default_pair_variant();
     EPH_HIP(hipGetDevice(&o->device_));
     EPH_HIP(hipStreamCreateWithFlags(&o->stream_, hipStreamNonBlocking));
     EPH_HIP(hipEventCreate(&o->ev0_));
@@ -105,7 +106,7 @@ int NBodyIntegration::clone(std::unique_ptr<NBodyIntegration> *out) {
     o->device_ = device_;
     o->n_ = n_; o->L_ = L_;
     o->is_multistep_ = is_multistep_; o->lm_ = lm_; o->rk_ = rk_; o->substeps_ = substeps_;
-    o->h_ = h_; o->h_sub_ = h_sub_; o->time_ = time_; o->bound_ = bound_;
+    o->h_ = h_; o->h_sub_ = h_sub_; o->time_ = time_; o->bound_ = bound_; o->pv_ = pv_;
     o->starter_i_ = starter_i_; o->lm_i_ = lm_i_; o->evals_ = evals_;
     o->cur_ = cur_; o->pp_ = pp_; o->path_ = path_;
     o->lo_ = lo_; o->hi_ = hi_; o->slice_ = slice_; o->xch_ = xch_;   // a clone of a sharded handle shares the ranks
@@ -167,7 +168,7 @@ int NBodyIntegration::srkn_step(double h, double *y_slot) {
         const KickDrift kd{V_.p, y_slot, h * rk_.B[s], h * rk_.A[s], P_[pp_ ^ 1].p};
         if (!rk_.fsal || s > 0 || starter_i_ == 0) {
             // problem.ode.eval(t_stage, &problem.state.y, self.ddy.zero()) and the stage update behind it, one launch
-            if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind(), lo_, hi_, &kd))) return st;
+            if ((st = launch_accel(pv_, stream_, n_, npad_, P_[pp_].p, nullptr, ASR_.p, force_kind(), lo_, hi_, &kd))) return st;
             evals_++;
         } else if ((st = launch_kick_drift(stream_, n_, npad_, ASR_.p, V_.p, y_slot, kd.hb, kd.ha, mu_.p, P_[pp_ ^ 1].p))) {
             return st;                                 // FSAL first stage: the acceleration is the previous step's last
@@ -191,7 +192,7 @@ int NBodyIntegration::startup_macro_step() {
     if (time_ + h_ == time_) return EPH_STEP_SIZE_UNDERFLOW;
     int st;
     if (starter_i_ / (uint32_t)substeps_ == 0) {
-        if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_), force_kind(), lo_, hi_))) return st;
+        if ((st = launch_accel(pv_, stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(cur_), force_kind(), lo_, hi_))) return st;
         evals_++;
     }
     const int nslot = (cur_ + L_ - 1) % L_;
@@ -199,7 +200,7 @@ int NBodyIntegration::startup_macro_step() {
     cur_ = nslot;   // from here on the working state is the new front, as in the reference after the clone_from
     for (int s = 0; s < substeps_; ++s)
         if ((st = srkn_step(h_sub_, Yslot(nslot)))) return st;
-    if ((st = launch_accel(stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot), force_kind(), lo_, hi_))) return st;
+    if ((st = launch_accel(pv_, stream_, n_, npad_, P_[pp_].p, nullptr, Aslot(nslot), force_kind(), lo_, hi_))) return st;
     evals_++;
     return EPH_OK;
 }
@@ -260,7 +261,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
         a.pos_cur = P_[pp_].p;
         a.pos_next = P_[pp_ ^ 1].p;
         if (collect_) collect_->push_back(a);                           // launched by advance_many with the gang's others
-        else if ((st = launch_lm_persistent(stream_, a, k))) return st;
+        else if ((st = launch_lm_persistent(pv_, stream_, a, k))) return st;
         cur_ = (int)(((int64_t)cur_ - k % L_ + L_) % L_);
         if (timing_) kernel_launches_ += 1;
     } else {
@@ -277,9 +278,9 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.pos_next = P_[pp_ ^ 1].p;
             a.do_predict = s < k;
             a.step = (uint32_t)s;
-            if ((st = fast ? launch_lm_step_fast(stream_, a, fast_partial_.p, path_ == EPH_PATH_FAST_RSQ,
+            if ((st = fast ? launch_lm_step_fast(pv_, stream_, a, fast_partial_.p, path_ == EPH_PATH_FAST_RSQ,
                                                  path_ == EPH_PATH_F32_PAIRS ? posf_.p : nullptr)
-                           : launch_lm_step(stream_, a)))
+                           : launch_lm_step(pv_, stream_, a)))
                 return st;
             if (a.do_predict && (st = gather_packed(a.pos_next))) return st;
         }
@@ -361,7 +362,8 @@ int NBodyIntegration::advance_many(NBodyIntegration *const *igs, int count, int6
     if (count == 0 || k == 0) return EPH_OK;
     bool gang = count > 1;
     for (int i = 0; i < count && gang; ++i)
-        gang = igs[i] && igs[i]->gang_ready(k) && igs[i]->device_ == igs[0]->device_ && igs[i]->L_ == igs[0]->L_;
+        gang = igs[i] && igs[i]->gang_ready(k) && igs[i]->device_ == igs[0]->device_ && igs[i]->L_ == igs[0]->L_ &&
+               igs[i]->pv_ == igs[0]->pv_;
     for (int i = 0; i < count; ++i) {
         if (!igs[i]) return EPH_ERR_BAD_ARGUMENT;
         for (int j = 0; j < i; ++j)
@@ -425,7 +427,7 @@ int NBodyIntegration::advance_many(NBodyIntegration *const *igs, int count, int6
     EPH_GANG_HIP(hipMemcpyAsync(lead.gang_args_.p, lead.gang_host_, sizeof(LmArgs) * (size_t)count, hipMemcpyHostToDevice, lead.stream_));
     EPH_GANG_HIP(hipEventRecord(lead.gang_copy_ev_, lead.stream_));
     if (lead.timing_) EPH_GANG_HIP(hipEventRecord(lead.ev0_, lead.stream_));
-    st = launch_lm_small_many(lead.stream_, lead.gang_args_.p, count, lead.L_, k);
+    st = launch_lm_small_many(lead.pv_, lead.stream_, lead.gang_args_.p, count, lead.L_, k);
     if (st) return fail(st);
     for (int i = 0; i < count; ++i) igs[i]->replay_deferred_time();     // host bookkeeping under the kernel
     if (lead.timing_) {
@@ -494,7 +496,7 @@ int accel_eval_device(int n, const double *pos, const double *mu, double *acc) {
     if ((st = launch_pack(s, n, npad, soa.p, dmu.p, P.p))) return st;
     EPH_HIP(hipMemcpyAsync(aos.p, acc, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
     if ((st = launch_aos_to_soa(s, n, npad, aos.p, init.p))) return st;
-    if ((st = launch_accel(s, n, npad, P.p, init.p, out.p))) return st;
+    if ((st = launch_accel(default_pair_variant(), s, n, npad, P.p, init.p, out.p))) return st;
     if ((st = launch_soa_to_aos(s, n, npad, out.p, aos.p))) return st;
     EPH_HIP(hipMemcpyAsync(acc, aos.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
     EPH_HIP(hipStreamSynchronize(s));

@@ -50,12 +50,17 @@ typedef enum eph_status {
 #define EPH_BACKWARD (-1)
 
 int32_t eph_abi_version(void);
-/* Which evaluation order of the point-mass term 1/r^3 this library was built with (-DEPH_PAIR_VARIANT=k, 0..3;
- * csrc/device_math.h). Stands in for `particular::gravity::newtonian::AccelerationPaired::acceleration_paired`
+/* The evaluation order of the point-mass term -- `particular::gravity::newtonian` acceleration_paired / acceleration_at::<false>
  * (crate `particular` 0.8.0-dev @ d490707a, Cargo.lock:4277-4285; call sites ephemeris/src/propagators/nbody.rs:29,
- * ephemeris_explorer/src/dynamics/spacecraft.rs:73), whose source is not in the reference tree: 0 = the published
- * crate's form 1/(n2*sqrt(n2)), the default build. */
+ * ephemeris_explorer/src/dynamics/spacecraft.rs:73), whose source is not in the reference tree. The library carries seven orders
+ * (csrc/pair_term.h: 0 = `d * (mu * (1 / (n2 * sqrt n2)))`, the published crate's form and the default; 1-3 other one-reciprocal
+ * orders; 4 = `(d * mu) / p`, 5 = `d * (mu / p)`, 6 = `(d / p) * mu` with p = n2 * sqrt n2 and three true divisions), each
+ * bit-identical to the CPU restatement in the same order. eph_set_pair_variant(k) chooses the order for every handle CREATED
+ * afterwards (eph_nbody_create, eph_prop_create, eph_craft_batch_create; clones inherit; eph_accel_eval uses the current value);
+ * the initial value is the environment's EPH_PAIR_VARIANT, else 0. tools/identify_pair_variant.py names the right k from a
+ * print-out of the real crate (tools/particular_probe.rs, tests/golden/pair_probe.json). */
 int32_t eph_pair_variant(void);
+int32_t eph_set_pair_variant(int32_t k);   /* EPH_ERR_BAD_ARGUMENT outside 0..6 */
 const char *eph_status_string(int32_t status);
 /* text of the last HIP error seen by the calling thread ("" if none) */
 const char *eph_last_error(void);
@@ -445,6 +450,8 @@ int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast,
 /* Test hook: 1/(x*sqrt(x)) for n inputs computed by the kernel's in-range fast sequences (NaN where the range
  * guard would send the tile to the IEEE form) and by the compiler's IEEE sqrt/divide expansions. */
 int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee);
+/* a / (x * sqrt(x)): the division forms' shared-reciprocal quotient (csrc/pair_term.h) beside the compiler's IEEE division */
+int32_t eph_debug_quot(int64_t n, const double *x, const double *a, double *fast, double *ieee);
 /* Test hook: the same comparison over n operands generated on the device (splitmix64(seed + index): random mantissa,
  * exponent uniform over the guarded range; n is rounded up to a multiple of 2^20). *mismatches = operands whose two
  * results differ in any bit; *example_bits = the IEEE bits of one of them (0 when none). */

@@ -1,11 +1,12 @@
-"""-m gpu: the point-mass evaluation order as a build flag (csrc/device_math.h, -DEPH_PAIR_VARIANT=k).
+"""-m gpu: the point-mass evaluation order as a RUN-TIME choice (csrc/pair_term.h, eph_set_pair_variant / EPH_PAIR_VARIANT).
 
 The reference takes 1/r^3 from the crate `particular` (0.8.0-dev @ d490707a), whose source is not in its tree; the
-product's default build restates the published crate's form (variant 0). Should the pinned revision evaluate it in
-another order, the fix is a rebuild with a flag, and this test shows each alternative build is bit-identical to the
-CPU restatement switched to the same order (orc.set_pair_variant) on every kernel family that evaluates the term:
-k_accel (wave and workgroup forms), the fused multistep kernels, the single-workgroup kernel and the spacecraft sweep.
-Each variant runs in its own process: the library is chosen at import (EPH_AMD_PAIR_VARIANT)."""
+library's default restates the published crate's form (order 0). Should the pinned revision evaluate it in another order,
+the fix is one call (tools/identify_pair_variant.py says which), and this file shows every order bit-identical to the CPU
+restatement switched to the same order (orc.set_pair_variant) on every kernel family that evaluates the term: k_accel (wave
+and workgroup forms), the fused multistep kernels, the single-workgroup kernel and the spacecraft sweeps; on the committed
+probe operands of the identification kit; with handles of different orders alive in one process; and the division forms'
+shared-reciprocal quotient on the numerators closest to a rounding boundary (tests/division_hard_cases.py)."""
 import os
 import subprocess
 import sys
@@ -25,7 +26,9 @@ import ephemeris_explorer_amd as ea
 from ephemeris_explorer_amd.systems import load_system, load_ship
 from ephemeris_explorer_amd.workloads import plummer
 from oracle import orc
-assert ea._lib().eph_pair_variant() == k
+if sys.argv[3] == "call":
+    ea.set_pair_variant(k)
+assert ea.pair_variant() == k                # ("env": EPH_PAIR_VARIANT in the environment)
 orc.set_pair_variant(k)
 orc.set_pair_variant(k, native=True)
 same = lambda a, b: np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
@@ -103,12 +106,13 @@ print("variant", k, "ok")
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
-def test_pair_variant_build_matches_oracle_variant(gpu, variant):
-    from ephemeris_explorer_amd import build as b
-    lib = b.build(pair_variant=variant)
-    assert lib.exists()
-    env = dict(os.environ, EPH_AMD_PAIR_VARIANT=str(variant))
-    r = subprocess.run([sys.executable, "-c", SCRIPT, str(ROOT), str(variant)], env=env, capture_output=True,
+def test_pair_variant_matches_oracle_variant(gpu, variant):
+    how = "env" if variant % 2 else "call"
+    env = dict(os.environ)
+    env.pop("EPH_PAIR_VARIANT", None)
+    if how == "env":
+        env["EPH_PAIR_VARIANT"] = str(variant)
+    r = subprocess.run([sys.executable, "-c", SCRIPT, str(ROOT), str(variant), how], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert f"variant {variant} ok" in r.stdout
@@ -118,5 +122,90 @@ def test_pair_variant_build_matches_oracle_variant(gpu, variant):
         f.write([ln for ln in r.stdout.splitlines() if "us_per_step_4096" in ln][0] + "\n")
 
 
-def test_default_build_is_variant_zero(gpu):
-    assert gpu._lib().eph_pair_variant() == 0
+def test_default_is_order_zero_and_bad_orders_are_refused(gpu):
+    assert gpu.pair_variant() == 0
+    for bad in (-1, 7, 100):
+        with pytest.raises(Exception):
+            gpu.set_pair_variant(bad)
+    assert gpu.pair_variant() == 0
+
+
+def _same(a, b):
+    import numpy as np
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+def test_probe_operands_give_the_committed_bits_in_every_order(gpu):
+    """tests/golden/pair_probe.json through seam 1 (two bodies): what the identification kit promises the maintainer"""
+    import json
+
+    import numpy as np
+    doc = json.loads((ROOT / "tests/golden/pair_probe.json").read_text())
+    f = lambda h: np.array([int(x, 16) for x in h], dtype=np.uint64).view(np.float64)
+    try:
+        for k in range(7):
+            gpu.set_pair_variant(k)
+            for i, p in enumerate(doc["pairs"]):
+                pos = np.array([f(p["pi"]), f(p["pj"])])
+                mu = np.array([f([p["mui"]])[0], f([p["muj"]])[0]])
+                got = gpu.accel_eval(pos, mu).reshape(-1).view(np.uint64)
+                want = np.array([int(x, 16) for x in doc["expected"][str(k)][i]], dtype=np.uint64)
+                want[want == np.uint64(1 << 63)] = 0          # accumulated into +0: a -0 term arrives as +0
+                assert np.array_equal(got, want), (k, i)
+    finally:
+        gpu.set_pair_variant(0)
+
+
+def test_handles_of_different_orders_coexist(gpu):
+    """the order is fixed per handle at creation: a handle made under order 4 keeps it after the default moved on"""
+    import numpy as np
+
+    from ephemeris_explorer_amd.workloads import plummer
+    from oracle import orc
+    pos, vel, mu = plummer(700)
+    try:
+        gpu.set_pair_variant(4)
+        g4 = gpu.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
+        gpu.set_pair_variant(0)
+        g0 = gpu.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
+        c4 = g4.clone()                                   # a clone inherits its parent's order, not the default
+        for g in (g4, g0, c4):
+            g.advance(12 + 6)
+        for k, gs in ((4, (g4, c4)), (0, (g0,))):
+            orc.set_pair_variant(k, native=True)
+            o = orc.NBody(pos, vel, mu, 0.0, 1.0 / 1024.0, native=True)
+            assert o.advance(12 + 6) == 0
+            for g in gs:
+                assert _same(g.state()[0], o.state()[0]) and _same(g.state()[1], o.state()[1]), k
+        assert not _same(g4.acc(), g0.acc())               # (the orders differ in last bits of the accelerations)
+    finally:
+        gpu.set_pair_variant(0)
+        orc.set_pair_variant(0, native=True)
+
+
+def test_seeded_quotient_on_hard_cases(gpu):
+    """a / p, p = x sqrt(x), through r = RN(1/p) and Markstein's step against the device's IEEE division: numerators whose
+    quotient lies k 2^-106 / p' from a rounding boundary (k = 1, 2, 3, 5), and random ones"""
+    import math
+    import random
+
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "tests"))
+    import division_hard_cases as dh
+    rng = random.Random(20260927)
+    xs, as_ = [], []
+    while len(xs) < 400000:
+        x = math.ldexp(1.0 + rng.random(), rng.randrange(-130, 130))
+        p = dh.p_of(x)
+        for a in dh.hard_numerators(p) + [math.ldexp(1.0 + rng.random(), rng.randrange(-190, 190)) for _ in range(2)]:
+            for sgn in (1.0, -1.0):
+                xs.append(x)
+                as_.append(sgn * a)
+    try:
+        gpu.set_pair_variant(4)
+        fast, ieee = gpu.debug_quot(np.array(xs), np.array(as_))
+    finally:
+        gpu.set_pair_variant(0)
+    assert _same(fast, ieee)
+    host = np.array(as_) / np.array([dh.p_of(x) for x in xs])
+    assert _same(ieee, host)
