@@ -262,7 +262,52 @@ def craft_cpu_baseline(s, ship, pos, vel, t_end, craft_days, sample=1000):
             "seconds": dt, "craft": n}
 
 
-def sharded_4096(dist, world, rank, steps, backend_is_nccl):
+def transport_preflight(dist, world, rank, backend_is_nccl, record):
+    """Before any sharded timing: every transport of the exchange step (RCCL when each rank has its own device, direct peer
+    writes, host staging) runs start-up + 5 steps of a 1024-body system partitioned over the job's ranks, and every rank compares
+    the gathered state bit for bit with its own single-device run. `record` (filled in place, so that a watchdog that fires
+    sees what was established so far) gets {"rccl": "ok" | "<what failed, per rank>", "peer": ..., "host": ..., "peer_memory":
+    [form per rank]}. A transport that HANGS on hardware it has never met is the watchdog's business (main())."""
+    import numpy as np
+
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.parallel import host_staged_exchange, peer_transport, shard_nbody
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(1024, seed=20260927)
+    ref = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    ref.advance(12 + 5)
+    rp, rv = ref.state()[:2]
+    del ref
+    host_group = dist.new_group(backend="gloo") if backend_is_nccl else None      # CPU tensors need a gloo group
+    for transport in (["rccl"] if backend_is_nccl else []) + ["peer", "host"]:
+        status, forms = "ok", None
+        try:
+            g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            if transport == "host":
+                g.shard(rank, world, exchange=host_staged_exchange(dist, group=host_group))
+            elif transport == "peer":
+                t = peer_transport(dist, slot_bytes=1 << 20)
+                forms = t.forms
+                g.shard_peer(t)
+            else:
+                shard_nbody(g, dist, transport="rccl", device="cuda")
+            g.advance(12 + 5)
+            p, v = g.state()[:2]
+            if not (np.array_equal(p, rp) and np.array_equal(v, rv)):
+                status = "bits differ from the single-device run"
+            del g
+        except Exception as e:
+            status = f"{type(e).__name__}: {e}"[:200]
+        every = [None] * world
+        dist.all_gather_object(every, status)
+        bad = [f"rank {r}: {st}" for r, st in enumerate(every) if st != "ok"]
+        record[transport] = "ok" if not bad else "; ".join(bad)[:400]
+        if forms is not None:
+            record["peer_memory"] = forms
+    return record
+
+
+def sharded_4096(dist, world, rank, steps, backend_is_nccl, usable=None):
     """"2/4/8-GPU scaling of config 3 is expected to be poor and must be reported as measured". The metric's
     own 4096-body system as ONE system partitioned by target body over the ranks of this job, once per transport that can
     run here (direct peer writes always; RCCL when every rank has its own device), timed like the main line (repeated
@@ -284,6 +329,9 @@ def sharded_4096(dist, world, rank, steps, backend_is_nccl):
     # RCCL first (when every rank has its own device), then the direct-write transport; EPH_BENCH_SHARDED=rccl|peer|0 narrows it
     want = os.environ.get("EPH_BENCH_SHARDED", "rccl,peer").split(",")
     for transport in [t for t in (["rccl", "peer"] if backend_is_nccl else ["peer"]) if t in want]:
+        if usable is not None and usable.get(transport) != "ok":
+            out["transports"][transport] = {"error": "failed the preflight: " + str(usable.get(transport))[:300]}
+            continue
         try:
             g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
             shard_nbody(g, dist, transport=transport, device="cuda" if backend_is_nccl else "cpu")
@@ -314,6 +362,32 @@ def sharded_4096(dist, world, rank, steps, backend_is_nccl):
         best = min(ok, key=lambda k: ok[k]["ms_per_step"])
         out.update(transport=best, ms_per_step=ok[best]["ms_per_step"], gathers=ok[best]["gathers"],
                    bit_identical_to_single_device=all(v.get("bit_identical_to_single_device", True) for v in ok.values()))
+    return out
+
+
+def other_variants(pos, vel, mu, steps=400):
+    """us per step of the same system under the OTHER evaluation orders of the unpinned point-mass term (csrc/pair_term.h): the
+    headline is measured on order `pair_variant` (0 unless EPH_PAIR_VARIANT says otherwise); should the Rust binary follow another
+    order (tools/identify_pair_variant.py), this is what the step costs there. HIP events on each handle's stream."""
+    import ephemeris_explorer_amd as ea
+    out, keep = {}, ea.pair_variant()
+    try:
+        for k in range(7):
+            if k == keep:
+                continue
+            ea.set_pair_variant(k)
+            g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+            g.advance(12 + 50)
+            g.enable_timing(True)
+            g.advance(steps)
+            g.sync()
+            ms, launches = g.kernel_time()
+            out[str(k)] = {"us_per_step": ms / launches * 1e3, "body_steps_per_s": len(mu) / (ms / launches * 1e-3)}
+            del g
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        ea.set_pair_variant(keep)
     return out
 
 
@@ -431,6 +505,9 @@ def main():
                          "transfer / heliocentric in equal numbers (step counts spanning > 10x)")
     ap.add_argument("--population-order", choices=["interleaved", "blocked"], default="interleaved")
     args = ap.parse_args()
+    # `--gpus N` without a launcher environment: this process becomes the launcher (every workload)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args.gpus)
     if args.workload == "craft":
         return craft_main(args)
     sharded = args.workload == "nbody-sharded"
@@ -441,8 +518,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            return self_launch(args.gpus)
         args.gpus = world
 
     import numpy as np
@@ -513,6 +588,17 @@ def main():
     _, t_min = reduce_timing(blocks[0], 0, dist, device="cuda")
     _, t_max = reduce_timing(blocks[-1], 0, dist, device="cuda")
     ms_kernel, launches = g.kernel_time()
+    # The contract's region is ONE K-step block between synchronisations; a 20-step block of this kernel is 0.8 ms, of which the
+    # launch ramp and the synchronisation are about 40 us (6 %). The same K steps ten times per synchronisation, once, beside it:
+    long_reps = 10
+    g.enable_timing(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(long_reps):
+        g.advance(args.steps)
+    g.sync()
+    barrier()
+    _, t_long = reduce_timing(time.perf_counter() - t0, 0, dist, device="cuda")
     want_strong = world > 1 and not sharded and not fast and n == N_BODIES
     out = None
 
@@ -537,6 +623,11 @@ def main():
             "blocks": len(blocks), "ms_per_step_min": t_min / args.steps * 1e3, "ms_per_step_max": t_max / args.steps * 1e3,
             "timing": f"the {args.steps}-step block timed {len(blocks)} times (barrier + device sync around each); "
                       "value and ms_per_step are the median block",
+            "long_region": {"steps": long_reps * args.steps, "ms_per_step": t_long / (long_reps * args.steps) * 1e3,
+                            "value": units / (t_long / long_reps),
+                            "note": f"{long_reps} x the K-step block per synchronisation, one region: the block's ramp and "
+                                    "synchronisation amortised (value / ms_per_step above stay the contract's single block)"},
+            "pair_variant": ea.pair_variant(),
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": ("f32 pair arithmetic, f64 accumulation and integrator (mixed)" if args.path == "f32-pairs" else "f64"),
             "data": "synthetic",
@@ -634,6 +725,10 @@ def main():
         import threading
         limit = float(os.environ.get("EPH_BENCH_SHARDED_TIMEOUT", "240"))
 
+        preflight = {}
+        if rank == 0:
+            out["transports"] = preflight          # (filled in place: what the preflight established, whatever happens next)
+
         def expired():
             if rank == 0:
                 out["sharded_4096"] = {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"}
@@ -644,7 +739,9 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            strong = sharded_4096(dist, world, rank, args.steps, os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl")
+            nccl = os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl"
+            transport_preflight(dist, world, rank, nccl, preflight)
+            strong = sharded_4096(dist, world, rank, args.steps, nccl, usable=preflight)
         except BaseException as e:                       # (a peer gone, a collective torn down: the group is not usable any more)
             if rank == 0:
                 out["sharded_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -654,6 +751,8 @@ def main():
         if rank == 0:
             strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
             out["sharded_4096"] = strong
+    if rank == 0 and world == 1 and n == N_BODIES and not sharded and not fast and not args.no_other_configs:
+        out["other_variants"] = other_variants(pos, vel, mu)
     if (rank == 0 and world == 1 and n == N_BODIES and not sharded and not fast and not args.no_cpu_baseline
             and not args.no_other_configs):
         out["other_configs"] = other_configs()

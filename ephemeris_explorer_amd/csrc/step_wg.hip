@@ -34,9 +34,32 @@
 #undef EPH_WG_SIDE
 #define EPH_WG_SIDE 0
 #endif
+// ablations for the same tuning builds (results meaningless): 1 = pair waves keep their contributions in registers (no ds_write),
+// 2 = no barrier inside the tile loops -- what the floor model of profiles/r04_step_kernel_evidence.md is calibrated with
+#if !EPH_EXPERIMENTS || !defined(EPH_WG_ABLATE)
+#undef EPH_WG_ABLATE
+#define EPH_WG_ABLATE 0
+#endif
+#define WG_LOOP_BARRIER() do { if constexpr (!(EPH_WG_ABLATE & 2)) __syncthreads(); } while (0)
+
+// round 4's structural attempts (profiles/r04_step_kernel_evidence.md), tuning builds only: EPH_WG_X & 1 = the tail wave's stores
+// (ring rows, velocity, next positions) nontemporal; & 2 = a pair wave's first source tiles requested before its own bodies'
+// positions; & 4 = own bodies' positions through scalar loads (SGPR operands of the differences); & 8 = source rows addressed as
+// uniform tile base + loop-invariant lane offset (no address arithmetic in the loop); & 16 = two intervals per trip, the two
+// register sets of prefetched sources trading places instead of being copied
+#if !EPH_EXPERIMENTS || !defined(EPH_WG_X)
+#undef EPH_WG_X
+#define EPH_WG_X 0
+#endif
 
 namespace eph {
 namespace EPH_PV_NS {
+
+template <typename T>
+__device__ __forceinline__ void tail_store(T *p, T v) {
+    if constexpr (EPH_WG_X & 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 constexpr int kWgBodies = 16;
 constexpr int kWgChainWave = 4;                      // the chain wave (wave 4: lands on SIMD 0)
@@ -69,7 +92,10 @@ __device__ __forceinline__ void wg_pair_tile(const double (&xi)[NB], const doubl
         for (int b = 0; b < NB; ++b) pair_finish<false>(pre[b], pj.mu, c[3 * b], c[3 * b + 1], c[3 * b + 2]);
     }
 #pragma unroll
-    for (int q = 0; q < 3 * NB; ++q) tile[(3 * b0 + q) * kRow + lane] = c[q];
+    for (int q = 0; q < 3 * NB; ++q) {
+        if constexpr (EPH_WG_ABLATE & 1) asm volatile("" ::"v"(c[q]));
+        else tile[(3 * b0 + q) * kRow + lane] = c[q];
+    }
 }
 
 // Barrier-per-64-sources schedule (every wave executes tiles + 1 barriers): B_0 after tiles 0 and 1 are in LDS; iteration t:
@@ -146,8 +172,12 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
     }
 #pragma unroll
     for (int q = 0; q < 3 * NB; ++q) {
-        tile_a[(3 * b0 + q) * kRow + lane] = c[q];
-        tile_b[(3 * b0 + q) * kRow + lane] = c[3 * NB + q];
+        if constexpr (EPH_WG_ABLATE & 1) {
+            asm volatile("" ::"v"(c[q]), "v"(c[3 * NB + q]));
+        } else {
+            tile_a[(3 * b0 + q) * kRow + lane] = c[q];
+            tile_b[(3 * b0 + q) * kRow + lane] = c[3 * NB + q];
+        }
     }
 }
 
@@ -164,19 +194,37 @@ __device__ __forceinline__ int big_count(int tiles) { return tiles <= 2 ? tiles 
 template <int NB, typename PosPtr>
 __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag, int wbuf) {
     double xi[NB], yi[NB], zi[NB];
+    Body4 first[4];
+    if constexpr (EPH_WG_X & 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int j = min(t, tiles - 1) * kTile + lane; first[t] = pos[j < n ? j : n - 1]; }
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int ii = min(i0 + b0 + b, n - 1);
-        xi[b] = pos[ii].x;
-        yi[b] = pos[ii].y;
-        zi[b] = pos[ii].z;
+        if constexpr (EPH_WG_X & 4) {
+            const auto *ps = (const __attribute__((address_space(4))) Body4 *)(unsigned long long)(&pos[__builtin_amdgcn_readfirstlane(ii)]);
+            xi[b] = ps->x; yi[b] = ps->y; zi[b] = ps->z;
+        } else {
+            xi[b] = pos[ii].x;
+            yi[b] = pos[ii].y;
+            zi[b] = pos[ii].z;
+        }
     }
     // (source rows addressed as SGPR tile base + loop-invariant VGPR offset, and two iterations per trip with the register sets
     // trading places instead of being copied, both remove VALU bookkeeping and both measured SLOWER: 38.0 / 39.0 against 36.9 us --
     // the pair waves are bound by f64 issue, not by their integer overhead; profiles/r03_step_kernel_evidence.md section 6)
+    const unsigned off_full = (unsigned)lane * (unsigned)sizeof(Body4);
+    const unsigned off_last = (unsigned)min(lane, n - 1 - (tiles - 1) * kTile) * (unsigned)sizeof(Body4);
     auto load_src = [&](int t) -> Body4 {
-        const int j = min(t, tiles - 1) * kTile + lane;
-        return pos[j < n ? j : n - 1];
+        if constexpr (EPH_WG_X & 8) {
+            const int tt = min(t, tiles - 1);
+            const char *tp = reinterpret_cast<const char *>(&pos[(size_t)tt * kTile]);
+            return *reinterpret_cast<const Body4 *>(tp + (tt == tiles - 1 ? off_last : off_full));
+        } else {
+            const int j = min(t, tiles - 1) * kTile + lane;
+            return pos[j < n ? j : n - 1];
+        }
     };
     auto produce = [&](int K, const Body4 &pa, const Body4 &pb) {          // big tile K
         const int t = big_start(K);
@@ -186,21 +234,35 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
         else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
     };
     const int TB = big_count(tiles);
-    Body4 pa = load_src(0), pb = load_src(1), na = load_src(2), nb = load_src(3);
+    Body4 pa, pb, na, nb;
+    if constexpr (EPH_WG_X & 2) { pa = first[0]; pb = first[1]; na = first[2]; nb = first[3]; }
+    else { pa = load_src(0); pb = load_src(1); na = load_src(2); nb = load_src(3); }
     produce(0, pa, pa);
     produce(1, pb, pb);
     __syncthreads();
-    for (int K = 0; K < TB; ++K) {
-        pa = na; pb = nb;
-        na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
-        produce(K + 2, pa, pb);
-        __syncthreads();
+    if constexpr (EPH_WG_X & 16) {
+        for (int K = 0; K < TB; K += 2) {
+            pa = load_src(big_start(K + 3)); pb = load_src(big_start(K + 3) + 1);
+            produce(K + 2, na, nb);
+            __syncthreads();
+            if (K + 1 >= TB) break;
+            na = load_src(big_start(K + 4)); nb = load_src(big_start(K + 4) + 1);
+            produce(K + 3, pa, pb);
+            __syncthreads();
+        }
+    } else {
+        for (int K = 0; K < TB; ++K) {
+            pa = na; pb = nb;
+            na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
+            produce(K + 2, pa, pb);
+            WG_LOOP_BARRIER();
+        }
     }
 }
 // a wave with no tile work: TB + 1 barriers like everybody
 __device__ __forceinline__ void wg_idle_wave(int tiles) {
     __syncthreads();
-    for (int T = 0; T < big_count(tiles); ++T) __syncthreads();
+    for (int T = 0; T < big_count(tiles); ++T) WG_LOOP_BARRIER();
 }
 
 // chain over a full tile whose first two chunks are already in q[0], q[1]; leaves the first two chunks of the
@@ -302,20 +364,16 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
         if (body >= 0) { wg_pair_wave_big<1>(pos, n, i0, body, C, lane, tiles, tdiag, kBuf); return 0.0; }
         if (wave != kWgChainWave) { wg_idle_wave(tiles); return 0.0; }
     } else {
-        switch (wave) {                                  // wave k runs on SIMD k % 4
-            case 0: wg_pair_wave_big<1>(pos, n, i0, 0, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 8: wg_idle_wave(tiles); return 0.0;    // (k_lm_step_wg gives this wave the integrator's work instead)
-            case 1: wg_pair_wave_big<2>(pos, n, i0, 1, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 5: wg_pair_wave_big<2>(pos, n, i0, 3, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 9: wg_pair_wave_big<1>(pos, n, i0, 5, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 2: wg_pair_wave_big<2>(pos, n, i0, 6, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 6: wg_pair_wave_big<2>(pos, n, i0, 8, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 10: wg_pair_wave_big<1>(pos, n, i0, 10, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 3: wg_pair_wave_big<2>(pos, n, i0, 11, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 7: wg_pair_wave_big<2>(pos, n, i0, 13, C, lane, tiles, tdiag, kBuf); return 0.0;
-            case 11: wg_pair_wave_big<1>(pos, n, i0, 15, C, lane, tiles, tdiag, kBuf); return 0.0;
-            default: break;
-        }
+        // Roles of the twelve waves (wave k runs on SIMD k % 4): pair waves of 2 / 2 / 1 bodies on SIMDs 1-3, a one-body pair wave
+        // on SIMD 0 beside the chain wave (4) and the tail wave (8). ONE copy of the pair loop per body count, the role's first
+        // body a run-time scalar: inlining the loop once per role (eleven copies, round 2-3) measured 0.15 us slower at N = 4096
+        // (36.20 against 36.04 us, profiles/r04_step_kernel_evidence.md) and is 40 KB more code per evaluation order.
+        const int w = __builtin_amdgcn_readfirstlane(wave);
+        const int nb = (w == kWgChainWave || w == kWgTailWave) ? 0 : ((w == 0 || w >= 9) ? 1 : 2);
+        const int b0 = w == 0 ? 0 : w == 1 ? 1 : w == 5 ? 3 : w == 9 ? 5 : w == 2 ? 6 : w == 6 ? 8 : w == 10 ? 10 : w == 3 ? 11 : w == 7 ? 13 : 15;
+        if (nb == 2) { wg_pair_wave_big<2>(pos, n, i0, b0, C, lane, tiles, tdiag, kBuf); return 0.0; }
+        if (nb == 1) { wg_pair_wave_big<1>(pos, n, i0, b0, C, lane, tiles, tdiag, kBuf); return 0.0; }
+        if (w == kWgTailWave) { wg_idle_wave(tiles); return 0.0; }   // (k_lm_step_wg gives this wave the integrator's work instead)
     }
     // chain wave. Its dependent adds issue ahead of the one-body pair wave of its SIMD (s_setprio; the same library with and
     // without, alternating on one box: 36.3 against 36.8 us per step at N = 4096 on two boxes of the pool, 36.2 either way on a
@@ -348,7 +406,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
                 load_chunk(rn, 1, q[1]);
             }
         }
-        __syncthreads();                              // big tile T consumed, big tile T + 2 ready
+        WG_LOOP_BARRIER();                            // big tile T consumed, big tile T + 2 ready
     }
     return accL + acc;
 }
@@ -412,21 +470,21 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
         __syncthreads();                              // the chain wave's result is in LDS
         if (owner) {
             const double anew = C[lane];
-            a.A[(size_t)a.cur * lvl + off] = anew;
+            tail_store(&a.A[(size_t)a.cur * lvl + off], anew);
             {
                 double prev[L];
 #pragma unroll
                 for (int j = 0; j < L - 1; ++j) prev[j] = av[j + 1];
                 prev[L - 1] = 0.0;
-                a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
+                tail_store(&a.V[off], lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc));
             }
             maybe_sample(a.samp, my_i, cc, a.step, yv[0]);
             if (a.do_predict) {
                 av[0] = anew;
                 const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
                 const int nslot = (a.cur + L - 1) % L;
-                a.Y[(size_t)nslot * lvl + off] = ynext;
-                reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
+                tail_store(&a.Y[(size_t)nslot * lvl + off], ynext);
+                tail_store(&reinterpret_cast<double *>(a.pos_next + my_i)[cc], ynext);
             }
         }
     } else {

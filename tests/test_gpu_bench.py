@@ -52,9 +52,14 @@ def test_default_line_single_gpu():
         assert k in d["cpu_baseline"]
     assert "plummer_4096_f64_qt12" in d["config"]["workload"]
     # the companions of the default line: configs[1] in-process, the configs[3] sweep from a child process
+    assert d["pair_variant"] == 0 and set(d["other_variants"]) == {"1", "2", "3", "4", "5", "6"}
+    assert d["roofline"]["binding"] == "fp64_valu" and 0.05 < d["roofline"]["fp64"]["frac"] < 0.5
+    assert d["long_region"]["steps"] == 100 and d["long_region"]["ms_per_step"] <= d["ms_per_step"] * 1.02
     oc = d["other_configs"]
     assert oc["configs1_full_solar_system"]["bodies"] == 32 and 0.1 < oc["configs1_full_solar_system"]["us_per_step"] < 5.0
     assert oc["configs3_craft_sweep"]["value"] > 1e7 and "craft" in oc["configs3_craft_sweep"]["workload"]
+    assert oc["configs3_craft_sweep"]["fp64"]["frac"] > 0.05 and oc["configs3_craft_sweep"]["cpu_baseline"]["cores"] == 1
+    assert oc["configs3_craft_sweep"]["wall_over_kernel"] < 1.2
 
 
 def test_two_ranks_replicas():
@@ -77,6 +82,21 @@ def test_gpus_flag_without_a_launcher_spawns_its_own_ranks():
     assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     s4 = d["sharded_4096"]                              # the strong-scaling figure of the metric's own system
     assert s4["ranks"] == 2 and s4["ms_per_step"] > 0 and s4["bit_identical_to_single_device"] is True
+    # the preflight ran every transport this job can use against the single-device bits before the sharded timing
+    assert d["transports"]["peer"] == "ok" and d["transports"]["host"] == "ok" and d["transports"]["peer_memory"][0] in ("fine", "coarse")
+
+
+def test_craft_workload_spawns_its_own_ranks_too():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["EPH_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "craft", "--gpus", "2", "--craft", "32768", "--steps", "2",
+                        "--warmup", "1", "--prewarm", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["metric"] == "craft-steps/s" and d["roofline"]["binding"] == "fp64_valu" and d["roofline"]["fp64"]["frac"] > 0
 
 
 def test_a_strong_scaling_leg_that_never_returns_does_not_cost_the_line():

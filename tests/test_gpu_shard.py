@@ -294,3 +294,82 @@ def test_peer_that_never_delivers_is_an_error_not_a_hang(gpu):
     mp.spawn(_lost_peer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     status, text = out[0]
     assert status == -6 and "rank 1" in text
+
+
+def _fallback_worker(rank, world, port, force, out):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), EPH_PEER_TIMEOUT_MS="5000")
+    if force:
+        os.environ["EPH_PEER_FORCE_FAIL"] = force
+    import torch.distributed as dist
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel, mu = plummer(1024)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    t = parallel.peer_transport(dist, slot_bytes=1 << 16)
+    nb.shard_peer(t)
+    nb.advance(12 + 8)
+    p, v = nb.state()[:2]
+    out[rank] = (t.memory, list(t.forms), list(t.attempts), p, v)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("force,memory", [("", None), ("alloc", "coarse"), ("export", "coarse"), ("open", "coarse")])
+def test_peer_mailbox_fallbacks(gpu, force, memory):
+    """Every branch of the mailbox's fallback (csrc/peer.hip, parallel.peer_transport), forced with EPH_PEER_FORCE_FAIL: the
+    fine-grained allocation fails, its hipIpc export fails (both: plain device memory inside eph_peer_create), a peer cannot map
+    it (every rank re-creates in plain device memory and connects again) -- the exchange works and reports which form is live."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fallback_worker, args=(2, _free_port(), force, out), nprocs=2, join=True)
+    (p0, v0, t0, sc0), a0 = _single(1024, "QuinlanTremaine12", 12 + 8)
+    for r in range(2):
+        mem, forms, attempts, p, v = out[r]
+        assert np.array_equal(p, p0) and np.array_equal(v, v0), (force, r)
+        assert mem in ("fine", "coarse") and forms == [mem, mem]
+        if memory:
+            assert mem == memory
+        if force == "open":
+            assert attempts and all("connect[auto]" in a for a in attempts)      # the first round failed on every rank, and says so
+        else:
+            assert attempts == []
+
+
+def _lost_peer_state_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), EPH_PEER_TIMEOUT_MS="300")
+    import torch.distributed as dist
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel, mu = plummer(256)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H, "BlanesMoan6B")
+    parallel.shard_nbody(nb, dist, transport="peer")
+    if rank == 0:                                      # rank 1 never joins the gather of get_state: THIS call must report it
+        try:
+            nb.state()
+            out[0] = "no error"
+        except ea.EphemerisError as e:
+            out[0] = (e.status, str(e))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_get_state_reports_a_lost_peer_itself(gpu):
+    """(advisor, round 3) a timed-out wait used to surface at the NEXT exchange, with the stale mailbox slot copied into the gathered
+    buffer and EPH_OK returned: the call that synchronises the stream now polls the transport, and the kernel skips the copy-out"""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lost_peer_state_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    status, text = out[0]
+    assert status == -6 and "rank 1" in text
