@@ -42,24 +42,8 @@
 #endif
 #define WG_LOOP_BARRIER() do { if constexpr (!(EPH_WG_ABLATE & 2)) __syncthreads(); } while (0)
 
-// round 4's structural attempts (profiles/r04_step_kernel_evidence.md), tuning builds only: EPH_WG_X & 1 = the tail wave's stores
-// (ring rows, velocity, next positions) nontemporal; & 2 = a pair wave's first source tiles requested before its own bodies'
-// positions; & 4 = own bodies' positions through scalar loads (SGPR operands of the differences); & 8 = source rows addressed as
-// uniform tile base + loop-invariant lane offset (no address arithmetic in the loop); & 16 = two intervals per trip, the two
-// register sets of prefetched sources trading places instead of being copied
-#if !EPH_EXPERIMENTS || !defined(EPH_WG_X)
-#undef EPH_WG_X
-#define EPH_WG_X 0
-#endif
-
 namespace eph {
 namespace EPH_PV_NS {
-
-template <typename T>
-__device__ __forceinline__ void tail_store(T *p, T v) {
-    if constexpr (EPH_WG_X & 1) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
 
 constexpr int kWgBodies = 16;
 constexpr int kWgChainWave = 4;                      // the chain wave (wave 4: lands on SIMD 0)
@@ -191,40 +175,29 @@ __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const doub
 // were measured: 37.6-37.7 vs 37.0 us at N = 4096, 18.6 vs 18.3 at 2048, 12.05 vs 11.9 at 1024. Not kept.)
 __device__ __forceinline__ int big_start(int K) { return K < 2 ? K : 2 * K - 2; }
 __device__ __forceinline__ int big_count(int tiles) { return tiles <= 2 ? tiles : 2 + (tiles - 2 + 1) / 2; }
+// (Round 4 measured what the loop's barriers cost -- pair side alone 34.4 us, 33.4 without its LDS writes, 28.6 without the
+// barriers either -- and replaced them by LDS counters: pair waves free-running up to two big tiles ahead, each adding 1 to a counter
+// behind its ds_writes, the chain wave polling that counter and publishing how far it has consumed. Bit-identical and SLOWER: 37.9
+// against 36.3 us at N = 4096, 19.6 against 18.6 at 2048 (39.1 with memory-model fences, which also wait for the prefetched global
+// loads). The barrier keeps the write bursts of ten waves and the chain wave's reads in separate phases of the one LDS pipe.
+// profiles/r04_step_kernel_evidence.md section 4; the patch: scripts/experiments/wg_counter_sync.patch.)
 template <int NB, typename PosPtr>
 __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int b0, double *C, int lane, int tiles, int tdiag, int wbuf) {
     double xi[NB], yi[NB], zi[NB];
-    Body4 first[4];
-    if constexpr (EPH_WG_X & 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { const int j = min(t, tiles - 1) * kTile + lane; first[t] = pos[j < n ? j : n - 1]; }
-    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int ii = min(i0 + b0 + b, n - 1);
-        if constexpr (EPH_WG_X & 4) {
-            const auto *ps = (const __attribute__((address_space(4))) Body4 *)(unsigned long long)(&pos[__builtin_amdgcn_readfirstlane(ii)]);
-            xi[b] = ps->x; yi[b] = ps->y; zi[b] = ps->z;
-        } else {
-            xi[b] = pos[ii].x;
-            yi[b] = pos[ii].y;
-            zi[b] = pos[ii].z;
-        }
+        xi[b] = pos[ii].x;
+        yi[b] = pos[ii].y;
+        zi[b] = pos[ii].z;
     }
-    // (source rows addressed as SGPR tile base + loop-invariant VGPR offset, and two iterations per trip with the register sets
-    // trading places instead of being copied, both remove VALU bookkeeping and both measured SLOWER: 38.0 / 39.0 against 36.9 us --
-    // the pair waves are bound by f64 issue, not by their integer overhead; profiles/r03_step_kernel_evidence.md section 6)
-    const unsigned off_full = (unsigned)lane * (unsigned)sizeof(Body4);
-    const unsigned off_last = (unsigned)min(lane, n - 1 - (tiles - 1) * kTile) * (unsigned)sizeof(Body4);
+    // (Measured and NOT kept, rounds 3 and 4, each bit-identical: source rows addressed as uniform tile base + loop-invariant lane
+    // offset -- ten VALU fewer per interval -- 36.7 against 36.2 us; two intervals per trip with the prefetched register sets
+    // trading places instead of being copied 38.7; own bodies' positions through scalar loads 36.4; the first source tiles requested
+    // before the own positions 36.3; nontemporal stores of the tail wave 36.1 (nothing): profiles/r04_step_kernel_evidence.md.)
     auto load_src = [&](int t) -> Body4 {
-        if constexpr (EPH_WG_X & 8) {
-            const int tt = min(t, tiles - 1);
-            const char *tp = reinterpret_cast<const char *>(&pos[(size_t)tt * kTile]);
-            return *reinterpret_cast<const Body4 *>(tp + (tt == tiles - 1 ? off_last : off_full));
-        } else {
-            const int j = min(t, tiles - 1) * kTile + lane;
-            return pos[j < n ? j : n - 1];
-        }
+        const int j = min(t, tiles - 1) * kTile + lane;
+        return pos[j < n ? j : n - 1];
     };
     auto produce = [&](int K, const Body4 &pa, const Body4 &pb) {          // big tile K
         const int t = big_start(K);
@@ -234,29 +207,15 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
         else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
     };
     const int TB = big_count(tiles);
-    Body4 pa, pb, na, nb;
-    if constexpr (EPH_WG_X & 2) { pa = first[0]; pb = first[1]; na = first[2]; nb = first[3]; }
-    else { pa = load_src(0); pb = load_src(1); na = load_src(2); nb = load_src(3); }
+    Body4 pa = load_src(0), pb = load_src(1), na = load_src(2), nb = load_src(3);
     produce(0, pa, pa);
     produce(1, pb, pb);
     __syncthreads();
-    if constexpr (EPH_WG_X & 16) {
-        for (int K = 0; K < TB; K += 2) {
-            pa = load_src(big_start(K + 3)); pb = load_src(big_start(K + 3) + 1);
-            produce(K + 2, na, nb);
-            __syncthreads();
-            if (K + 1 >= TB) break;
-            na = load_src(big_start(K + 4)); nb = load_src(big_start(K + 4) + 1);
-            produce(K + 3, pa, pb);
-            __syncthreads();
-        }
-    } else {
-        for (int K = 0; K < TB; ++K) {
-            pa = na; pb = nb;
-            na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
-            produce(K + 2, pa, pb);
-            WG_LOOP_BARRIER();
-        }
+    for (int K = 0; K < TB; ++K) {
+        pa = na; pb = nb;
+        na = load_src(big_start(K + 3)); nb = load_src(big_start(K + 3) + 1);
+        produce(K + 2, pa, pb);
+        WG_LOOP_BARRIER();
     }
 }
 // a wave with no tile work: TB + 1 barriers like everybody
@@ -366,7 +325,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     } else {
         // Roles of the twelve waves (wave k runs on SIMD k % 4): pair waves of 2 / 2 / 1 bodies on SIMDs 1-3, a one-body pair wave
         // on SIMD 0 beside the chain wave (4) and the tail wave (8). ONE copy of the pair loop per body count, the role's first
-        // body a run-time scalar: inlining the loop once per role (eleven copies, round 2-3) measured 0.15 us slower at N = 4096
+        // body a run-time scalar: inlining the loop once per role (ten copies, round 2-3) measured 0.15 us slower at N = 4096
         // (36.20 against 36.04 us, profiles/r04_step_kernel_evidence.md) and is 40 KB more code per evaluation order.
         const int w = __builtin_amdgcn_readfirstlane(wave);
         const int nb = (w == kWgChainWave || w == kWgTailWave) ? 0 : ((w == 0 || w >= 9) ? 1 : 2);
@@ -378,17 +337,17 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     // chain wave. Its dependent adds issue ahead of the one-body pair wave of its SIMD (s_setprio; the same library with and
     // without, alternating on one box: 36.3 against 36.8 us per step at N = 4096 on two boxes of the pool, 36.2 either way on a
     // third; nothing at the chain-bound sizes)
-    if constexpr (WB == kWgBodies) __builtin_amdgcn_s_setprio(3);
     const int ch = lane < kRows ? lane : kRows - 1;
     const double *row = C + ch * kRow;
     const int gself = (i0 % kTile) / WB;
     const int li = (i0 % kTile) + ch / 3;
     double acc = init, accL = 0.0;
     double2 q[4][8];
+    const int TB = big_count(tiles);
+    if constexpr (WB == kWgBodies) __builtin_amdgcn_s_setprio(3);
     __syncthreads();                                  // B_0: tiles 0 and 1 ready
     load_chunk(row, 0, q[0]);
     load_chunk(row, 1, q[1]);
-    const int TB = big_count(tiles);
     for (int T = 0; T < TB; ++T) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -470,21 +429,21 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
         __syncthreads();                              // the chain wave's result is in LDS
         if (owner) {
             const double anew = C[lane];
-            tail_store(&a.A[(size_t)a.cur * lvl + off], anew);
+            a.A[(size_t)a.cur * lvl + off] = anew;
             {
                 double prev[L];
 #pragma unroll
                 for (int j = 0; j < L - 1; ++j) prev[j] = av[j + 1];
                 prev[L - 1] = 0.0;
-                tail_store(&a.V[off], lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc));
+                a.V[off] = lm_cowell<L>(anew, prev, yv[0], yv[1], a.cw, a.h, a.hc);
             }
             maybe_sample(a.samp, my_i, cc, a.step, yv[0]);
             if (a.do_predict) {
                 av[0] = anew;
                 const double ynext = lm_predict<L>(yv, av, a.wa, a.wb, a.hh);
                 const int nslot = (a.cur + L - 1) % L;
-                tail_store(&a.Y[(size_t)nslot * lvl + off], ynext);
-                tail_store(&reinterpret_cast<double *>(a.pos_next + my_i)[cc], ynext);
+                a.Y[(size_t)nslot * lvl + off] = ynext;
+                reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
             }
         }
     } else {
