@@ -119,11 +119,14 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
 // ------------------------------------------------------------------------------------------------------
 // OPT-IN MIXED PRECISION (eph_nbody_set_path(.., EPH_PATH_F32_PAIRS); BASELINE.json configs[4] "65 536-body f32 system"):
 // the pair arithmetic in binary32 -- differences of positions rounded to f32, n2 by fma, v_rsq_f32 + one Newton step,
-// y^3, mu y^3, the three products -- two sources at a time in the packed f32 instructions (v_pk_add / v_pk_mul /
-// v_pk_fma_f32: the only VALU form that runs at twice the f64 rate), every contribution then converted to f64 and
-// ACCUMULATED in f64 in the fast path's slice order; Cowell, predictor and the whole integrator state stay f64 (a
-// twelfth-order multistep recurrence cannot hold its state in binary32). The reference has no f32
-// path (ephemeris/src/propagators/nbody.rs:13,19): no parity claim, never the default, for large systems only.
+// ((mu y) y) y, the three products -- two sources at a time in the packed f32 instructions (v_pk_add / v_pk_mul /
+// v_pk_fma_f32: the only VALU form that runs at twice the f64 rate), the contributions of FOUR consecutive sources summed in
+// binary32, converted and ACCUMULATED in f64 in the fast path's slice order; Cowell, predictor and the whole integrator state
+// stay f64 (a twelfth-order multistep recurrence cannot hold its state in binary32). The reference has no
+// f32 path (ephemeris/src/propagators/nbody.rs:13,19): no parity claim, never the default, for large systems only.
+// Supported magnitudes: positions and mu must be representable in binary32 (|x| < 3.4e38, mu >= 1.2e-38 or 0); separations from
+// 0 (two bodies coinciding after rounding: their mutual term is dropped) to 1.8e19 length units (beyond: the term is ~0) --
+// the reference's km and N-body units are far inside, SI metres at heliocentric distances (1e12-1e13) still are.
 // ------------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct BodyF { float x, y, z, mu; };
@@ -134,7 +137,7 @@ __global__ void __launch_bounds__(256) k_pos_to_f32(int n, int npad, const Body4
     if (i < n) { const Body4 p = pos[i]; b = BodyF{(float)p.x, (float)p.y, (float)p.z, (float)p.mu}; }
     out[i] = b;
 }
-template <bool DIAG>
+template <bool MASKED>
 __device__ __forceinline__ void f32_slice(const __attribute__((address_space(4))) BodyF *src, int j0, int j1, int n, int i,
                                           float xi, float yi, float zi, double &ax, double &ay, double &az) {
     constexpr int U = 4;                               // sources per iteration: two packed pairs
@@ -151,21 +154,31 @@ __device__ __forceinline__ void f32_slice(const __attribute__((address_space(4))
             v2f n2 = dx * dx;
             n2 = __builtin_elementwise_fma(dy, dy, n2);
             n2 = __builtin_elementwise_fma(dz, dz, n2);
+            // two bodies whose positions coincide after rounding to binary32 (n2 = 0) and separations beyond 1.8e19 length units
+            // (n2 = inf) would turn the sum into NaN: clamped (one v_med3_f32 each), their terms come out as 0 resp. negligible
+            n2 = v2f{__builtin_amdgcn_fmed3f(n2.x, 1.0e-37f, 3.0e38f), __builtin_amdgcn_fmed3f(n2.y, 1.0e-37f, 3.0e38f)};
             v2f y{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)};
             const v2f hn = n2 * v2f{0.5f, 0.5f};
             const v2f r = __builtin_elementwise_fma(-(hn * y), y, v2f{0.5f, 0.5f});   // 0.5 (1 - n2 y^2)
             y = __builtin_elementwise_fma(y, r, y);
-            const v2f sc = v2f{pa.mu, pb.mu} * (y * y * y);
+            // (mu y) y y, not mu (y y y): y^3 alone leaves binary32's normal range for separations above 2e12 length units
+            const v2f sc = ((v2f{pa.mu, pb.mu} * y) * y) * y;
             cx[h] = dx * sc; cy[h] = dy * sc; cz[h] = dz * sc;
         }
+        if constexpr (MASKED) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (DIAG && j + u == i) continue;          // the body itself (n2 = 0 -> NaN): not a source
-            if (j + u >= n) continue;                  // padding rows
-            ax = ax + (double)cx[u >> 1][u & 1];
-            ay = ay + (double)cy[u >> 1][u & 1];
-            az = az + (double)cz[u >> 1][u & 1];
+            for (int u = 0; u < U; ++u) {
+                if ((j + u == i) || (j + u >= n)) {    // the body itself (its clamped term is not a source); padding rows
+                    cx[u >> 1][u & 1] = 0.0f; cy[u >> 1][u & 1] = 0.0f; cz[u >> 1][u & 1] = 0.0f;
+                }
+            }
         }
+        // the four contributions summed in binary32 (their own rounding is 2^-24 of each term, as is the sum's), ONE conversion and
+        // one f64 addition per component and four sources: the f64 side was a third of the loop's issue cycles (6 cvt + 6 adds per two)
+        const v2f sx = cx[0] + cx[1], sy = cy[0] + cy[1], sz = cz[0] + cz[1];
+        ax = ax + (double)(sx.x + sx.y);
+        ay = ay + (double)(sy.x + sy.y);
+        az = az + (double)(sz.x + sz.y);
     }
 }
 __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int npad, const BodyF *__restrict__ posf, int S,
@@ -182,7 +195,7 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int
     const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (j0 < j1) {
-        if (j0 < block * 64 + 64 && j1 > block * 64) f32_slice<true>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        if ((j0 < block * 64 + 64 && j1 > block * 64) || j1 > n) f32_slice<true>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
         else f32_slice<false>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
     }
     double *pp = partial + (size_t)slice * 3 * npad + i;

@@ -130,7 +130,7 @@ def test_fast_path_body_at_the_origin_with_padded_sources(gpu, path):
     assert np.abs(a - ae).max() < 1e-9 * np.abs(ae).max()
 
 
-@pytest.mark.parametrize("n", [1000, 16384])
+@pytest.mark.parametrize("n", [1000, 16384, 65536])      # 65 536: BASELINE configs[4]'s size
 def test_f32_pairs_path(gpu, n):
     """EPH_PATH_F32_PAIRS (BASELINE.json configs[4]'s precision): pair arithmetic in binary32, f64 accumulation in slice
     order, f64 integrator. Deterministic; accelerations at single-precision distance from the exact path's, the state after
