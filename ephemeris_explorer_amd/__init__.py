@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
     "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_quot", "eph_debug_inv_r3_sweep", "eph_debug_wg_cycles",
-    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
+    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_set_body_order", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_summary", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div", "eph_debug_rsq",
@@ -768,6 +768,16 @@ class SpacecraftBatch:
 
     RECORD = np.dtype([("t", "f8"), ("pos", "f8", 3), ("vel", "f8", 3), ("next_h", "f8"), ("status", "i4"), ("nknots", "i4"),
                        ("attempts", "u4"), ("steps", "u4")])        # eph_craft_record
+
+    def set_body_order(self, order):
+        """The order in which the massive bodies' terms are added in the acceleration (eph_craft_batch_set_body_order):
+        a permutation of range(n_bodies), or None for the table's order."""
+        if order is None:
+            _check(self._L.eph_craft_batch_set_body_order(self._h, None), "eph_craft_batch_set_body_order")
+        else:
+            o = np.ascontiguousarray(order, dtype=np.int32)
+            _check(self._L.eph_craft_batch_set_body_order(self._h, o.ctypes.data_as(C.POINTER(C.c_int32))), "eph_craft_batch_set_body_order")
+        return self
 
     def summary(self, out=None):
         """status() and state() in one device-packed record array (eph_craft_batch_summary): fields t, pos, vel, next_h,

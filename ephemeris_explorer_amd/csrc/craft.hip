@@ -714,6 +714,7 @@ struct eph_craft_batch {
     DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (a clone's: on first use)
     DevBuf<unsigned long long> queue;         // k_craft_queue's work queue (one counter)
     bool heterogeneous = false;               // the craft's dynamical time scales differ widely (craft_time_scales): queue form
+    DevBuf<int> body_order;                   // eph_craft_batch_set_body_order (empty: table order)
     DevBuf<int> perm, slot_of;                // heterogeneous batches: lane / queue position -> craft by dynamical time, and back
     std::vector<int> h_slot;                  //   (craft_sort); the knot slabs' columns are lane positions
     // SpacecraftSolout events (optional)
@@ -1148,6 +1149,7 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
     a.step_limit = step_limit;
     a.queue = b->queue.p;
     a.perm = b->perm.p;
+    a.body_order = b->body_order.p;
     EPH_HIP(hipEventRecord(b->ev0, b->stream));
     int st = craft_launch(b->pv, b->stream, a, b->heterogeneous);
     if (st) return st;
@@ -1251,6 +1253,28 @@ int32_t eph_craft_batch_summary(eph_craft_batch *b, eph_craft_record *out) {
     const auto t2 = tick();
     EPH_HIP(hipStreamSynchronize(b->stream));
     if (trace) fprintf(stderr, "summary: pack launch %.0f memcpyAsync %.0f sync %.0f us\n", us(t0, t1), us(t1, t2), us(t2, tick()));
+    return EPH_OK;
+}
+
+// The order in which Bodies::acceleration adds the massive bodies' terms (dynamics/spacecraft.rs:222-228 iterates an EntityHashMap:
+// unspecified upstream). Table (file) order by default -- the library test's IndexMap; a maintainer who wants the bits of a given
+// app run passes that run's iteration order here. Burn reference bodies, SOI radii and event body indices keep the table's numbering.
+int32_t eph_craft_batch_set_body_order(eph_craft_batch *b, const int32_t *order) {
+    if (!b) return EPH_ERR_BAD_ARGUMENT;
+    EPH_HIP(hipSetDevice(b->device));
+    EPH_HIP(hipStreamSynchronize(b->stream));
+    if (!order) { b->body_order.release(); return EPH_OK; }
+    const int n = b->eph->n_bodies;
+    std::vector<int> o((size_t)std::max(n, 1));
+    std::vector<char> seen((size_t)std::max(n, 1), 0);
+    for (int q = 0; q < n; ++q) {
+        if (order[q] < 0 || order[q] >= n || seen[(size_t)order[q]]) return EPH_ERR_BAD_ARGUMENT;   // not a permutation
+        seen[(size_t)order[q]] = 1;
+        o[(size_t)q] = order[q];
+    }
+    int st;
+    if ((st = b->body_order.alloc(o.size()))) return st;
+    EPH_HIP(hipMemcpy(b->body_order.p, o.data(), sizeof(int) * o.size(), hipMemcpyHostToDevice));
     return EPH_OK;
 }
 
@@ -1411,7 +1435,7 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
             (st = clone_buf(b->ntr, c->ntr, s)) || (st = clone_buf(b->nap, c->nap, s)) ||
             (st = clone_buf(b->ev_status, c->ev_status, s)) || (st = clone_buf(b->tr_body, c->tr_body, s)) ||
             (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)) ||
-            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = c->queue.alloc(1)))
+            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = clone_buf(b->body_order, c->body_order, s)) || (st = c->queue.alloc(1)))
             return st;
         c->h_slot = b->h_slot;
         EPH_HIP(hipStreamSynchronize(s));

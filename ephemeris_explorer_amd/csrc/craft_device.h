@@ -48,6 +48,7 @@ struct CraftArgs {
     double t_end;
     unsigned step_limit;      // accepted steps this call may take per craft (0 = until t_end)
     unsigned long long *queue;   // k_craft_propagate's work queue: the next craft nobody has started (set by craft_launch)
+    const int *body_order;       // the order Bodies::acceleration visits the bodies in (null: table order); eph_craft_batch_set_body_order
     const int *perm;             // lane / queue position -> craft (null: identity). Heterogeneous batches: craft sorted by their
                                  // dynamical time at creation, so that the lanes of a wave carry craft of similar step counts
 };

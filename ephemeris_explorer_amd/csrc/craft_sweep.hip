@@ -130,13 +130,13 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     if (WAVE) {
         const int lane = threadIdx.x;
         for (int b0 = 0; b0 < a.n_bodies; b0 += kTile) {
-            const int b = b0 + lane;
+            const int b = b0 + lane;                  // position in the sum; the body there: a.body_order[b] (table order by default)
             V3 term = {0.0, 0.0, 0.0};
             bool located = true;
             if (b < a.n_bodies) {
-                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);
+                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);   // (lb holds that body, k_craft_wave)
                 else {
-                    const BodyEntry be = a.bodies[b];
+                    const BodyEntry be = a.bodies[a.body_order ? a.body_order[b] : b];
                     located = body_term(a, be, t, pos, term);
                 }
             }
@@ -169,9 +169,9 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             acc.z = lane_bcast(sum, 2);
         }
     } else {
-        for (int b = 0; b < a.n_bodies; ++b) {        // Bodies::acceleration: index order
+        for (int q = 0; q < a.n_bodies; ++q) {        // Bodies::acceleration: table order, or the caller's permutation of it
             // the body's table entry is the same for every lane: scalar loads through the constant address space
-            const int bu = __builtin_amdgcn_readfirstlane(b);
+            const int bu = __builtin_amdgcn_readfirstlane(a.body_order ? a.body_order[q] : q);
             const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
             BodyEntry be;
             be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
     }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
     LaneBody lb;
-    lb.be = a.bodies[lane < a.n_bodies ? lane : 0];
+    lb.be = a.bodies[lane < a.n_bodies ? (a.body_order ? a.body_order[lane] : lane) : 0];
     lb.r = rcp_refined(lb.be.interval);
     lb.b_ok = in_range_div(lb.be.interval);
     lb.idx = -1;

@@ -302,6 +302,11 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
                                eph_craft_batch **out);
 /* IncrementalPropagator::step_to for every craft: step() until solution.end() >= t_end (spacecraft.rs:598-615,
  * 691-693) or an error; per-craft outcomes via eph_craft_batch_status. Returns EPH_OK if the sweep ran. */
+/* The order in which the massive bodies' terms are added in a craft's acceleration (Bodies::acceleration iterates an EntityHashMap,
+ * ephemeris_explorer/src/dynamics/spacecraft.rs:164-165,222-228: unspecified upstream). Default: the ephemeris table's (file) order,
+ * which is what the library test's IndexMap gives (ephemeris/tests/spacecraft_propagation.rs:226-240). `order` = a permutation of
+ * 0 .. n_bodies-1 (position in the sum -> body), NULL = back to table order; takes effect for the steps that follow. */
+int32_t eph_craft_batch_set_body_order(eph_craft_batch *b, const int32_t *order);
 int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end);
 /* IncrementalPropagator::step n_steps times for every craft (ephemeris/src/lib.rs:40-47, spacecraft.rs:598-615): each
  * craft takes exactly n_steps accepted steps (one knot each) unless it fails or its knot slab fills. */

@@ -1318,6 +1318,7 @@ typedef struct { double start, end; int is_burn; v3 acc; int ref; } segment_t;
 struct orc_craft {
     const orc_solution *eph;
     double *mu;
+    int32_t *body_order;           /* NULL = file order; else the order Bodies::acceleration visits the bodies in */
     int nseg, current_segment;
     segment_t *seg;
     /* problem */
@@ -1355,7 +1356,10 @@ static int craft_rhs(void *ctx, double t, const double *y, double *dy) {
     const v3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
     /* Bodies::acceleration  dynamics/spacecraft.rs:222-228 */
     v3 acc = {0.0, 0.0, 0.0};
-    for (int b = 0; b < c->eph->n; ++b) {
+    /* (the app iterates an EntityHashMap, dynamics/spacecraft.rs:164-165,222-228: its order is unspecified upstream; file order
+     * by default -- the library test's IndexMap -- or the permutation given to orc_craft_set_body_order) */
+    for (int q = 0; q < c->eph->n; ++q) {
+        const int b = c->body_order ? c->body_order[q] : q;
         double tau;
         const poly_t *p = spline_get_polynomial(&c->eph->s[b], t, &tau);
         if (!p) return ORC_EVAL_FAILED;
@@ -1665,7 +1669,25 @@ orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, c
     craft_push_knot(c);                                          /* CubicHermiteSplineSolout::new_solution :654-661 */
     return c;
 }
+int orc_craft_set_body_order(orc_craft *c, const int32_t *order) {
+    free(c->body_order);
+    c->body_order = NULL;
+    if (!order) return ORC_OK;
+    const int n = c->eph->n;
+    int32_t *o = malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    char *seen = calloc((size_t)(n > 0 ? n : 1), 1);
+    int ok = o && seen;
+    for (int q = 0; ok && q < n; ++q) {
+        ok = order[q] >= 0 && order[q] < n && !seen[order[q]];
+        if (ok) { seen[order[q]] = 1; o[q] = order[q]; }
+    }
+    free(seen);
+    if (!ok) { free(o); return ORC_BAD_ARGUMENT; }
+    c->body_order = o;
+    return ORC_OK;
+}
 void orc_craft_free(orc_craft *c) {
+    if (c) free(c->body_order);
     if (!c) return;
     free(c->mu); free(c->seg); free(c->kt); free(c->kp); free(c->kv); free(c->soi_radius); free(c->tr); free(c->ap);
     free(c);

@@ -126,6 +126,8 @@ orc_craft *orc_craft_new(const orc_solution *eph, const double *mu, double t0, c
                          double fac_min, double fac_max, double fac, uint32_t n_max, int nburns,
                          const double *burn_start, const double *burn_end, const double *burn_acc,
                          const int32_t *burn_ref);
+/* the order Bodies::acceleration visits the bodies in (a permutation of 0..n-1; NULL = file order) */
+int orc_craft_set_body_order(orc_craft *, const int32_t *order);
 void orc_craft_free(orc_craft *);
 int orc_craft_step(orc_craft *);              /* IncrementalPropagator::step  spacecraft.rs:598-615 */
 int orc_craft_step_to(orc_craft *, double t); /* step_to: until solution.end() >= t */

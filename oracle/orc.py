@@ -108,6 +108,8 @@ def lib(native=False):
     L.orc_craft_new.argtypes = [vp, _dp, C.c_double, _dp, _dp, C.c_char_p] + [C.c_double] * 7 + [C.c_uint32, C.c_int,
                                 _dp, _dp, _dp, _i32p]
     L.orc_craft_free.argtypes = [vp]
+    L.orc_craft_set_body_order.argtypes = [vp, _i32p]
+    L.orc_craft_set_body_order.restype = C.c_int
     L.orc_craft_free.restype = None
     L.orc_craft_step.argtypes = [vp]
     L.orc_craft_step_to.argtypes = [vp, C.c_double]
@@ -384,7 +386,7 @@ class Craft:
 
     def __init__(self, eph, mu, t0, pos, vel, method="Verner87", h_init=60.0, h_max=1.7976931348623157e308,
                  tol_pos=1e-3, tol_vel=1e-3, fac_min=1.0 / 5.0, fac_max=5.0 / 1.0, fac=9.0 / 10.0, n_max=1_000_000,
-                 burns=(), soi_radius=None):
+                 burns=(), soi_radius=None, body_order=None):
         self.L = eph.L
         self.eph = eph          # keep the splines alive
         mu, pos, vel = _f64(mu), _f64(pos), _f64(vel)
@@ -398,6 +400,10 @@ class Craft:
                                       _ptr(br, _i32p))
         if not self.h:
             raise ValueError(method)
+        if body_order is not None:      # the order Bodies::acceleration visits the bodies in
+            bo = np.ascontiguousarray(body_order, dtype=np.int32)
+            if self.L.orc_craft_set_body_order(self.h, _ptr(bo, _i32p)) != 0:
+                raise ValueError("body_order must be a permutation of the bodies")
         if soi_radius is not None:      # the app's SpacecraftSolout: SOI transitions + apsides
             self.L.orc_craft_enable_events(self.h, _ptr(_f64(soi_radius)))
 

@@ -621,3 +621,50 @@ def test_queue_and_static_sweeps_give_the_same_bits(gpu, tmp_path, method):
         nk = a["rec"]["nknots"][i]
         assert nk == len(ot)
         assert np.array_equal(b["kt"][:nk, i], ot) and np.array_equal(b["ky"][:nk, :3, i], op) and np.array_equal(b["ky"][:nk, 3:, i], ov)
+
+
+def test_body_order_of_the_acceleration_sum(gpu):
+    """eph_craft_batch_set_body_order: the app iterates an EntityHashMap (dynamics/spacecraft.rs:164-165,222-228), so WHICH order
+    the massive bodies' terms are added in is the caller's to say. Thread-per-craft and wave-per-craft kernels against the
+    restatement in the same order; a permutation changes bits; None restores the table's order; non-permutations are refused."""
+    from conftest import ROOT
+    from ephemeris_explorer_amd.systems import load_system as load_sys
+    sysdir = ROOT / "tests/golden/systems/full_solar_system_2433282.5"
+    s = load_sys(sysdir)
+    ship = load_ship(sysdir / "ships" / "Mars Transfer Ship.json")
+    g = gpu.NBodyPropagator.from_system(s)
+    o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree)
+    g.step_to(ship.start + 2 * 86400.0)
+    assert o.step_to(ship.start + 2 * 86400.0) == 0
+    sg, so = g.take_solution(), o.take_solution()
+    eph = gpu.Ephemeris(sg, s.mu)
+    order = np.random.default_rng(4).permutation(s.n).astype(np.int32)
+    t_end = ship.start + 6 * 3600.0
+    knots = {}
+    for ncraft in (3, 20000):                          # wave-per-craft | thread-per-craft
+        pos = np.repeat(ship.pos[None], ncraft, 0) + np.arange(ncraft)[:, None] * 1e-2
+        vel = np.repeat(ship.vel[None], ncraft, 0)
+        for which in ("table", "permuted"):
+            b = gpu.SpacecraftBatch(eph, ship.start, pos, vel, "Verner87", max_knots=256)
+            if which == "permuted":
+                b.set_body_order(order)
+            tw = b.clone()                             # a clone inherits the order
+            for x in (b, tw):
+                x.propagate(t_end)
+                assert (x.status()["status"] == 0).all()
+            for i in (0, ncraft - 1):
+                c = orc.Craft(so, s.mu, ship.start, pos[i], vel[i], "Verner87", body_order=order if which == "permuted" else None)
+                assert c.step_to(t_end) == 0
+                ot, op, ov = c.knots()
+                for x in (b, tw):
+                    kt, kp, kv = x.knots(i)
+                    assert np.array_equal(kt, ot) and np.array_equal(kp, op) and np.array_equal(kv, ov), (ncraft, which, i)
+            knots[(ncraft, which)] = b.knots(0)
+        assert not np.array_equal(knots[(ncraft, "table")][1], knots[(ncraft, "permuted")][1])
+    b = gpu.SpacecraftBatch(eph, ship.start, pos[:3], vel[:3], "Verner87", max_knots=256)
+    b.set_body_order(order).set_body_order(None)
+    b.propagate(t_end)
+    assert np.array_equal(b.knots(0)[1], knots[(3, "table")][1])
+    for bad in (np.zeros(s.n, dtype=np.int32), np.arange(s.n, dtype=np.int32) + 1):
+        with pytest.raises(gpu.EphemerisError):
+            b.set_body_order(bad)
