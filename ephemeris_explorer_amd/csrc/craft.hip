@@ -714,7 +714,7 @@ struct eph_craft_batch {
     DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (a clone's: on first use)
     DevBuf<unsigned long long> queue;         // k_craft_queue's work queue (one counter)
     bool heterogeneous = false;               // the craft's dynamical time scales differ widely (craft_time_scales): queue form
-    DevBuf<int> body_order;                   // eph_craft_batch_set_body_order (empty: table order)
+    DevBuf<BodyEntry> bodies_ordered;         // eph_craft_batch_set_body_order: the ephemeris's table permuted (empty: table order)
     DevBuf<int> perm, slot_of;                // heterogeneous batches: lane / queue position -> craft by dynamical time, and back
     std::vector<int> h_slot;                  //   (craft_sort); the knot slabs' columns are lane positions
     // SpacecraftSolout events (optional)
@@ -1134,7 +1134,9 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
     CraftArgs a{};
     a.n_craft = b->n;
     a.n_bodies = b->eph->n_bodies;
-    a.bodies = b->eph->bodies.p; a.coeffs = b->eph->coeffs.p; a.ncoef = b->eph->ncoef.p;
+    a.bodies = b->bodies_ordered.p ? b->bodies_ordered.p : b->eph->bodies.p;
+    a.bodies_by_index = b->eph->bodies.p;
+    a.coeffs = b->eph->coeffs.p; a.ncoef = b->eph->ncoef.p;
     a.time = b->time.p; a.y = b->y.p; a.next_h = b->next_h.p; a.klast = b->klast.p; a.last_knot_t = b->last_knot.p;
     a.n_attempts = b->n_attempts.p; a.rk_i = b->rk_i.p; a.steps = b->steps.p;
     a.cur_seg = b->cur_seg.p; a.status = b->status.p; a.nknots = b->nknots.p;
@@ -1149,7 +1151,6 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
     a.step_limit = step_limit;
     a.queue = b->queue.p;
     a.perm = b->perm.p;
-    a.body_order = b->body_order.p;
     EPH_HIP(hipEventRecord(b->ev0, b->stream));
     int st = craft_launch(b->pv, b->stream, a, b->heterogeneous);
     if (st) return st;
@@ -1263,18 +1264,21 @@ int32_t eph_craft_batch_set_body_order(eph_craft_batch *b, const int32_t *order)
     if (!b) return EPH_ERR_BAD_ARGUMENT;
     EPH_HIP(hipSetDevice(b->device));
     EPH_HIP(hipStreamSynchronize(b->stream));
-    if (!order) { b->body_order.release(); return EPH_OK; }
+    if (!order) { b->bodies_ordered.release(); return EPH_OK; }
     const int n = b->eph->n_bodies;
-    std::vector<int> o((size_t)std::max(n, 1));
     std::vector<char> seen((size_t)std::max(n, 1), 0);
     for (int q = 0; q < n; ++q) {
         if (order[q] < 0 || order[q] >= n || seen[(size_t)order[q]]) return EPH_ERR_BAD_ARGUMENT;   // not a permutation
         seen[(size_t)order[q]] = 1;
-        o[(size_t)q] = order[q];
     }
+    // the sweep kernels walk a.bodies front to back: a permuted COPY of the ephemeris's table costs the kernels nothing (an index
+    // array read inside the body loop cost the thread-per-craft kernel 5 %: 35.0 against 33.4 ms)
+    std::vector<BodyEntry> table((size_t)std::max(n, 1)), perm((size_t)std::max(n, 1));
+    EPH_HIP(hipMemcpy(table.data(), b->eph->bodies.p, sizeof(BodyEntry) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int q = 0; q < n; ++q) perm[(size_t)q] = table[(size_t)order[q]];
     int st;
-    if ((st = b->body_order.alloc(o.size()))) return st;
-    EPH_HIP(hipMemcpy(b->body_order.p, o.data(), sizeof(int) * o.size(), hipMemcpyHostToDevice));
+    if ((st = b->bodies_ordered.alloc(perm.size()))) return st;
+    EPH_HIP(hipMemcpy(b->bodies_ordered.p, perm.data(), sizeof(BodyEntry) * perm.size(), hipMemcpyHostToDevice));
     return EPH_OK;
 }
 
@@ -1435,7 +1439,7 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
             (st = clone_buf(b->ntr, c->ntr, s)) || (st = clone_buf(b->nap, c->nap, s)) ||
             (st = clone_buf(b->ev_status, c->ev_status, s)) || (st = clone_buf(b->tr_body, c->tr_body, s)) ||
             (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)) ||
-            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = clone_buf(b->body_order, c->body_order, s)) || (st = c->queue.alloc(1)))
+            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = clone_buf(b->bodies_ordered, c->bodies_ordered, s)) || (st = c->queue.alloc(1)))
             return st;
         c->h_slot = b->h_slot;
         EPH_HIP(hipStreamSynchronize(s));

@@ -28,7 +28,8 @@ struct SegmentDev {           // Segment<DVec3, ReferenceFrame>
 struct CraftArgs {
     long long n_craft;
     int n_bodies;
-    const BodyEntry *bodies;
+    const BodyEntry *bodies;     // the table in the order Bodies::acceleration visits it (the ephemeris's own, or the batch's permuted copy)
+    const BodyEntry *bodies_by_index;   // the ephemeris's table: a burn's reference body is an index into THIS one
     const double *coeffs;     // [poly][8][3]
     const int *ncoef;
     // per craft (SoA)
@@ -48,7 +49,6 @@ struct CraftArgs {
     double t_end;
     unsigned step_limit;      // accepted steps this call may take per craft (0 = until t_end)
     unsigned long long *queue;   // k_craft_propagate's work queue: the next craft nobody has started (set by craft_launch)
-    const int *body_order;       // the order Bodies::acceleration visits the bodies in (null: table order); eph_craft_batch_set_body_order
     const int *perm;             // lane / queue position -> craft (null: identity). Heterogeneous batches: craft sorted by their
                                  // dynamical time at creation, so that the lanes of a wave carry craft of similar step counts
 };

@@ -130,13 +130,13 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     if (WAVE) {
         const int lane = threadIdx.x;
         for (int b0 = 0; b0 < a.n_bodies; b0 += kTile) {
-            const int b = b0 + lane;                  // position in the sum; the body there: a.body_order[b] (table order by default)
+            const int b = b0 + lane;
             V3 term = {0.0, 0.0, 0.0};
             bool located = true;
             if (b < a.n_bodies) {
-                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);   // (lb holds that body, k_craft_wave)
+                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);
                 else {
-                    const BodyEntry be = a.bodies[a.body_order ? a.body_order[b] : b];
+                    const BodyEntry be = a.bodies[b];
                     located = body_term(a, be, t, pos, term);
                 }
             }
@@ -169,9 +169,9 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             acc.z = lane_bcast(sum, 2);
         }
     } else {
-        for (int q = 0; q < a.n_bodies; ++q) {        // Bodies::acceleration: table order, or the caller's permutation of it
+        for (int b = 0; b < a.n_bodies; ++b) {        // Bodies::acceleration: the order of a.bodies (eph_craft_batch_set_body_order)
             // the body's table entry is the same for every lane: scalar loads through the constant address space
-            const int bu = __builtin_amdgcn_readfirstlane(a.body_order ? a.body_order[q] : q);
+            const int bu = __builtin_amdgcn_readfirstlane(b);
             const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
             BodyEntry be;
             be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
@@ -185,7 +185,7 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     if (sg.is_burn) {
         const V3 thrust = {sg.ax, sg.ay, sg.az};
         if (sg.ref >= 0) {                            // ReferenceFrame::Relative -> TNB::try_new(sv - ref.state_vector(t))
-            const BodyEntry be = a.bodies[sg.ref];
+            const BodyEntry be = a.bodies_by_index[sg.ref];
             long long idx;
             double tau;
             if (!spline_locate(be, t, idx, tau)) return false;
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
     }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
     LaneBody lb;
-    lb.be = a.bodies[lane < a.n_bodies ? (a.body_order ? a.body_order[lane] : lane) : 0];
+    lb.be = a.bodies[lane < a.n_bodies ? lane : 0];
     lb.r = rcp_refined(lb.be.interval);
     lb.b_ok = in_range_div(lb.be.interval);
     lb.idx = -1;
