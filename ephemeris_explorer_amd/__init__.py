@@ -973,7 +973,7 @@ def debug_div(a, b):
 
 
 def debug_wg_cycles():
-    """tuning hook: the eight debug counters the workgroup kernels leave (EPH_DEBUG_WG / EPH_DEBUG_SMALL)"""
+    """tuning hook: k_lm_small's eight tick counters (zeros unless the library was built with -DEPH_EXPERIMENTS=1)"""
     out = (C.c_int64 * 8)()
     _lib().eph_debug_wg_cycles.argtypes = [C.POINTER(C.c_int64)]
     _check(_lib().eph_debug_wg_cycles(out), "eph_debug_wg_cycles")

@@ -300,13 +300,13 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
                                const int64_t *burn_offset, const double *burn_start, const double *burn_end,
                                const double *burn_acc_xyz, const int32_t *burn_ref, int32_t max_knots,
                                eph_craft_batch **out);
-/* IncrementalPropagator::step_to for every craft: step() until solution.end() >= t_end (spacecraft.rs:598-615,
- * 691-693) or an error; per-craft outcomes via eph_craft_batch_status. Returns EPH_OK if the sweep ran. */
 /* The order in which the massive bodies' terms are added in a craft's acceleration (Bodies::acceleration iterates an EntityHashMap,
  * ephemeris_explorer/src/dynamics/spacecraft.rs:164-165,222-228: unspecified upstream). Default: the ephemeris table's (file) order,
  * which is what the library test's IndexMap gives (ephemeris/tests/spacecraft_propagation.rs:226-240). `order` = a permutation of
  * 0 .. n_bodies-1 (position in the sum -> body), NULL = back to table order; takes effect for the steps that follow. */
 int32_t eph_craft_batch_set_body_order(eph_craft_batch *b, const int32_t *order);
+/* IncrementalPropagator::step_to for every craft: step() until solution.end() >= t_end (spacecraft.rs:598-615,
+ * 691-693) or an error; per-craft outcomes via eph_craft_batch_status. Returns EPH_OK if the sweep ran. */
 int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end);
 /* IncrementalPropagator::step n_steps times for every craft (ephemeris/src/lib.rs:40-47, spacecraft.rs:598-615): each
  * craft takes exactly n_steps accepted steps (one knot each) unless it fails or its knot slab fills. */
@@ -461,8 +461,8 @@ int32_t eph_debug_quot(int64_t n, const double *x, const double *a, double *fast
  * exponent uniform over the guarded range; n is rounded up to a multiple of 2^20). *mismatches = operands whose two
  * results differ in any bit; *example_bits = the IEEE bits of one of them (0 when none). */
 int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, uint64_t *example_bits);
-/* Tuning hook (EPH_DEBUG_WG=3): s_memtime accounting of one workgroup of the force kernel: {pair wave work,
- * barrier wait, pair wave 0 work, wait, chain wave work, wait, tiles, 0}. */
+/* Tuning hook: zeros from the product library. A build with -DEPH_EXPERIMENTS=1 (scripts/build_exp.sh) returns the
+ * single-workgroup kernel's per-phase tick accounting of its last launch (EPH_DEBUG_SMALL=4). */
 int32_t eph_debug_wg_cycles(int64_t *out8);
 
 #ifdef __cplusplus

@@ -7,13 +7,12 @@
 #   TAG        output goes to gpurun_out/TAG/WHAT[_LIBNAME].log
 #   -l NAME    run once per experimental build ephemeris_explorer_amd/libephemeris_amd_exp_NAME.so (scripts/build_exp.sh NAME
 #              -DFLAG...; "product" = the product library). Default: product only.
-#   -e K=V     environment for every run (EPH_WG_LAYOUT, EPH_WG_BODIES, EPH_FORCE, EPH_DEBUG_WG, EPH_CRAFT_QUEUE, ...)
+#   -e K=V     environment for every run (EPH_WG_BODIES, EPH_FORCE, EPH_PAIR_VARIANT, EPH_CRAFT_SORT, EPH_CRAFT_QUEUE, ...)
 #   WHAT       sizes [N...]      steady QT12 step per size            (scripts/time_sizes.py)
 #              path N STEPS P    one size, path P (0 exact, 4 fast..) (scripts/time_path.py)
 #              ab N              minimal ctypes timing, any ABI       (scripts/ab_step.py <library>)
 #              small             k_lm_small: single, gangs, configs[1] (scripts/time_small.py)
 #              clock-small       shader clock + per-phase ticks       (scripts/clock_small.py; -l smallacct, -e EPH_DEBUG_SMALL=4)
-#              wg-cycles N       per-wave cycle accounting            (scripts/wg_cycles.py;  -e EPH_DEBUG_WG=4)
 #              craft ARGS...     bench.py --workload craft ARGS       (--population mixed --craft 524288 --craft-days 2 --steps 2)
 #              clocks CMD...     CMD under rocm-smi clock / power sampling (scripts/sample_clocks.sh)
 #              pytest ARGS...    python -m pytest ARGS
@@ -47,7 +46,6 @@ for lib in "${LIBS[@]}"; do
     ab) for n in "${@:-4096}"; do run python scripts/ab_step.py "$path"; done;;
     small) run python scripts/time_small.py;;
     clock-small) run python scripts/clock_small.py;;
-    wg-cycles) run python scripts/wg_cycles.py "$@";;
     craft) run python bench.py --workload craft --no-cpu-baseline "$@";;
     clocks) run scripts/sample_clocks.sh "$OUT/clocks_$lib.csv" "$@";;
     pytest) run python -m pytest "$@";;

@@ -44,14 +44,11 @@ def emit(d, us, fetch):
     print(json.dumps(d), flush=True)
 
 
-for layout, tile, pmc in ((0, 64, False), (1, 64, True), (2, 64, False), (3, 128, True), (4, 128, False), (5, 128, True), (6, 128, False)):
-    if not lib and layout != 5:
-        continue
-    us, f = run({"EPH_WG_LAYOUT": str(layout)}, 0, pmc)
-    emit({"path": "ordered", "kernel": f"k_lm_step_wg<12,{layout},16>", "sources_per_barrier": tile, "bodies_per_workgroup": 16}, us, f)
+us, f = run({}, 0, True)        # (the other role layouts of rounds 2-3 left the source in round 4: profiles/r03_tile_sweep.jsonl)
+emit({"path": "ordered", "kernel": "k_lm_step_wg<12,16>", "sources_per_barrier": 128, "bodies_per_workgroup": 16}, us, f)
 for wb in (8, 4):
     us, f = run({"EPH_WG_BODIES": str(wb)}, 0, True)
-    emit({"path": "ordered", "kernel": f"k_lm_step_wg<12,5,{wb}>", "sources_per_barrier": 128 if wb == 8 else 64, "bodies_per_workgroup": wb}, us, f)
+    emit({"path": "ordered", "kernel": f"k_lm_step_wg<12,{wb}>", "sources_per_barrier": 128 if wb == 8 else 64, "bodies_per_workgroup": wb}, us, f)
 for bpw in (1, 2, 4, 8):
     us, f = run({"EPH_FORCE": "wave", "EPH_BPW": str(bpw)}, 0, bpw == 4)
     emit({"path": "ordered", "kernel": f"k_lm_step<{bpw},12>", "sources_per_tile": 64, "bodies_per_wave": bpw}, us, f)

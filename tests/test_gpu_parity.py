@@ -333,7 +333,8 @@ def test_workgroup_kernel_at_every_tile_count(gpu):
     targets, 8 up to 2048, 16 above -- all three sizes occur below); its barrier schedule (single
     tiles first, then pairs of tiles, six LDS buffers) is exercised here at the tile counts it never sees by default -- 2, 3,
     4, 5, 7, 17 tiles, ragged last tiles -- by forcing it (EPH_FORCE=wg, read once per process: hence the subprocess),
-    for every role layout, accelerations and a few fused steps against the oracle."""
+    at the size-dependent workgroup choice and with each workgroup size forced at EVERY n, accelerations and a few fused
+    steps against the oracle."""
     import os
     import subprocess
     import sys
@@ -359,13 +360,12 @@ for n in (130, 300, 1030, 2100):
     assert same(g.state()[0], o.state()[0]) and same(g.state()[1], o.state()[1]), ("steps", n)
 print("ok")
 '''
-    cases = [(layout, None) for layout in "0123456"] + [("5", "4"), ("5", "8"), ("5", "16")]   # the last three: one size at EVERY n
-    for layout, bodies in cases:
-        env = dict(os.environ, EPH_FORCE="wg", EPH_WG_LAYOUT=layout)
+    for bodies in (None, "4", "8", "16"):
+        env = dict(os.environ, EPH_FORCE="wg")
         if bodies:
             env["EPH_WG_BODIES"] = bodies
         r = subprocess.run([sys.executable, "-c", script, str(ROOT)], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (layout, bodies, r.stdout[-1000:], r.stderr[-3000:])
+        assert r.returncode == 0 and "ok" in r.stdout, (bodies, r.stdout[-1000:], r.stderr[-3000:])
 
 
 def test_kernel_choice_boundaries(gpu):
