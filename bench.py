@@ -648,7 +648,7 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("k_fast_partial_f32 + k_fast_finish<12>" if args.path == "f32-pairs" else
                                     "k_fast_partial + k_fast_finish<12>" if fast else
-                                    "k_lm_step_wg<12,LAYOUT>" if nt >= 1024 else "k_lm_step<BPW,12>"),
+                                    f"k_lm_step_wg<12,{16 if nt > 2048 else 8 if nt > 1024 else 4}>" if nt > 512 else "k_lm_step<BPW,12>"),
                          "launch_us": launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * nt,
                          # what actually binds the kernel: f64 VALU issue (`bound` stays "hbm" because the contract's roofline

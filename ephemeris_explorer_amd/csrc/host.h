@@ -181,7 +181,7 @@ public:
     const double *positions_soa() { return Yslot(is_multistep_ ? cur_ : 0); }
     int npad() const { return npad_; }
     void enable_timing(bool on) { timing_ = on; }
-    double kernel_ms() const { return kernel_ms_; }
+    double kernel_ms() { (void)resolve_timing(); return kernel_ms_; }
     uint64_t kernel_launches() const { return kernel_launches_; }
     // how many of the next k advance() calls would succeed before BoundReached / StepSizeUnderflow
     int64_t steps_available(int64_t k, int *status_after) const;
@@ -208,6 +208,13 @@ private:
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    // enable_timing: every batch of steps is bracketed by a pair of events that is read LATER (kernel_ms(), or when 1024 pairs
+    // wait): waiting for the closing event inside advance() made the call synchronous and cost a 20-step block 2 % of its time
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending_, ev_free_;
+    int resolve_timing();
+    // the last fused step of a batch left the NEXT step's predicted positions in P_[pp_ ^ 1] and in the ring slot the next step
+    // takes (the oldest level's, dead by then): the next batch starts with its force evaluation instead of a predictor launch
+    bool predicted_ = false;
     int n_ = 0, npad_ = 0, L_ = 1;
     int lo_ = 0, hi_ = 0, slice_ = 0;         // owned targets [lo_, hi_); slice_ = npad_ / world when sharded
     std::shared_ptr<Exchange> xch_;

@@ -21,6 +21,8 @@ NBodyIntegration::~NBodyIntegration() {
         (void)hipStreamSynchronize(stream_);
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
+        for (auto *v : {&ev_pending_, &ev_free_})
+            for (auto &e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (gang_ev_) (void)hipEventDestroy(gang_ev_);
         if (gang_copy_ev_) { (void)hipEventSynchronize(gang_copy_ev_); (void)hipEventDestroy(gang_copy_ev_); }
         if (gang_host_) (void)hipHostFree(gang_host_);
@@ -108,7 +110,7 @@ int NBodyIntegration::clone(std::unique_ptr<NBodyIntegration> *out) {
     o->is_multistep_ = is_multistep_; o->lm_ = lm_; o->rk_ = rk_; o->substeps_ = substeps_;
     o->h_ = h_; o->h_sub_ = h_sub_; o->time_ = time_; o->bound_ = bound_; o->pv_ = pv_;
     o->starter_i_ = starter_i_; o->lm_i_ = lm_i_; o->evals_ = evals_;
-    o->cur_ = cur_; o->pp_ = pp_; o->path_ = path_;
+    o->cur_ = cur_; o->pp_ = pp_; o->path_ = path_; o->predicted_ = predicted_;
     o->lo_ = lo_; o->hi_ = hi_; o->slice_ = slice_; o->xch_ = xch_;   // a clone of a sharded handle shares the ranks
     EPH_HIP(hipStreamCreateWithFlags(&o->stream_, hipStreamNonBlocking));
     EPH_HIP(hipEventCreate(&o->ev0_));
@@ -231,6 +233,18 @@ int64_t NBodyIntegration::steps_available(int64_t k, int *status_after) const {
     return s;
 }
 
+int NBodyIntegration::resolve_timing() {
+    for (auto &e : ev_pending_) {
+        float ms = 0;
+        EPH_HIP(hipEventSynchronize(e.second));
+        EPH_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        kernel_ms_ += ms;
+    }
+    ev_free_.insert(ev_free_.end(), ev_pending_.begin(), ev_pending_.end());
+    ev_pending_.clear();
+    return EPH_OK;
+}
+
 // k x ELM2::advance   second_order/mod.rs:90-131
 int NBodyIntegration::lm_batch(int64_t k) {
     LmArgs a{};
@@ -255,7 +269,14 @@ int NBodyIntegration::lm_batch(int64_t k) {
     const bool persistent = n_ <= kSmallN && path_ != 1 && path_ != 3 && !fast;
     if (path_ == 2 && n_ > kSmallN) return EPH_ERR_UNSUPPORTED;
     if (collect_ && !persistent) return EPH_ERR_UNSUPPORTED;           // (advance_many checks gang_ready first)
-    if (timing_ && !collect_) EPH_HIP(hipEventRecord(ev0_, stream_));
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (timing_ && !collect_) {
+        if (ev_pending_.size() >= 1024 && (st = resolve_timing())) return st;
+        if (!ev_free_.empty()) { ev = ev_free_.back(); ev_free_.pop_back(); }
+        else { EPH_HIP(hipEventCreate(&ev.first)); EPH_HIP(hipEventCreate(&ev.second)); }
+        ev_pending_.push_back(ev);
+        EPH_HIP(hipEventRecord(ev.first, stream_));
+    }
     if (persistent) {
         a.cur = cur_;
         a.pos_cur = P_[pp_].p;
@@ -268,31 +289,32 @@ int NBodyIntegration::lm_batch(int64_t k) {
         a.cur = cur_;
         a.pos_cur = P_[pp_].p;
         a.pos_next = P_[pp_ ^ 1].p;
-        if ((st = launch_lm_predict(stream_, a))) return st;
-        if ((st = gather_packed(a.pos_next))) return st;
+        // a handle that can neither take the single-workgroup kernels nor exchange positions leaves the prediction of the step
+        // after the batch behind (host.h predicted_): one launch and one launch boundary less per call
+        const bool leave_prediction = n_ > kSmallN && !sharded();
+        if (!predicted_) {
+            if ((st = launch_lm_predict(stream_, a))) return st;
+            if ((st = gather_packed(a.pos_next))) return st;
+        }
+        predicted_ = false;
         for (int64_t s = 1; s <= k; ++s) {
             pp_ ^= 1;
             cur_ = (cur_ + L_ - 1) % L_;
             a.cur = cur_;
             a.pos_cur = P_[pp_].p;
             a.pos_next = P_[pp_ ^ 1].p;
-            a.do_predict = s < k;
+            a.do_predict = s < k || leave_prediction;
             a.step = (uint32_t)s;
             if ((st = fast ? launch_lm_step_fast(pv_, stream_, a, fast_partial_.p, path_ == EPH_PATH_FAST_RSQ,
                                                  path_ == EPH_PATH_F32_PAIRS ? posf_.p : nullptr)
                            : launch_lm_step(pv_, stream_, a)))
                 return st;
-            if (a.do_predict && (st = gather_packed(a.pos_next))) return st;
+            if (s < k && (st = gather_packed(a.pos_next))) return st;
         }
+        predicted_ = leave_prediction;
         if (timing_) kernel_launches_ += (uint64_t)k;
     }
-    if (timing_ && !collect_) {
-        EPH_HIP(hipEventRecord(ev1_, stream_));
-        EPH_HIP(hipEventSynchronize(ev1_));
-        float ms = 0;
-        EPH_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
-        kernel_ms_ += ms;
-    }
+    if (ev.second) EPH_HIP(hipEventRecord(ev.second, stream_));
     if (collect_) deferred_time_steps_ += k;              // advance_many replays them once the gang is launched
     else for (int64_t s = 0; s < k; ++s) time_ = time_ + h_;   // problem.time = problem.time + h, per step (the launch is already queued)
     lm_i_ += (uint32_t)k;
