@@ -33,6 +33,7 @@ BYTES_PER_BODY_STEP = 680.0            # 12 y + 12 a levels (576) + mu (8) + own
 FLOP_PER_INTERACTION = 20.0
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_VECTOR_PEAK_TFLOPS = 78.6         # MI355X vector FP64 (no MFMA on this path)
+FP32_VECTOR_PEAK_TFLOPS = 157.3        # MI355X vector FP32 (packed v_pk_fma_f32): the roof of --path f32-pairs' pair arithmetic
 
 
 def cpu_baseline(pos, vel, mu, steps):
@@ -299,7 +300,7 @@ def transport_preflight(dist, world, rank, backend_is_nccl, record):
         except Exception as e:
             status = f"{type(e).__name__}: {e}"[:200]
         every = [None] * world
-        dist.all_gather_object(every, status)
+        dist.all_gather_object(every, status, group=host_group)        # (the gloo group under nccl: no device tensors for a string)
         bad = [f"rank {r}: {st}" for r, st in enumerate(every) if st != "ok"]
         record[transport] = "ok" if not bad else "; ".join(bad)[:400]
         if forms is not None:
@@ -661,6 +662,14 @@ def main():
                          "note": "working set (912 B/body) is L2-resident; the path is f64-VALU bound, see roofline.fp64"
                                  + ("; launch_us includes the per-step all-gather" if sharded else "")},
         }
+        if args.path == "f32-pairs":
+            # the pair arithmetic of this opt-in path is binary32: the same flop count against the packed-f32 vector roof
+            out["roofline"]["binding"] = "fp32_valu"
+            out["roofline"]["fp32"] = {"achieved": flops / launch_s / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": flops / launch_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS, "flop_per_launch": flops,
+                                       "count": "the exact path's 20 (N - 1) + 231 flop per body-step (TFLOP/s-EQUIVALENT: the f32 "
+                                                "loop issues 18 flop per interaction, v_rsq_f32 counted as one)"}
+            out["roofline"]["note"] = "working set is L2-resident; the pair loop is f32-VALU bound (v_pk_* + v_rsq_f32), see roofline.fp32"
         out["fp64"] = dict(out["roofline"]["fp64"], bound="fp64_valu")       # (round 3's top-level key, kept for readers of older lines)
         if valu_insts:
             # issue-slot view of the same launch: wave64 VALU instructions (SQ_INSTS_VALU of the committed profile) x 64

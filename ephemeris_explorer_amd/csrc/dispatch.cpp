@@ -112,11 +112,11 @@ int launch_lm_small_many(int pv, hipStream_t s, const LmArgs *argv_dev, int coun
     if (count <= 0 || nsteps <= 0) return EPH_OK;
     return t->lm_small_many(s, argv_dev, count, L, nsteps);
 }
-// slices of the fast path: enough waves for two per SIMD (2048), a multiple of the workgroup's 4, at most 64
+// slices of the fast path: enough waves for two per SIMD (2048), a multiple of the workgroup's 4, at least 8, at most 64
 int fast_slices(int npad) {
     static const int forced = env_int("EPH_FAST_SLICES", 0);
     int S = forced > 0 ? forced : 2048 / (npad / 64);
-    S = std::max(4, std::min(64, S));
+    S = std::max(8, std::min(64, S));            // (8 rather than 4 slices at 65 536 bodies, eight waves per SIMD: 1.17 -> 1.13 ms on the f32 path)
     return (S + 3) / 4 * 4;
 }
 int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf) {

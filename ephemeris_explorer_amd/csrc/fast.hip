@@ -118,70 +118,66 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
 
 // ------------------------------------------------------------------------------------------------------
 // OPT-IN MIXED PRECISION (eph_nbody_set_path(.., EPH_PATH_F32_PAIRS); BASELINE.json configs[4] "65 536-body f32 system"):
-// the pair arithmetic in binary32 -- differences of positions rounded to f32, n2 by fma, v_rsq_f32 + one Newton step,
-// ((mu y) y) y, the three products -- two sources at a time in the packed f32 instructions (v_pk_add / v_pk_mul /
-// v_pk_fma_f32: the only VALU form that runs at twice the f64 rate), the contributions of FOUR consecutive sources summed in
-// binary32, converted and ACCUMULATED in f64 in the fast path's slice order; Cowell, predictor and the whole integrator state
-// stay f64 (a twelfth-order multistep recurrence cannot hold its state in binary32). The reference has no
-// f32 path (ephemeris/src/propagators/nbody.rs:13,19): no parity claim, never the default, for large systems only.
-// Supported magnitudes: positions and mu must be representable in binary32 (|x| < 3.4e38, mu >= 1.2e-38 or 0); separations from
-// 0 (two bodies coinciding after rounding: their mutual term is dropped) to 1.8e19 length units (beyond: the term is ~0) --
-// the reference's km and N-body units are far inside, SI metres at heliocentric distances (1e12-1e13) still are.
+// the pair arithmetic in binary32 -- differences of positions rounded to f32, n2 by fma, v_rsq_f32 (1 ulp; a Newton step on top
+// bought nothing measurable: the error of this path is the rounding of the POSITIONS to binary32, 1.3e-6 of the accelerations
+// with and without it), ((mu y) y) y -- two sources at a time in the packed f32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32:
+// the only VALU form that runs at twice the f64 rate), the contributions of 32 consecutive sources accumulated by packed fma
+// in binary32 (even sources in one half, odd ones in the other), then converted and ACCUMULATED in f64 in the fast path's slice
+// order; Cowell, predictor and the whole integrator state stay f64 (a twelfth-order multistep recurrence cannot hold its state in
+// binary32). The reference has no f32 path (ephemeris/src/propagators/nbody.rs:13,19): no parity claim,
+// never the default, for large systems only.
+// Supported magnitudes: positions and mu must be representable in binary32 (|x| < 3.4e38, mu >= 1.2e-38 or 0). Two bodies that
+// coincide after rounding to binary32 (n2 = 0, y = inf): mu y^3 is clamped to the largest finite value and multiplies a zero
+// separation -- their mutual term is dropped, and so is a body's term with itself (no source is masked); a massless source there
+// (0 * inf = NaN) leaves the clamp as 0 (v_med3_f32 returns the minimum of the other two for a NaN). Separations beyond 1.8e19 length units (n2 = inf, y = 0): the term is 0. The
+// reference's km and N-body units are far inside, SI metres at heliocentric distances (1e12-1e13) still are.
+// Layout of the binary32 copy: sources in PAIRS, {x_a, x_b, y_a, y_b, z_a, z_b, mu_a, mu_b} -- the operand pairs of the packed
+// instructions arrive in consecutive scalar registers straight from s_load_dwordx16 (the AoS form needed 13 s_mov per 4 sources).
 // ------------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
-struct BodyF { float x, y, z, mu; };
-__global__ void __launch_bounds__(256) k_pos_to_f32(int n, int npad, const Body4 *__restrict__ pos, BodyF *__restrict__ out) {
+#ifndef EPH_F32_GROUP
+#define EPH_F32_GROUP 32
+#endif
+constexpr int kF32Group = EPH_F32_GROUP;               // sources per conversion to f64 (slices are multiples of it)
+__global__ void __launch_bounds__(256) k_pos_to_f32(int n, int npad, const Body4 *__restrict__ pos, float *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
-    BodyF b{0.f, 0.f, 0.f, 0.f};
-    if (i < n) { const Body4 p = pos[i]; b = BodyF{(float)p.x, (float)p.y, (float)p.z, (float)p.mu}; }
-    out[i] = b;
+    float x = 0.f, y = 0.f, z = 0.f, mu = 0.f;
+    if (i < n) { const Body4 p = pos[i]; x = (float)p.x; y = (float)p.y; z = (float)p.z; mu = (float)p.mu; }
+    float *o = out + (size_t)(i >> 1) * 8 + (i & 1);
+    o[0] = x; o[2] = y; o[4] = z; o[6] = mu;
 }
-template <bool MASKED>
-__device__ __forceinline__ void f32_slice(const __attribute__((address_space(4))) BodyF *src, int j0, int j1, int n, int i,
+__device__ __forceinline__ void f32_slice(const __attribute__((address_space(4))) float *src, int j0, int j1,
                                           float xi, float yi, float zi, double &ax, double &ay, double &az) {
-    constexpr int U = 4;                               // sources per iteration: two packed pairs
     const v2f x2{xi, xi}, y2{yi, yi}, z2{zi, zi};
-    for (int j = j0; j < j1; j += U) {                 // j1 - j0 is a multiple of U; sources >= n are padding
-        BodyF p[U];
+    const auto *pg = src + (size_t)j0 * 4;
+    for (int jg = j0; jg < j1; jg += kF32Group, pg += 4 * kF32Group) {   // j1 - j0 is a multiple of kF32Group
+        v2f sx{0.f, 0.f}, sy{0.f, 0.f}, sz{0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < U; ++u) { p[u].x = src[j + u].x; p[u].y = src[j + u].y; p[u].z = src[j + u].z; p[u].mu = src[j + u].mu; }
-        v2f cx[2], cy[2], cz[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const BodyF &pa = p[2 * h], &pb = p[2 * h + 1];
-            const v2f dx = v2f{pa.x, pb.x} - x2, dy = v2f{pa.y, pb.y} - y2, dz = v2f{pa.z, pb.z} - z2;
+        for (int u = 0; u < kF32Group; u += 2) {
+            const auto *p = pg + 4 * u;                // the pair (jg + u, jg + u + 1)
+            const v2f dx = v2f{p[0], p[1]} - x2, dy = v2f{p[2], p[3]} - y2, dz = v2f{p[4], p[5]} - z2;
             v2f n2 = dx * dx;
             n2 = __builtin_elementwise_fma(dy, dy, n2);
             n2 = __builtin_elementwise_fma(dz, dz, n2);
-            // two bodies whose positions coincide after rounding to binary32 (n2 = 0) and separations beyond 1.8e19 length units
-            // (n2 = inf) would turn the sum into NaN: clamped (one v_med3_f32 each), their terms come out as 0 resp. negligible
-            n2 = v2f{__builtin_amdgcn_fmed3f(n2.x, 1.0e-37f, 3.0e38f), __builtin_amdgcn_fmed3f(n2.y, 1.0e-37f, 3.0e38f)};
-            v2f y{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)};
-            const v2f hn = n2 * v2f{0.5f, 0.5f};
-            const v2f r = __builtin_elementwise_fma(-(hn * y), y, v2f{0.5f, 0.5f});   // 0.5 (1 - n2 y^2)
-            y = __builtin_elementwise_fma(y, r, y);
+            const v2f y{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)};
             // (mu y) y y, not mu (y y y): y^3 alone leaves binary32's normal range for separations above 2e12 length units
-            const v2f sc = ((v2f{pa.mu, pb.mu} * y) * y) * y;
-            cx[h] = dx * sc; cy[h] = dy * sc; cz[h] = dz * sc;
+            v2f sc = ((v2f{p[6], p[7]} * y) * y) * y;
+            // No source is masked: the body itself and whatever coincides with it have d = 0, n2 = 0, y = inf -- mu y^3 = inf is
+            // clamped to a finite value and multiplies the zero separation, a massless one's 0 * inf = NaN comes out of the
+            // clamp as 0; padding rows (position 0, mu 0) contribute 0 * y^3 = 0, or that NaN when the body sits at the origin.
+            sc = v2f{__builtin_amdgcn_fmed3f(sc.x, 0.0f, 3.0e38f), __builtin_amdgcn_fmed3f(sc.y, 0.0f, 3.0e38f)};
+            sx = __builtin_elementwise_fma(dx, sc, sx);
+            sy = __builtin_elementwise_fma(dy, sc, sy);
+            sz = __builtin_elementwise_fma(dz, sc, sz);
         }
-        if constexpr (MASKED) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if ((j + u == i) || (j + u >= n)) {    // the body itself (its clamped term is not a source); padding rows
-                    cx[u >> 1][u & 1] = 0.0f; cy[u >> 1][u & 1] = 0.0f; cz[u >> 1][u & 1] = 0.0f;
-                }
-            }
-        }
-        // the four contributions summed in binary32 (their own rounding is 2^-24 of each term, as is the sum's), ONE conversion and
-        // one f64 addition per component and four sources: the f64 side was a third of the loop's issue cycles (6 cvt + 6 adds per two)
-        const v2f sx = cx[0] + cx[1], sy = cy[0] + cy[1], sz = cz[0] + cz[1];
+        // one conversion and one f64 addition per component and group (per four sources: the f64 side was a fifth of the loop)
         ax = ax + (double)(sx.x + sx.y);
         ay = ay + (double)(sy.x + sy.y);
         az = az + (double)(sz.x + sz.y);
     }
 }
-__global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int npad, const BodyF *__restrict__ posf, int S,
+__global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int npad, const float *__restrict__ posf, int S,
                                                                       int slice_len, double *__restrict__ partial) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,14 +186,12 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int
     const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
     const int i = block * 64 + lane;
     const int ic = min(i, n - 1);
-    const auto *src = (const __attribute__((address_space(4))) BodyF *)(unsigned long long)posf;
-    const float xi = posf[ic].x, yi = posf[ic].y, zi = posf[ic].z;
+    const auto *src = (const __attribute__((address_space(4))) float *)(unsigned long long)posf;
+    const float *own = posf + (size_t)(ic >> 1) * 8 + (ic & 1);
+    const float xi = own[0], yi = own[2], zi = own[4];
     const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
     double ax = 0.0, ay = 0.0, az = 0.0;
-    if (j0 < j1) {
-        if ((j0 < block * 64 + 64 && j1 > block * 64) || j1 > n) f32_slice<true>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
-        else f32_slice<false>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
-    }
+    if (j0 < j1) f32_slice(src, j0, j1, xi, yi, zi, ax, ay, az);
     double *pp = partial + (size_t)slice * 3 * npad + i;
     pp[0] = ax;
     pp[(size_t)npad] = ay;
@@ -252,13 +246,12 @@ __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, cons
 
 int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unroll, bool approx, float *posf) {
     int slice_len = (a.npad + S - 1) / S;
-    const int un = approx ? 4 : unroll;
+    const int un = posf ? kF32Group : approx ? 4 : unroll;
     slice_len = (slice_len + un - 1) / un * un;
     const dim3 pgrid((unsigned)(a.npad / 64 * (S / kFastWaves))), pblock(64 * kFastWaves);
     if (posf) {                                                         // EPH_PATH_F32_PAIRS
-        BodyF *pf = reinterpret_cast<BodyF *>(posf);
-        hipLaunchKernelGGL(k_pos_to_f32, dim3((unsigned)((a.npad + 255) / 256)), dim3(256), 0, s, a.n, a.npad, a.pos_cur, pf);
-        hipLaunchKernelGGL(k_fast_partial_f32, pgrid, pblock, 0, s, a.n, a.npad, (const BodyF *)pf, S, slice_len, partial);
+        hipLaunchKernelGGL(k_pos_to_f32, dim3((unsigned)((a.npad + 255) / 256)), dim3(256), 0, s, a.n, a.npad, a.pos_cur, posf);
+        hipLaunchKernelGGL(k_fast_partial_f32, pgrid, pblock, 0, s, a.n, a.npad, (const float *)posf, S, slice_len, partial);
     } else if (approx)
         hipLaunchKernelGGL((k_fast_partial<4, true>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     else if (unroll == 8 && a.npad % 8 == 0)

@@ -29,9 +29,12 @@ size_t pool_cap(int device) {
     static const long long forced = [] { const char *e = getenv("EPH_POOL_MAX_MB"); return e ? atoll(e) : -1LL; }();
     if (forced >= 0) return (size_t)forced << 20;
     size_t free_b = 0, total = 0;
-    (void)device;
-    if (hipMemGetInfo(&free_b, &total) != hipSuccess) return 0;
-    return total / 4;
+    int current = device;
+    (void)hipGetDevice(&current);
+    if (device != current) (void)hipSetDevice(device);
+    const hipError_t e = hipMemGetInfo(&free_b, &total);
+    if (device != current) (void)hipSetDevice(current);
+    return e == hipSuccess ? total / 4 : 0;
 }
 }  // namespace
 
@@ -65,10 +68,13 @@ void dev_free(void *p, size_t bytes) {
     if (!p) return;
     int device = 0;
     if (bytes >= kPoolMinBytes && hipGetDevice(&device) == hipSuccess) {
+        const int current = device;
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, p) == hipSuccess) device = attr.device;
-        // what hipFree would have done before handing the block on: nothing may still be using it
+        // what hipFree would have done before handing the block on: nothing on ITS device may still be using it
+        if (device != current) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
+        if (device != current) (void)hipSetDevice(current);
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (g_pool_bytes + bytes <= pool_cap(device)) {
             g_pool[{device, bytes}].push_back(p);

@@ -152,3 +152,30 @@ def test_f32_pairs_path(gpu, n):
     rel = np.abs(am - ae).max() / np.abs(ae).max()
     assert 1e-9 < rel < 2e-5, rel                      # binary32 pair terms: ~6e-8 each, a few close pairs dominate
     assert 0.0 < np.abs(pm - pe).max() < 1e-6
+
+
+def test_f32_pairs_bodies_coinciding_in_binary32(gpu):
+    """Distinct bodies whose positions round to the same binary32 values (n2 = 0 in the f32 pair arithmetic, y = inf): a massive
+    partner's mu y^3 = inf is clamped and multiplies a zero separation, a massless one's 0 * inf = NaN leaves the clamp as 0 --
+    the mutual term is dropped instead of turning both sums into NaN. Partners sit in different 64-body blocks, so the unmasked
+    loop sees them; their masses are negligible and their velocities equal, so the exact path (start-up, and the comparison)
+    keeps them together."""
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(1000)
+    pairs = [(8 + k, 700 + k) for k in range(6)]
+    for k, (a, b) in enumerate(pairs):
+        pos[b] = pos[a] + 1e-9
+        vel[b] = vel[a]
+        mu[a] = 1e-30
+        mu[b] = 0.0 if k % 2 else 1e-30
+    runs = []
+    for path in (0, 6):
+        g = gpu.NBodyIntegration(pos, vel, mu, 0.0, H)
+        g.set_path(path)
+        g.advance(12 + 3)
+        runs.append((g.acc(), g.state()[0]))
+    (ae, pe), (am, pm) = runs
+    together = [np.array_equal(pm[a].astype(np.float32), pm[b].astype(np.float32)) for a, b in pairs]
+    assert sum(together) >= 3, together               # (a pair can straddle a rounding boundary: 1e-9 against an ulp of 6e-8)
+    assert np.isfinite(am).all() and np.isfinite(pm).all()
+    assert np.abs(am - ae).max() / np.abs(ae).max() < 2e-5
