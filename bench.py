@@ -670,8 +670,10 @@ def main():
                                        "count": "the exact path's 20 (N - 1) + 231 flop per body-step (TFLOP/s-EQUIVALENT: the f32 "
                                                 "loop issues 18 flop per interaction, v_rsq_f32 counted as one)"}
             out["roofline"]["note"] = "working set is L2-resident; the pair loop is f32-VALU bound (v_pk_* + v_rsq_f32), see roofline.fp32"
-        out["fp64"] = dict(out["roofline"]["fp64"], bound="fp64_valu")       # (round 3's top-level key, kept for readers of older lines)
-        if valu_insts:
+            del out["roofline"]["fp64"]                    # (an f64 figure would compare binary32 arithmetic with the f64 roof)
+        else:
+            out["fp64"] = dict(out["roofline"]["fp64"], bound="fp64_valu")   # (round 3's top-level key, kept for readers of older lines)
+        if valu_insts and "fp64" in out["roofline"]:
             # issue-slot view of the same launch: wave64 VALU instructions (SQ_INSTS_VALU of the committed profile) x 64
             # lanes / live launch time, against 256 CU x 4 SIMD x 16 f64 lanes per clock at 2.4 GHz
             lane_ops = valu_insts * 64.0 / launch_s
