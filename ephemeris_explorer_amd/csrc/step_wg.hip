@@ -41,6 +41,18 @@
 #define EPH_WG_ABLATE 0
 #endif
 #define WG_LOOP_BARRIER() do { if constexpr (!(EPH_WG_ABLATE & 2)) __syncthreads(); } while (0)
+// PREPARED, NOT MEASURED (-DEPH_EXPERIMENTS=1 -DEPH_WG_DIAG_PATCH=1): the interval that holds the workgroup's own tile takes the
+// IEEE form for BOTH of its tiles on every pair wave (n2 = 0 on the self lanes fails the range test of the whole wave): about 1.8 x
+// the instructions for one interval of 33, up to 0.5 us per step at N = 4096 if the pair side is the longer one there. With the
+// switch the self lanes get in-range operands instead (n2 = 1; their contribution is read and discarded by chain_masked) and the
+// interval stays on the seeded sequences. Round 2 measured the same idea on the barrier-per-tile kernel (40.1 vs 40.0 us, no
+// gain): to be re-measured on this one (scripts/experiment.sh TAG -l product -l diagpatch sizes 2048 4096, and
+// EPH_AMD_LIBRARY=...exp_diagpatch.so pytest tests/test_gpu_parity.py tests/test_gpu_horizon.py for the bits).
+#if EPH_EXPERIMENTS && defined(EPH_WG_DIAG_PATCH)
+#define EPH_WG_DIAG_PATCH_ON 1
+#else
+#define EPH_WG_DIAG_PATCH_ON 0
+#endif
 
 namespace eph {
 namespace EPH_PV_NS {
@@ -119,13 +131,17 @@ __device__ __forceinline__ void wg_pair_wave(PosPtr pos, int n, int i0, int b0, 
 template <int NB>
 __device__ __forceinline__ void wg_pair_tile2(const double (&xi)[NB], const double (&yi)[NB], const double (&zi)[NB],
                                               const Body4 &pa, const Body4 &pb, bool ieee, double *tile_a, double *tile_b,
-                                              int b0, int lane) {
+                                              int b0, int lane, int self_a = -64, int self_b = -64) {
     PairPre pre[2 * NB];
     unsigned worst = ieee ? kRangeSpan : max(mu_key(pa.mu), mu_key(pb.mu)), low = ~0u;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         pre[b] = pair_pre(xi[b], yi[b], zi[b], pa);
         pre[NB + b] = pair_pre(xi[b], yi[b], zi[b], pb);
+        if constexpr (EPH_WG_DIAG_PATCH_ON) {          // self_x: the lane that holds body b0 as a source of tile x (far off: none)
+            if (lane == self_a + b) { pre[b].n2 = 1.0; pre[b].lo = 0x3ff00000u; }
+            if (lane == self_b + b) { pre[NB + b].n2 = 1.0; pre[NB + b].lo = 0x3ff00000u; }
+        }
         worst = max(worst, max(range_key(pre[b].n2), range_key(pre[NB + b].n2)));
         low = min(low, min(pre[b].lo, pre[NB + b].lo));
     }
@@ -203,6 +219,14 @@ __device__ __forceinline__ void wg_pair_wave_big(PosPtr pos, int n, int i0, int 
         const int t = big_start(K);
         if (t >= tiles || EPH_WG_SIDE == 2) return;
         double *ta = C + (t % kWgTileBufs) * wbuf, *tb = C + ((t + 1) % kWgTileBufs) * wbuf;
+        if constexpr (EPH_WG_DIAG_PATCH_ON) {
+            if (K >= 2 && t + 1 < tiles) {
+                const int own = i0 + b0;                // (bodies beyond n are clamped copies of body n - 1: never diagonal lanes)
+                wg_pair_tile2<NB>(xi, yi, zi, pa, pb, false, ta, tb, b0, lane, tdiag == t ? own - t * kTile : -64,
+                                  tdiag == t + 1 ? own - (t + 1) * kTile : -64);
+                return;
+            }
+        }
         if (K >= 2 && t + 1 < tiles) wg_pair_tile2<NB>(xi, yi, zi, pa, pb, tdiag == t || tdiag == t + 1, ta, tb, b0, lane);
         else wg_pair_tile<NB>(xi, yi, zi, pa, tdiag == t, ta, b0, lane);
     };
