@@ -230,6 +230,8 @@ def craft_main(args):
         # kernel did about it (the work queue of k_craft_propagate refills finished lanes)
         att = st["attempts"].astype(np.float64)
         out["divergence"] = {"attempts_max_over_mean_per_wave": wave_divergence(att),
+                             "order": "craft index -- what an UNDEALT batch would idle; the kernel runs the dealt order (1.01, "
+                                      "profiles/r03_craft_queue.md)",
                              "attempts_per_craft_min": float(att.min()), "attempts_per_craft_max": float(att.max()),
                              "steps_by_family": {str(f): float(st["steps"][family[lo:hi] == f].mean())
                                                  for f in sorted(set(family[lo:hi].tolist()))}}
