@@ -550,8 +550,8 @@ def main():
     pos, vel, mu = plummer(n, seed=20260926 + (0 if sharded else rank))
     fast = args.path in ("fast", "fast-rsq", "f32-pairs")
     fast_path = {"fast": ea.PATH_FAST, "fast-rsq": ea.PATH_FAST_RSQ, "f32-pairs": ea.PATH_F32_PAIRS}.get(args.path)
-    if fast and sharded:
-        raise SystemExit("--path fast is not sharded")
+    if fast and sharded and args.path != "f32-pairs":
+        raise SystemExit("--path fast / fast-rsq are single-device paths; on a target partition: exact or f32-pairs")
     g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
     if fast:
         g.set_path(fast_path)
@@ -567,9 +567,17 @@ def main():
         scratch = g.clone()
         chunk = max(1, int(2000 * (N_BODIES / n) ** 2))            # ~0.1 s of work per chunk at any size
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < args.prewarm:
+        while True:
             scratch.advance(chunk)
             scratch.sync()
+            out_of_time = time.perf_counter() - t_pre >= args.prewarm
+            if sharded and dist is not None:
+                # a sharded advance is a collective: every rank must run the same number of chunks (a per-rank clock let one rank
+                # start a chunk its peers never entered -- "no data from rank 2 within the time limit", round 5)
+                from ephemeris_explorer_amd.parallel import reduce_timing as _rt
+                out_of_time = _rt(1.0 if out_of_time else 0.0, 0, dist, device="cuda")[1] > 0.0
+            if out_of_time:
+                break
         del scratch
     g.advance(args.warmup)
     g.enable_timing(True)
@@ -634,11 +642,15 @@ def main():
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": ("f32 pair arithmetic, f64 accumulation and integrator (mixed)" if args.path == "f32-pairs" else "f64"),
             "data": "synthetic",
-            "config": ({"workload": f"plummer_{n}_f64_qt12, one system partitioned by target body "
-                                    f"(BASELINE.json configs[4] in f64; h=1/1024, seed 20260926)",
-                        "bodies_per_gpu": nt, "method": "QuinlanTremaine12",
-                        "parallelism": f"target-partition x{world}, 1 all-gather of {32 * n} B per step "
-                                       f"({args.transport})"} if sharded else
+            "config": ({"workload": (f"plummer_{n}_qt12_f32pairs, one system partitioned by target body (BASELINE.json configs[4] AS "
+                                     "STATED: binary32 pair arithmetic on a shard; f64 accumulation in global slice order and f64 "
+                                     "integrator; bit-identical to this library's single-device f32 path for any world size -- the "
+                                     "reference has no f32 path; h=1/1024, seed 20260926)" if args.path == "f32-pairs" else
+                                     f"plummer_{n}_f64_qt12, one system partitioned by target body "
+                                     f"(BASELINE.json configs[4] in f64; h=1/1024, seed 20260926)"),
+                        "bodies_per_gpu": nt, "method": "QuinlanTremaine12", "path": args.path,
+                        "parallelism": f"target-partition x{world}, 1 all-gather of {(16 if args.path == 'f32-pairs' else 32) * n} B "
+                                       f"per step ({args.transport})"} if sharded else
                        {"workload": (f"plummer_{n}_qt12_f32pairs (BASELINE.json configs[4] on one GPU; h=1/1024, seed 20260926+rank); "
                                      "OPT-IN mixed precision: pair arithmetic in binary32, f64 accumulation in slice order, f64 "
                                      "integrator -- the reference has no f32 path, no parity claim" if args.path == "f32-pairs" else

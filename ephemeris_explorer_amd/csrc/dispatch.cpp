@@ -119,13 +119,17 @@ int fast_slices(int npad) {
     S = std::max(8, std::min(64, S));            // (8 rather than 4 slices at 65 536 bodies, eight waves per SIMD: 1.17 -> 1.13 ms on the f32 path)
     return (S + 3) / 4 * 4;
 }
-int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf) {
+int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf, int f32_stage, int conv_lo,
+                        int conv_cnt) {
     const PairKernels *t = table(pv);
     if (!t) return EPH_ERR_BAD_ARGUMENT;
     if (a.n <= 0) return EPH_OK;
-    if (a.lo != 0 || a.hi != a.n) return EPH_ERR_UNSUPPORTED;          // the fast path is not sharded
+    // only the binary32 pair arithmetic runs on a target partition (BASELINE configs[4]); the f64 reordered paths stay single-device
+    if (!posf && (a.lo != 0 || a.hi != a.n)) return EPH_ERR_UNSUPPORTED;
+    if (conv_cnt < 0) { conv_lo = 0; conv_cnt = a.npad; }
+    if (f32_stage != 1 && a.hi <= a.lo) return EPH_OK;                  // a rank whose slice is all padding
     static const int unroll = env_int("EPH_FAST_UNROLL", 4) == 8 ? 8 : 4;
-    return t->lm_step_fast(s, a, partial, fast_slices(a.npad), unroll, approx, posf);
+    return t->lm_step_fast(s, a, partial, fast_slices(a.npad), unroll, approx, posf, f32_stage, conv_lo, conv_cnt);
 }
 int launch_craft(int pv, hipStream_t s, const CraftArgs &a, const CraftLaunch &how) {
     const PairKernels *t = table(pv);

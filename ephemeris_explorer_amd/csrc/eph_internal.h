@@ -107,7 +107,10 @@ constexpr int kGangMaxN = 32;
 int launch_lm_small_many(int pv, hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);
 // opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
 int fast_slices(int npad);                                          // S
-int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr);   // posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body
+// posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body. f32_stage 0: the whole step; 1: only the binary32 copy of rows
+// [conv_lo, conv_lo + conv_cnt) (conv_cnt < 0: all); 2: the step on a copy that is complete already (a sharded handle gathers between)
+int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr, int f32_stage = 0,
+                        int conv_lo = 0, int conv_cnt = -1);
 // the massless sweep (craft_sweep.hip); CraftArgs: craft_device.h
 struct CraftArgs;
 struct CraftLaunch { bool wave_form, queue, occ2; long long resident_waves; };
@@ -125,7 +128,7 @@ struct PairKernels {                        // one evaluation order's launchers 
     int (*lm_persistent)(hipStream_t, const LmArgs &, int64_t);
     int (*lm_small)(hipStream_t, const LmArgs &, int64_t);
     int (*lm_small_many)(hipStream_t, const LmArgs *, int, int, int64_t);
-    int (*lm_step_fast)(hipStream_t, const LmArgs &, double *, int, int, bool, float *);
+    int (*lm_step_fast)(hipStream_t, const LmArgs &, double *, int, int, bool, float *, int, int, int);
     int (*craft_launch)(hipStream_t, const CraftArgs &, const CraftLaunch &);
     int (*debug_inv_r3)(hipStream_t, int64_t, const double *, double *, double *);
     int (*debug_inv_r3_sweep)(hipStream_t, uint64_t, int64_t, unsigned long long *);

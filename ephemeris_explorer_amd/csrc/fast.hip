@@ -139,9 +139,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define EPH_F32_GROUP 32
 #endif
 constexpr int kF32Group = EPH_F32_GROUP;               // sources per conversion to f64 (slices are multiples of it)
-__global__ void __launch_bounds__(256) k_pos_to_f32(int n, int npad, const Body4 *__restrict__ pos, float *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npad) return;
+// rows [lo, lo + cnt) of the binary32 copy (a sharded handle converts the rows it owns: they are what it sends)
+__global__ void __launch_bounds__(256) k_pos_to_f32(int n, int lo, int cnt, const Body4 *__restrict__ pos, float *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const int i = lo + t;
     float x = 0.f, y = 0.f, z = 0.f, mu = 0.f;
     if (i < n) { const Body4 p = pos[i]; x = (float)p.x; y = (float)p.y; z = (float)p.z; mu = (float)p.mu; }
     float *o = out + (size_t)(i >> 1) * 8 + (i & 1);
@@ -177,12 +179,14 @@ __device__ __forceinline__ void f32_slice(const __attribute__((address_space(4))
         az = az + (double)(sz.x + sz.y);
     }
 }
+// block0: the first 64-body block of TARGETS of this launch (a sharded handle sums its own bodies; the slices are cut on global
+// source indices, so a body's sum does not depend on how many ranks share the system)
 __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int npad, const float *__restrict__ posf, int S,
-                                                                      int slice_len, double *__restrict__ partial) {
+                                                                      int slice_len, double *__restrict__ partial, int block0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wgs_per_block = S / kFastWaves;
-    const int block = blockIdx.x / wgs_per_block;
+    const int block = block0 + blockIdx.x / wgs_per_block;
     const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
     const int i = block * 64 + lane;
     const int ic = min(i, n - 1);
@@ -202,9 +206,9 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int
 template <int L>
 __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, const double *__restrict__ partial) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 3 * a.npad) return;
-    const int cc = t / a.npad, my_i = t % a.npad;               // consecutive threads = consecutive bodies: coalesced
-    if (my_i >= a.n) return;
+    const int span = a.hi - a.lo;                               // the launch's bodies [lo, hi): all of them unless the handle is sharded
+    if (t >= 3 * span) return;
+    const int cc = t / span, my_i = a.lo + t % span;            // consecutive threads = consecutive bodies: coalesced
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + my_i;
     double yv[L], av[L];
@@ -244,21 +248,28 @@ __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, cons
 }
 
 
-int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unroll, bool approx, float *posf) {
+// f32_stage (EPH_PATH_F32_PAIRS only): 0 = the whole step; 1 = only the binary32 copy of rows [conv_lo, conv_lo + conv_cnt) (a sharded
+// handle: its own rows, which it then all-gathers); 2 = the step on a copy that is already complete
+int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unroll, bool approx, float *posf, int f32_stage,
+                 int conv_lo, int conv_cnt) {
     int slice_len = (a.npad + S - 1) / S;
     const int un = posf ? kF32Group : approx ? 4 : unroll;
     slice_len = (slice_len + un - 1) / un * un;
-    const dim3 pgrid((unsigned)(a.npad / 64 * (S / kFastWaves))), pblock(64 * kFastWaves);
+    const int block0 = a.lo / 64, nblocks = (a.hi - a.lo + 63) / 64;    // (a.lo is a multiple of 64 on a sharded handle, else 0)
+    if (!posf && (a.lo != 0 || a.hi != a.n)) return EPH_ERR_UNSUPPORTED;
+    const dim3 pgrid((unsigned)(nblocks * (S / kFastWaves))), pblock(64 * kFastWaves);
     if (posf) {                                                         // EPH_PATH_F32_PAIRS
-        hipLaunchKernelGGL(k_pos_to_f32, dim3((unsigned)((a.npad + 255) / 256)), dim3(256), 0, s, a.n, a.npad, a.pos_cur, posf);
-        hipLaunchKernelGGL(k_fast_partial_f32, pgrid, pblock, 0, s, a.n, a.npad, (const float *)posf, S, slice_len, partial);
+        if (f32_stage != 2 && conv_cnt > 0)
+            hipLaunchKernelGGL(k_pos_to_f32, dim3((unsigned)((conv_cnt + 255) / 256)), dim3(256), 0, s, a.n, conv_lo, conv_cnt, a.pos_cur, posf);
+        if (f32_stage == 1) return launched("k_pos_to_f32");
+        hipLaunchKernelGGL(k_fast_partial_f32, pgrid, pblock, 0, s, a.n, a.npad, (const float *)posf, S, slice_len, partial, block0);
     } else if (approx)
         hipLaunchKernelGGL((k_fast_partial<4, true>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     else if (unroll == 8 && a.npad % 8 == 0)
         hipLaunchKernelGGL((k_fast_partial<8, false>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     else
         hipLaunchKernelGGL((k_fast_partial<4, false>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
-    const dim3 grid((3 * a.npad + 255) / 256), block(256);
+    const dim3 grid((3 * (a.hi - a.lo) + 255) / 256), block(256);
     if (a.L == 12) hipLaunchKernelGGL(k_fast_finish<12>, grid, block, 0, s, a, S, partial);
     else if (a.L == 13) hipLaunchKernelGGL(k_fast_finish<13>, grid, block, 0, s, a, S, partial);
     else return EPH_ERR_UNSUPPORTED;

@@ -259,7 +259,9 @@ int NBodyIntegration::lm_batch(int64_t k) {
     a.kind = force_kind();
     int st;
     const bool fast = path_ == EPH_PATH_FAST || path_ == EPH_PATH_FAST_RSQ || path_ == EPH_PATH_F32_PAIRS;
-    if (fast && (n_ <= kSmallN || sharded())) return EPH_ERR_UNSUPPORTED;
+    // on a target partition only the binary32 pair arithmetic runs (BASELINE configs[4] as stated); fast / fast-rsq stay single-device
+    if (fast && (n_ <= kSmallN || (sharded() && path_ != EPH_PATH_F32_PAIRS))) return EPH_ERR_UNSUPPORTED;
+    const bool f32_sharded = sharded() && path_ == EPH_PATH_F32_PAIRS;
     if (fast && !fast_partial_.p) {
         if ((st = fast_partial_.alloc((size_t)fast_slices(npad_) * 3 * npad_))) return st;
     }
@@ -305,6 +307,15 @@ int NBodyIntegration::lm_batch(int64_t k) {
             a.pos_next = P_[pp_ ^ 1].p;
             a.do_predict = s < k || leave_prediction;
             a.step = (uint32_t)s;
+            if (f32_sharded) {
+                // this rank's rows of the binary32 copy (16 B per body: SURVEY 8(e)'s f32x4), one all-gather of them, then the rank's
+                // targets against all sources in the single-device slice order. The f64 packed positions of the OTHER ranks' bodies
+                // are not needed between the steps of a batch (the batch's first prediction gathers them once, above).
+                if ((st = launch_lm_step_fast(pv_, stream_, a, fast_partial_.p, false, posf_.p, 1, lo_, slice_))) return st;
+                if ((st = xch_->all_gather_inplace(posf_.p, sizeof(float) * 4 * (size_t)slice_, stream_))) return st;
+                if ((st = launch_lm_step_fast(pv_, stream_, a, fast_partial_.p, false, posf_.p, 2))) return st;
+                continue;
+            }
             if ((st = fast ? launch_lm_step_fast(pv_, stream_, a, fast_partial_.p, path_ == EPH_PATH_FAST_RSQ,
                                                  path_ == EPH_PATH_F32_PAIRS ? posf_.p : nullptr)
                            : launch_lm_step(pv_, stream_, a)))

@@ -6,8 +6,8 @@
 // single-device one. What a rank lacks after a step are the other ranks' new packed positions: one all-gather
 // of slice*32 bytes per force evaluation. Two transports:
 //   * RCCL over xGMI: ncclAllGather on the handle's own stream, no host synchronisation between steps. The
-//     library is resolved at run time (dlopen) so that a process that already carries an RCCL (PyTorch ships
-//     one) does not get a second copy; EPH_RCCL_LIB overrides the search.
+//     library is resolved at run time (dlopen): the RCCL beside the HIP runtime this library is bound to -- NOT whatever
+//     RCCL the process already carries (PyTorch bundles one, bound to its own bundled runtime); EPH_RCCL_LIB overrides.
 //   * direct peer writes (peer.hip, eph_peer_*): each rank's slice written straight into hipIpc-mapped mailboxes of
 //     its peers, one small launch per exchange, no collective library -- the low-latency transport for small systems.
 //   * a caller-supplied function (eph_exchange_fn), e.g. MPI or a host-staged gather; it is handed the stream
@@ -37,15 +37,39 @@ struct Rccl {
 };
 constexpr int kNcclInt8 = 0;   // ncclInt8 / ncclChar
 
+// Which RCCL: the one that sits beside the HIP runtime THIS library is bound to. A process that imported PyTorch carries a second,
+// bundled HIP runtime and an RCCL bound to it (torch/lib/librccl.so); device pointers and streams of one runtime mean nothing to
+// the other, so an RCCL that merely happens to be loaded already is the wrong one unless it lives in our runtime's directory
+// (round 5: ncclCommInitRank "no ROCm-capable device is detected" in a test process that had imported torch first). RTLD_DEEPBIND:
+// the second RCCL resolves its own symbols before any global-scope copy. EPH_RCCL_LIB overrides the search.
+std::string dir_of(const void *symbol) {
+    Dl_info di{};
+    if (!dladdr(symbol, &di) || !di.dli_fname) return std::string();
+    const std::string f(di.dli_fname);
+    const size_t k = f.rfind('/');
+    return k == std::string::npos ? std::string() : f.substr(0, k);
+}
 Rccl *rccl() {
     static Rccl r = [] {
         Rccl x;
+        const int flags = RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND;
         const char *env = getenv("EPH_RCCL_LIB");
+        if (env && *env) x.lib = dlopen(env, flags);
+        const std::string hipdir = dir_of((const void *)&hipGetDeviceCount);   // where the runtime this library calls lives
+        if (!x.lib && !hipdir.empty())
+            for (const char *name : {"/librccl.so.1", "/librccl.so"})
+                if ((x.lib = dlopen((hipdir + name).c_str(), flags))) break;
+        // no RCCL beside the runtime: one that is loaded already, provided it is bound to the same runtime directory
         const char *loaded[] = {"librccl.so", "librccl.so.1"};
+        for (size_t i = 0; !x.lib && i < 2; ++i) {
+            void *h = dlopen(loaded[i], RTLD_NOW | RTLD_NOLOAD);
+            if (!h) continue;
+            void *sym = dlsym(h, "ncclAllGather");
+            if (sym && (hipdir.empty() || dir_of(sym) == hipdir)) x.lib = h;
+            else dlclose(h);
+        }
         const char *fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        if (env && *env) x.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-        for (size_t i = 0; !x.lib && i < 2; ++i) x.lib = dlopen(loaded[i], RTLD_NOW | RTLD_NOLOAD);
-        for (size_t i = 0; !x.lib && i < 3; ++i) x.lib = dlopen(fresh[i], RTLD_NOW | RTLD_LOCAL);
+        for (size_t i = 0; !x.lib && i < 3; ++i) x.lib = dlopen(fresh[i], flags);
         if (!x.lib) return x;
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.lib, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.lib, "ncclCommInitRank");

@@ -373,3 +373,98 @@ def test_get_state_reports_a_lost_peer_itself(gpu):
     mp.spawn(_lost_peer_state_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     status, text = out[0]
     assert status == -6 and "rank 1" in text
+
+
+# ---- BASELINE configs[4] as stated: binary32 pair arithmetic ON a target partition ------------------------------------------------
+def _single_f32(n, steps_f32, steps_exact):
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(n)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    nb.set_path(ea.PATH_F32_PAIRS)
+    nb.advance(12 + steps_f32)
+    mid = nb.state(), nb.acc()
+    nb.set_path(0)
+    nb.advance(steps_exact)
+    return mid, (nb.state(), nb.acc())
+
+
+def _f32_worker(rank, world, port, n, steps_f32, steps_exact, out, transport):
+    import sys
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd import parallel
+    from ephemeris_explorer_amd.workloads import plummer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pos, vel, mu = plummer(n)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    nb.set_path(ea.PATH_F32_PAIRS)
+    if transport == "host":
+        # the host-staged exchange costs ~0.2 s per gather between processes that share a GPU and the start-up has 336 of them
+        # (covered sharded by test_ranks_on_one_gpu_match_single_device): every rank starts the whole system up, then the partition
+        nb.advance(12)
+        parallel.shard_nbody(nb, dist, transport=transport)
+        nb.advance(1)
+    else:
+        parallel.shard_nbody(nb, dist, transport=transport)
+        nb.advance(12 + 1)                            # start-up (f64, sharded) and the first binary32 step
+    g0 = nb.shard_info()[2]
+    nb.advance(steps_f32 - 1)                         # one batch: one f64 gather (the batch's prediction) + one f32 gather per step
+    g1 = nb.shard_info()[2]
+    mid = nb.state(), nb.acc()
+    twin = nb.clone()
+    nb.set_path(0)                                    # back to the exact path on the same partition: nothing stale is read
+    nb.advance(steps_exact)
+    twin.set_path(0)
+    twin.advance(steps_exact)
+    end = nb.state(), nb.acc()
+    out[rank] = (mid, end, g1 - g0, np.array_equal(twin.state()[0], end[0][0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,transport", [(4096, 2, "host"), (4096, 4, "peer"), (4050, 2, "peer"), (16384, 2, "peer"),
+                                               (16384, 4, "host")])
+def test_f32_pairs_on_a_target_partition(gpu, n, world, transport, monkeypatch):
+    """EPH_PATH_F32_PAIRS on a sharded handle (BASELINE configs[4]: "65 536-body f32 system, 8 x MI355X shard"): each rank converts
+    ITS rows to binary32, one all-gather of 16 B per body, then k_fast_partial_f32 over its own targets. The slices of the f64
+    accumulation are cut on GLOBAL source indices, so the result is bit-identical to the single-device f32 path for any world
+    size (the reference has no f32 path -- ephemeris/src/propagators/nbody.rs:13,19 -- so that is what there is to compare with).
+    Then the same handles go back to the exact path and stay identical to the single device that did the same."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("EPH_PEER_TIMEOUT_MS", "5000")
+    steps_f32, steps_exact = (30, 3) if n <= 4096 and transport != "host" else (8, 2)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_f32_worker, args=(world, _free_port(), n, steps_f32, steps_exact, out, transport), nprocs=world, join=True)
+    mid0, end0 = _single_f32(n, steps_f32, steps_exact)
+    assert set(out.keys()) == set(range(world))
+    for r in range(world):
+        mid, end, gathers, twin_ok = out[r]
+        for (st, a), (st0, a0), what in ((mid, mid0, "f32 leg"), (end, end0, "exact leg after it")):
+            assert st[2:] == st0[2:], what
+            assert np.array_equal(st[0], st0[0]) and np.array_equal(st[1], st0[1]) and np.array_equal(a, a0), (r, what)
+        assert twin_ok
+        assert gathers == 1 + (steps_f32 - 1)        # the batch's first prediction in f64 + the binary32 rows once per step
+
+
+def test_f32_pairs_sharded_through_rccl(gpu):
+    """the same through ncclAllGather (a one-rank communicator: the collective still runs on the 16-byte rows)"""
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(4096)
+    nb = ea.NBodyIntegration(pos, vel, mu, 0.0, H).shard(0, 1, unique_id=ea.rccl_unique_id())
+    nb.set_path(ea.PATH_F32_PAIRS)
+    nb.advance(12 + 25)
+    one = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    one.set_path(ea.PATH_F32_PAIRS)
+    one.advance(12 + 25)
+    assert np.array_equal(nb.state()[0], one.state()[0]) and np.array_equal(nb.acc(), one.acc())
+    for path in (ea.PATH_FAST, ea.PATH_FAST_RSQ):    # the f64 reordered paths stay single-device
+        nb.set_path(path)
+        with pytest.raises(ea.EphemerisError) as e:
+            nb.advance(1)
+        assert e.value.status == ea.ERR_UNSUPPORTED
