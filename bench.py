@@ -400,6 +400,7 @@ def other_configs():
     propagator with its solout and every least-squares fit, in this process -- and configs[3], the massless sweep, as a child
     process of this file (`--workload craft`) under a time limit. Neither can cost the headline: failures are recorded."""
     import subprocess
+    import numpy as np
     out = {}
     try:
         import ephemeris_explorer_amd as ea
@@ -410,9 +411,39 @@ def other_configs():
         t = time.perf_counter()
         p.step_n(1_000_000)
         w = time.perf_counter() - t
-        out["configs1_full_solar_system"] = {"bodies": int(s.n), "steps": 1000000, "seconds": w, "us_per_step": w / 1e6 * 1e6,
-                                             "body_steps_per_s": s.n * 1e6 / w,
-                                             "includes": "k_lm_small steps + solout sampling + every least-squares fit"}
+        c1 = {"bodies": int(s.n), "steps": 1000000, "seconds": w, "us_per_step": w / 1e6 * 1e6,
+              "body_steps_per_s": s.n * 1e6 / w,
+              "includes": "k_lm_small steps + solout sampling + every least-squares fit"}
+        out["configs1_full_solar_system"] = c1
+        # the same 1 020 000 steps by the CPU restatement (NBodyPropagator with its solout and fits; native build, one thread --
+        # the reference steps this system on one thread, ephemeris_explorer/src/load/mod.rs:673-687), the last 1e6 timed
+        from oracle import orc
+        orc.build(native=True)
+        o = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, s.dt, 1, s.count, s.degree, native=True)
+        assert o.step_n(20000) == 0
+        t = time.perf_counter()
+        assert o.step_n(1_000_000) == 0
+        wc = time.perf_counter() - t
+        c1["cpu_baseline"] = {"value": s.n * 1e6 / wc, "unit": "body-steps/s", "cores": 1, "kind": "port",
+                              "sample": "the same 1e6 steps of the same system with solout and fits (oracle Propagator, -O2 "
+                                        "-march=native, one thread)", "seconds": wc, "us_per_step": wc}
+        pg, po = p.state(), o.state()
+        c1["parity"] = {"max_abs_dpos": float(np.abs(pg[0] - po[0]).max()), "max_abs_dvel": float(np.abs(pg[1] - po[1]).max()),
+                        "steps": int(po[3]), "vs": "oracle (port)"}
+        # Latency roofline: a step of 32 bodies is ONE dependent chain through one workgroup, not throughput. Its shortest form,
+        # priced with the measured dependent-issue interval of v_add_f64 on this part (5.9 cycles, profiles/r02_chain2_ubench.txt;
+        # multiplies and fmas taken at the same figure -- optimistic) at the 2.4 GHz shader clock:
+        #   pair term   25 dependent f64 operations (difference, three-term square, the IEEE square root's and reciprocal's
+        #               refinement sequences, mu * inv, d * (...)) + v_rsq_f64 (16)
+        #   row sums    31 ordered additions of the longest chain (bodies 0 and 31) + the two halves' addition
+        #   predictor   a * w_beta[0], eleven more ordered additions, * h^2/beta_d, + sum1 = 15 (sum1's twelve run beside the pairs)
+        #   two LDS round trips (positions out and in, contributions out and in): 2 x (write 64 + barrier + read 64)
+        dep = 5.9
+        floor = (25 * dep + 16) + 32 * dep + 15 * dep + 2 * 128
+        ticks = w / 1e6 * 2.4e9
+        c1["latency_roofline"] = {"floor_ticks_per_step": floor, "ticks_per_step": ticks, "frac": floor / ticks, "clock_ghz": 2.4,
+                                  "floor": "(25 x 5.9 + 16) pair chain + 32 x 5.9 ordered row sum + 15 x 5.9 predictor + 2 x 128 LDS "
+                                           "round trips; where the rest goes: profiles/r05_small_kernel_evidence.md"}
     except Exception as e:
         out["configs1_full_solar_system"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     try:

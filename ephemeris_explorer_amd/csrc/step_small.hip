@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
     const int chain = tid >> 1, half = tid & 1;
     const bool chain_thread = chain < 3 * n;
     const bool owner = chain_thread && half == 0;     // the (body, comp) thread: history, velocity, predictor
+    // waves that hold chain threads (tid < 6 n): the only ones that carry the predictor's arithmetic (wave-uniform by construction)
+    const bool owner_wave = __builtin_amdgcn_readfirstlane(tid >> 6) <= ((6 * n - 1) >> 6);
     const int my_i = chain_thread ? chain / 3 : 0, cc = chain_thread ? chain % 3 : 0;
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + my_i;
@@ -133,8 +135,10 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
     // reciprocal sequences run first and unconditionally; the range test that validates them (device_math.h) is decided
     // behind them, where the branch no longer stalls the wave, and an out-of-range operand anywhere in the wave redoes
     // the term in the full IEEE form.
-    auto pair = [&]() {
-        const double4 vi = *reinterpret_cast<const double4 *>(&sP[pi0]), vj = *reinterpret_cast<const double4 *>(&sP[pj0]);
+    // `before_branch()` runs between the wrapper-free results and the (rare, wave-uniform) branch that redoes them in the full
+    // IEEE form: the owner waves pin the predictor's position chain there, so that it is emitted in the SAME block as the
+    // sequences and fills their issue gaps; without it the compiler places the chain behind the stores (round 5, read off the ISA).
+    auto pair = [&](const double4 &vi, const double4 &vj, auto &&before_branch) {
         const double dx = vj.x - vi.x, dy = vj.y - vi.y, dz = vj.z - vi.z;
         const double n2 = dx * dx + dy * dy + dz * dz;
         double ax, ay, az, bx, by, bz;
@@ -143,6 +147,9 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
             pair_apply<true>(den, dx, dy, dz, vj.w, ax, ay, az);
             pair_apply<true>(den, -dx, -dy, -dz, vi.w, bx, by, bz);
         }
+        // the wrapper-free results exist HERE (otherwise the compiler sinks them into the else-side of the branch below)
+        asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz));
+        before_branch();
         if (__builtin_amdgcn_ballot_w64(!in_range(n2)) != 0) {
             const PairDen den = pair_den<false>(n2);
             pair_apply<false>(den, dx, dy, dz, vj.w, ax, ay, az);
@@ -184,19 +191,30 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
         // costs the chain its full latency every term -- measured ~25 cycles per term instead of ~8.4, 330 cycles for the
         // twelve terms behind the force. The eleven products of the acceleration half that do not involve the new
         // acceleration are formed here too.)
-        double p1[L], q2[L];
-        p1[0] = ynew * wa[0];
+        // ONLY the waves that hold owners run it (round 5): every wave executed these 35 f64 instructions for the sake of three,
+        // and the phase is issue-bound with two waves per SIMD (accounting build: the first wave of a SIMD left at 581 ticks, the
+        // second at 962, without the stores). A wave-uniform branch; both sides hold the pair arithmetic as straight-line code.
+        double q2[L], s1;                              // (set and read in the owner waves only)
+        // the pair's two bodies: the reads are in flight under the products below
+        const double4 vi = *reinterpret_cast<const double4 *>(&sP[pi0]), vj = *reinterpret_cast<const double4 *>(&sP[pj0]);
+        if (owner_wave) {
+            double p1[L];
+            p1[0] = ynew * wa[0];
 #pragma unroll
-        for (int j = 1; j < L; ++j) { p1[j] = yv[(R + j - 1) % L] * wa[j]; q2[j] = av[(R + j - 1) % L] * wb[j]; }
-        __builtin_amdgcn_sched_barrier(0);
-        double s1 = 0.0;
+            for (int j = 1; j < L; ++j) { p1[j] = yv[(R + j - 1) % L] * wa[j]; q2[j] = av[(R + j - 1) % L] * wb[j]; }
+            __builtin_amdgcn_sched_barrier(0);
+            s1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < L; ++j) s1 = s1 + p1[j];
-        // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
-        pair();
-        asm volatile("" : "+v"(s1));                   // computed HERE (the compiler would sink it behind the force)
+            for (int j = 0; j < L; ++j) s1 = s1 + p1[j];
+            // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
+            pair(vi, vj, [&]() {
+                asm volatile("" : "+v"(s1));           // computed HERE, among the sequences
 #pragma unroll
-        for (int j = 1; j < L; ++j) asm volatile("" : "+v"(q2[j]));
+                for (int j = 1; j < L; ++j) asm volatile("" : "+v"(q2[j]));
+            });
+        } else {
+            pair(vi, vj, []() {});
+        }
         if constexpr (EPH_SMALL_ACCOUNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SMALL_TICK(1);
         lds_barrier();     // contributions visible
@@ -208,6 +226,10 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
             const double *row = half ? &U[chain][0] : &Lw[chain][0];
             auto sum_blocks = [&](auto nb) {
                 constexpr int NB = decltype(nb)::value;
+                // (the optimiser hoists the common first eight reads and two adds of the two row lengths in front of the branch and
+                // issues the long row's other eight reads behind sixteen adds. Forcing all sixteen reads in front of the first add
+                // was SLOWER -- row sums 610 -> 677 ticks: a lone wave's ds_read_b128 costs it ~12 issue cycles each and overlaps
+                // nothing of its own, profiles/r02_chain2_ubench.txt -- so the accident stays; round 5)
                 double2 r[8 * NB];
 #pragma unroll
                 for (int k = 0; k < 8 * NB; ++k) r[k] = *reinterpret_cast<const double2 *>(row + 2 * k);

@@ -869,6 +869,15 @@ int orc_prop_step(orc_prop *pr) {
     if (!prop_solout(pr)) return ORC_SOLOUT_EXIT;                /* nbody.rs:201-204 */
     return ORC_OK;
 }
+/* n x IncrementalPropagator::step, stopping at the first error (a loop for callers that time the restatement: one call from
+ * Python per step would be half of what is measured) */
+int orc_prop_step_n(orc_prop *pr, int64_t n) {
+    for (int64_t k = 0; k < n; ++k) {
+        int st = orc_prop_step(pr);
+        if (st) return st;
+    }
+    return ORC_OK;
+}
 /* DirectionalSolout::solution_time  nbody.rs:501-508 */
 double orc_prop_time(const orc_prop *pr) {
     int n = pr->solution->n;

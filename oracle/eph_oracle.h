@@ -87,6 +87,7 @@ orc_prop *orc_prop_new(int n, const double *pos, const double *vel, const double
 orc_prop *orc_prop_clone(const orc_prop *);
 void orc_prop_free(orc_prop *);
 int orc_prop_step(orc_prop *);               /* IncrementalPropagator::step  nbody.rs:200-207 */
+int orc_prop_step_n(orc_prop *pr, int64_t n);      /* n steps, stopping at the first error */
 int orc_prop_step_to(orc_prop *, double t);  /* ephemeris/src/lib.rs:49-60 */
 double orc_prop_time(const orc_prop *);      /* DirectionalPropagator::time  nbody.rs:225-227,502-508 */
 int orc_prop_has_reached(const orc_prop *, double t);

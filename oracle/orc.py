@@ -82,6 +82,7 @@ def lib(native=False):
     L.orc_prop_free.argtypes = [vp]
     L.orc_prop_free.restype = None
     L.orc_prop_step.argtypes = [vp]
+    L.orc_prop_step_n.argtypes = [vp, C.c_int64]
     L.orc_prop_step_to.argtypes = [vp, C.c_double]
     L.orc_prop_time.argtypes = [vp]
     L.orc_prop_time.restype = C.c_double
@@ -296,6 +297,9 @@ class Propagator:
 
     def step(self):
         return self.L.orc_prop_step(self.h)
+
+    def step_n(self, n):
+        return self.L.orc_prop_step_n(self.h, int(n))
 
     def step_to(self, t):
         return self.L.orc_prop_step_to(self.h, float(t))
