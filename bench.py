@@ -226,6 +226,31 @@ def craft_main(args):
             "wall_over_kernel": elapsed / nsweeps / launch_s,
         }
         out["fp64"] = dict(out["roofline"]["fp64"], bound="fp64_valu")
+        # counters of the committed rocprofv3 passes of this kernel (scripts/prof_craft.sh), scaled by the attempts of THIS run;
+        # dropped when the kernel's sources changed since they were taken
+        tj = ROOT / "profiles" / "traffic_craft.json"
+        if tj.exists() and args.population == "transfer":
+            from ephemeris_explorer_amd.workloads import profile_is_current
+            tinfo = json.loads(tj.read_text())
+            current, why = profile_is_current(tinfo, "craft")
+            out["roofline"]["traffic_profile_commit"] = tinfo.get("profile_commit")
+            if current and tinfo.get("traffic_bytes_per_attempt"):
+                att_launch = attempts_local / nsweeps
+                out["roofline"]["traffic"] = tinfo["traffic_bytes_per_attempt"] * att_launch
+                out["roofline"]["traffic_source"] = (tinfo.get("source", "") + ": raw FETCH_SIZE + WRITE_SIZE per attempt x this launch's attempts "
+                                                     "(5-6 x the 56 B per accepted step: mostly the scratch stores of the 100 spilled VGPRs)")
+                lane_ops = tinfo["valu_wave_insts_per_attempt"] * att_launch * 64.0 / launch_s
+                out["roofline"]["fp64"]["valu_issue"] = {
+                    "achieved": lane_ops / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS / 2.0, "unit": "T lane-ops/s",
+                    "frac": lane_ops / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
+                    "valu_wave_insts_per_attempt": tinfo["valu_wave_insts_per_attempt"],
+                    "f64_wave_insts_per_attempt": tinfo.get("f64_wave_insts_per_attempt"),
+                    "active_inst_valu_over_wave_cycles": tinfo.get("active_inst_valu_over_wave_cycles"),
+                    "waves_per_simd": tinfo.get("waves_per_simd"), "vgpr_count": tinfo.get("vgpr_count"),
+                    "vgpr_spill_count": tinfo.get("vgpr_spill_count")}
+                out["fp64"]["valu_issue"] = out["roofline"]["fp64"]["valu_issue"]
+            elif not current:
+                out["roofline"]["traffic_stale"] = f"{tj.name} not used: {why}"
         # lane idling of a static craft -> lane assignment: per wave max / mean attempts (1.0 = none), and what the
         # kernel did about it (the work queue of k_craft_propagate refills finished lanes)
         att = st["attempts"].astype(np.float64)
@@ -456,7 +481,10 @@ def other_configs():
         out["configs3_craft_sweep"] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                                        "workload": d["config"]["workload"], "kernel": d["roofline"]["kernel"],
                                        "launch_us": d["roofline"]["launch_us"], "wall_over_kernel": d["ms_per_step"] * 1e3 / d["roofline"]["launch_us"],
-                                       "fp64": d["roofline"]["fp64"], "cpu_baseline": d.get("cpu_baseline"),
+                                       "fp64": d["roofline"]["fp64"], "traffic": d["roofline"].get("traffic"),
+                                       "traffic_profile_commit": d["roofline"].get("traffic_profile_commit"),
+                                       "algorithmic_bytes_per_launch": d["roofline"].get("algorithmic_bytes_per_launch"),
+                                       "cpu_baseline": d.get("cpu_baseline"),
                                        "divergence": d["divergence"]["attempts_max_over_mean_per_wave"]}
     except Exception as e:
         out["configs3_craft_sweep"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -654,10 +682,19 @@ def main():
         # as MI355X_MICROARCH.md prescribes) of this same command, committed under profiles/ -- not measurable live
         traffic, traffic_src, valu_insts = None, None, None
         tj = ROOT / "profiles" / ("traffic_fast.json" if fast else "traffic.json")
+        traffic_commit, traffic_stale = None, None
         if tj.exists() and n == N_BODIES and not sharded:                   # the committed PMC passes of this path
+            from ephemeris_explorer_amd.workloads import profile_is_current
             tinfo = json.loads(tj.read_text())
-            traffic, traffic_src = tinfo.get("traffic_bytes_per_launch"), tinfo.get("source")
-            valu_insts = tinfo.get("valu_wave_insts_per_launch")
+            # the figures are only as good as the kernel they were counted on: the file carries the sha256 of the kernel's sources
+            # (scripts/summarize_profile.py), recomputed here; a source that changed since drops them from the line
+            current, why = profile_is_current(tinfo, "fast" if fast else "nbody")
+            traffic_commit = tinfo.get("profile_commit")
+            if current:
+                traffic, traffic_src = tinfo.get("traffic_bytes_per_launch"), tinfo.get("source")
+                valu_insts = tinfo.get("valu_wave_insts_per_launch")
+            else:
+                traffic_stale = f"{tj.name} not used: {why} (re-take with scripts/round_profile.sh + scripts/summarize_profile.py)"
         out = {
             "metric": "body-steps/s", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -692,6 +729,7 @@ def main():
                         "path": args.path}),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_profile_commit": traffic_commit, "traffic_stale": traffic_stale,
                          "kernel": ("k_fast_partial_f32 + k_fast_finish<12>" if args.path == "f32-pairs" else
                                     "k_fast_partial + k_fast_finish<12>" if fast else
                                     f"k_lm_step_wg<12,{16 if nt > 2048 else 8 if nt > 1024 else 4}>" if nt > 512 else "k_lm_step<BPW,12>"),

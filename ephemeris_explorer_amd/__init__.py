@@ -49,11 +49,11 @@ ABI_SYMBOLS = [
     "eph_prop_has_reached", "eph_prop_integrator_time", "eph_prop_get_state", "eph_prop_take_solution",
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
-    "eph_solution_destroy", "eph_least_squares_fit", "eph_debug_inv_r3", "eph_debug_quot", "eph_debug_inv_r3_sweep", "eph_debug_wg_cycles",
+    "eph_solution_destroy", "eph_least_squares_fit",
     "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_set_body_order", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_summary", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
-    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points", "eph_debug_pow", "eph_debug_div", "eph_debug_rsq",
+    "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points",
 ]
 
 
@@ -181,8 +181,6 @@ def _lib():
     L.eph_solution_destroy.argtypes = [vp]
     L.eph_solution_destroy.restype = None
     L.eph_least_squares_fit.argtypes = [i32, i32, i64, _dp, _dp, _i32p]
-    L.eph_debug_inv_r3.argtypes = [i64, _dp, _dp, _dp]
-    L.eph_debug_inv_r3_sweep.argtypes = [C.c_uint64, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.eph_ephemeris_create.argtypes = [vp, _dp, C.POINTER(vp)]
     L.eph_ephemeris_interpolation_errors.argtypes = [vp, vp, i64, _dp, C.POINTER(i64)]
     L.eph_ephemeris_destroy.argtypes = [vp]
@@ -216,10 +214,7 @@ def _lib():
     L.eph_transitions_join.argtypes = [i64, _dp, _i32p, i64, _dp, _i32p, f64, i64, _dp, _i32p, _i64p]
     L.eph_apsides_join.argtypes = [i64, _dp, _dp, _i32p, _i32p, i64, _dp, _dp, _i32p, _i32p, f64, i64, _dp, _dp, _i32p,
                                    _i32p, _i64p]
-    L.eph_debug_pow.argtypes = [i64, _dp, f64, _dp]
-    L.eph_debug_div.argtypes = [i64, _dp, _dp, _dp, _dp]
-    L.eph_debug_rsq.argtypes = [i64, _dp, _dp, _dp]
-    if L.eph_abi_version() != 1:
+    if L.eph_abi_version() != 2:
         raise ImportError("libephemeris_amd.so ABI version mismatch")
     _L = L
     return L
@@ -308,31 +303,6 @@ def pair_variant():
 def set_pair_variant(k):
     """eph_set_pair_variant: the order (0..6, csrc/pair_term.h) for every handle created afterwards"""
     _check(_lib().eph_set_pair_variant(int(k)), "eph_set_pair_variant")
-
-
-def debug_quot(x, a):
-    """test hook: (fast, ieee) device evaluations of a / (x * sqrt(x)) -- the division forms' shared-reciprocal quotient"""
-    x, a = _f64(x), _f64(a)
-    fast, ieee = np.zeros_like(x), np.zeros_like(x)
-    _lib().eph_debug_quot.argtypes = [C.c_int64, _dp, _dp, _dp, _dp]
-    _check(_lib().eph_debug_quot(x.size, _p(x), _p(a), _p(fast), _p(ieee)), "eph_debug_quot")
-    return fast, ieee
-
-
-def debug_inv_r3(n2):
-    """test hook: (fast, ieee) device evaluations of 1/(x*sqrt(x))"""
-    n2 = _f64(n2)
-    fast, ieee = np.zeros_like(n2), np.zeros_like(n2)
-    _check(_lib().eph_debug_inv_r3(n2.size, _p(n2), _p(fast), _p(ieee)), "eph_debug_inv_r3")
-    return fast, ieee
-
-
-def debug_inv_r3_sweep(seed, n):
-    """(mismatches, bits of one mismatching operand) of the in-range 1/(x*sqrt(x)) sequence against the IEEE expansion
-    over n device-generated operands."""
-    bad, ex = C.c_uint64(), C.c_uint64()
-    _check(_lib().eph_debug_inv_r3_sweep(int(seed), int(n), C.byref(bad), C.byref(ex)), "eph_debug_inv_r3_sweep")
-    return bad.value, ex.value
 
 
 def _shard_call(fn, name, handle, rank, world, unique_id, exchange):
@@ -962,35 +932,3 @@ def apsides_join(lhs, rhs, at):
                                    _p(rb, _i32p), float(at), cap, _p(t), _p(d), _p(k, _i32p), _p(b, _i32p), C.byref(n)),
            "eph_apsides_join")
     return t[:n.value].copy(), d[:n.value].copy(), k[:n.value].copy(), b[:n.value].copy()
-
-
-def debug_div(a, b):
-    """(shared-reciprocal quotient, compiler IEEE quotient) of a / b on the device."""
-    a, b = _f64(a).ravel(), _f64(b).ravel()
-    fast, ieee = np.zeros_like(a), np.zeros_like(a)
-    _check(_lib().eph_debug_div(a.size, _p(a), _p(b), _p(fast), _p(ieee)), "eph_debug_div")
-    return fast, ieee
-
-
-def debug_wg_cycles():
-    """tuning hook: k_lm_small's eight tick counters (zeros unless the library was built with -DEPH_EXPERIMENTS=1)"""
-    out = (C.c_int64 * 8)()
-    _lib().eph_debug_wg_cycles.argtypes = [C.POINTER(C.c_int64)]
-    _check(_lib().eph_debug_wg_cycles(out), "eph_debug_wg_cycles")
-    return list(out)
-
-
-def debug_rsq(x):
-    """test hook: (v_rsq_f64(x), h after the square root's coupled step) on the device"""
-    x = _f64(x).ravel()
-    y, h = np.zeros_like(x), np.zeros_like(x)
-    _check(_lib().eph_debug_rsq(x.size, _p(x), _p(y), _p(h)), "eph_debug_rsq")
-    return y, h
-
-
-def debug_pow(x, y):
-    """test hook: the controller's correctly rounded pow on the device"""
-    x = _f64(x)
-    out = np.zeros_like(x)
-    _check(_lib().eph_debug_pow(x.size, _p(x), float(y), _p(out)), "eph_debug_pow")
-    return out

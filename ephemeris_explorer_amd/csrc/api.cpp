@@ -47,6 +47,8 @@ struct eph_prop {
         return EPH_ERR_HIP;                             \
     }
 
+// the library is compiled with -fvisibility=hidden: the boundary below (and craft.hip's half of it) is ALL it exports
+#pragma GCC visibility push(default)
 extern "C" {
 
 int32_t eph_abi_version(void) { return EPH_ABI_VERSION; }
@@ -564,62 +566,6 @@ int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, co
     EPH_GUARD_END
 }
 
-int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee) {
-    EPH_GUARD_BEGIN
-    if (n < 0 || (n > 0 && (!n2 || !fast || !ieee))) return EPH_ERR_BAD_ARGUMENT;
-    int st = check_device();
-    if (st) return st;
-    if (n == 0) return EPH_OK;
-    DevBuf<double> a, b, c;
-    if ((st = a.alloc(n)) || (st = b.alloc(n)) || (st = c.alloc(n))) return st;
-    EPH_HIP(hipMemcpy(a.p, n2, sizeof(double) * n, hipMemcpyHostToDevice));
-    if ((st = launch_debug_inv_r3(default_pair_variant(), nullptr, n, a.p, b.p, c.p))) return st;
-    EPH_HIP(hipMemcpy(fast, b.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    EPH_HIP(hipMemcpy(ieee, c.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    return EPH_OK;
-    EPH_GUARD_END
-}
-
-// a / (x * sqrt(x)) through the division forms' seeded reciprocal + Markstein step, and through the compiler's IEEE expansions
-int32_t eph_debug_quot(int64_t n, const double *x, const double *a, double *fast, double *ieee) {
-    EPH_GUARD_BEGIN
-    if (n < 0 || (n > 0 && (!x || !a || !fast || !ieee))) return EPH_ERR_BAD_ARGUMENT;
-    int st = check_device();
-    if (st) return st;
-    if (n == 0) return EPH_OK;
-    DevBuf<double> dx, da, b, c;
-    if ((st = dx.alloc(n)) || (st = da.alloc(n)) || (st = b.alloc(n)) || (st = c.alloc(n))) return st;
-    EPH_HIP(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
-    EPH_HIP(hipMemcpy(da.p, a, sizeof(double) * n, hipMemcpyHostToDevice));
-    if ((st = launch_debug_quot(default_pair_variant(), nullptr, n, dx.p, da.p, b.p, c.p))) return st;
-    EPH_HIP(hipMemcpy(fast, b.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    EPH_HIP(hipMemcpy(ieee, c.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    return EPH_OK;
-    EPH_GUARD_END
-}
-
-int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, uint64_t *example_bits) {
-    EPH_GUARD_BEGIN
-    if (n < 0 || !mismatches || !example_bits) return EPH_ERR_BAD_ARGUMENT;
-    int st = check_device();
-    if (st) return st;
-    DevBuf<unsigned long long> out;
-    if ((st = out.alloc(2))) return st;
-    EPH_HIP(hipMemset(out.p, 0, 2 * sizeof(unsigned long long)));
-    if ((st = launch_debug_inv_r3_sweep(default_pair_variant(), nullptr, seed, n, out.p))) return st;
-    unsigned long long h[2];
-    EPH_HIP(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
-    *mismatches = h[0];
-    *example_bits = h[1];
-    return EPH_OK;
-    EPH_GUARD_END
-}
-
-int32_t eph_debug_wg_cycles(int64_t *out8) {
-    if (!out8) return EPH_ERR_BAD_ARGUMENT;
-    return debug_wg_cycles(default_pair_variant(), (long long *)out8);
-}
-
 // SpacecraftPropagator::join  spacecraft.rs:558-561 = CubicHermiteSpline::clear_after (trajectory.rs:842-845) + extend
 // (:847-849). Host only.
 int32_t eph_hermite_join(int64_t n_lhs, const double *t_lhs, const double *pos_lhs, const double *vel_lhs,
@@ -698,3 +644,4 @@ int32_t eph_apsides_join(int64_t n_lhs, const double *t_lhs, const double *dista
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

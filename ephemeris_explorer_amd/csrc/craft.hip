@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "craft_device.h"
+#include "eph_debug.h"
 #include "host.h"
 
 namespace eph {
@@ -938,6 +939,7 @@ static int clone_buf(const DevBuf<T> &src, DevBuf<T> &dst, hipStream_t s) {
     return EPH_OK;
 }
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out) {
@@ -1594,7 +1596,13 @@ int32_t eph_plot_points(const eph_ephemeris *e, const eph_plot_view *view, int64
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 
-int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast, double *ieee) {
+}  // extern "C"
+#pragma GCC visibility pop
+
+// ---- test hooks: the device halves (the extern "C" entry points live in debug_api.cpp, which only the test-hooks library and the
+// tuning builds link: csrc/eph_debug.h) ---------------------------------------------------------------------------------------------
+namespace eph {
+int debug_div_device(int64_t n, const double *a, const double *b, double *fast, double *ieee) {
     try {
         if (n < 0 || (n > 0 && (!a || !b || !fast || !ieee))) return EPH_ERR_BAD_ARGUMENT;
         int st = check_device();
@@ -1615,7 +1623,7 @@ int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast,
 }
 
 // raw v_rsq_f64(x) and the h = 0.5 / sqrt(x) that the square root's coupled step leaves (the reciprocal's seed is 8 h^3):
-// the two quantities the error-bound note of inv_r3_seeded (device_math.h) starts from
+// the two quantities the error-bound note of inv_r3_seeded (pair_term.h) starts from
 __global__ void k_debug_rsq(long long n, const double *__restrict__ x, double *__restrict__ y, double *__restrict__ h1) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1625,7 +1633,7 @@ __global__ void k_debug_rsq(long long n, const double *__restrict__ x, double *_
     y[i] = yy;
     h1[i] = __builtin_fma(h, r, h);
 }
-int32_t eph_debug_rsq(int64_t n, const double *x, double *rsq, double *h) {
+int debug_rsq_device(int64_t n, const double *x, double *rsq, double *h) {
     try {
         if (n < 0 || (n > 0 && (!x || !rsq || !h))) return EPH_ERR_BAD_ARGUMENT;
         int st = check_device();
@@ -1643,7 +1651,7 @@ int32_t eph_debug_rsq(int64_t n, const double *x, double *rsq, double *h) {
     } catch (...) { return EPH_ERR_HIP; }
 }
 
-int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out) {
+int debug_pow_device(int64_t n, const double *x, double y, double *out) {
     try {
         if (n < 0 || (n > 0 && (!x || !out))) return EPH_ERR_BAD_ARGUMENT;
         int st = check_device();
@@ -1660,4 +1668,4 @@ int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out) {
     } catch (...) { return EPH_ERR_HIP; }
 }
 
-}  // extern "C"
+}  // namespace eph

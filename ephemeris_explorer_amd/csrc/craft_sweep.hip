@@ -57,7 +57,7 @@ __device__ __forceinline__ bool body_term(const CraftArgs &a, const BodyEntry &b
     }
     const V3 d = sub(bp, pos);                        // acceleration_at::<false>: dir = body - at
     const double n2 = dot(d, d);
-    // the point-mass term in the build's evaluation order, IEEE sqrt and divide (device_math.h)
+    // the point-mass term in the build's evaluation order, IEEE sqrt and divide (pair_term.h)
     if (__builtin_amdgcn_ballot_w64(!in_range(n2)) == 0) pair_apply<true>(pair_den<true>(n2), d.x, d.y, d.z, be.mu, term.x, term.y, term.z);
     else pair_apply<false>(pair_den<false>(n2), d.x, d.y, d.z, be.mu, term.x, term.y, term.z);
     return true;

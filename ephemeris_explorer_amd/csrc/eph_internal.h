@@ -70,7 +70,7 @@ struct SampleArgs {            // solout sampling schedule for one batch (device
     double *log;               // AoS xyz
 };
 
-struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm_step / k_lm_persistent)
+struct LmArgs {                // fused linear-multistep step (step_wg.hip, step_wave.hip, step_small.hip: k_lm_step_wg / k_lm_step / k_lm_small / k_lm_persistent)
     int n, npad, L, cur;       // cur = ring slot of the level whose acceleration is evaluated
     int lo, hi;                // target bodies [lo, hi) of this launch (0, n unless the system is sharded over ranks)
     const Body4 *pos_cur;      // packed positions of that level
@@ -81,7 +81,7 @@ struct LmArgs {                // fused linear-multistep step (kernels.hip: k_lm
     int do_predict;
     uint32_t step;             // 1-based index of this step inside the batch (for sampling)
     int kind;                  // force kernel: 0 auto, 1 wave, 2 workgroup
-    int wg_flags;              // workgroup kernel tuning bits (kernels.hip wg_debug_flags)
+    int wg_flags;              // workgroup kernel tuning bits (tuning builds: EPH_DEBUG_SMALL, step_small.hip)
     SampleArgs samp;
 };
 

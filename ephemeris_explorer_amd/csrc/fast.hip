@@ -55,12 +55,16 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
         for (int u = 0; u < kFastUnroll; ++u) pj[u] = nxt[u];
         fetch(min(j + kFastUnroll, j1 - kFastUnroll), nxt);   // next group's scalar loads in flight under this one's arithmetic
         PairPre pre[kFastUnroll];
-        unsigned worst = 0u;
+        // the three keys pair_finish<true> requires its caller to have wave-tested (pair_term.h): n2 in range, and -- for the division
+        // forms -- the smallest |d_c| and mu inside the wrapper-free division's range, as step_wave.hip and step_wg.hip fold them
+        unsigned worst = 0u, low = ~0u;
 #pragma unroll
         for (int u = 0; u < kFastUnroll; ++u) {
             pre[u] = pair_pre(xi, yi, zi, pj[u]);
-            worst = max(worst, range_key(pre[u].n2));
+            worst = max(worst, max(range_key(pre[u].n2), mu_key(pj[u].mu)));
+            low = min(low, pre[u].lo);
         }
+        worst = max(worst, low_key(low));
         double c[3 * kFastUnroll];
         if (APPROX) {
 #pragma unroll

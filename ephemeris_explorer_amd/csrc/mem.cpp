@@ -3,10 +3,13 @@
 // 1. A cache of LARGE device blocks (>= kPoolMinBytes). A spacecraft batch owns knot slabs of several GB (56 B per knot and
 //    craft), and a sweep loop creates and destroys identical batches: taking such blocks from the driver and handing them back
 //    costs ~100 ms per batch (five 5.4 GB batches: 790 ms created with hipMalloc each time, 240-265 ms with the cache;
-//    profiles/r04_sweep_evidence.md). Blocks of exactly the requested size are reused instead, up to a cap (EPH_POOL_MAX_MB,
-//    default a quarter of the device); eph_release_cached_memory() returns them to the driver, and an allocation that fails
-//    empties the cache and retries. Contents are NOT cleared: no user of a block this large reads what it did not write (knot
-//    rows beyond nknots are unspecified by contract).
+//    profiles/r04_sweep_evidence.md). Blocks of exactly the requested size are reused instead.
+//    The cache is accounted PER DEVICE and bounded per device: EPH_POOL_MAX_MB (0 switches it off), default an eighth of that
+//    device's memory, read once per device. It never outlives the library's use of a device: when the LAST device allocation of
+//    this library on a device is freed (every handle destroyed), that device's cached blocks go back to the driver, so a process
+//    that shares the GPU with another allocator (PyTorch, RCCL, a second library) is not left holding GBs it does not use; while
+//    handles are alive such a caller calls eph_release_cached_memory() itself. An allocation of ours that fails empties the cache
+//    and retries. A reused block is cleared (what a fresh allocation looks like: no caller is handed another batch's rows).
 // 2. One process-wide staging buffer in pinned, device-mapped host memory that KERNELS read and write (no copy engine, no
 //    pinning of short-lived host vectors): the deal's index arrays at batch creation, the reordered knot rows of a dealt batch.
 #include <algorithm>
@@ -21,33 +24,63 @@ namespace eph {
 
 namespace {
 constexpr size_t kPoolMinBytes = (size_t)64 << 20;
+constexpr int kMaxDevices = 64;
 std::mutex g_pool_mu;
 std::map<std::pair<int, size_t>, std::vector<void *>> g_pool;   // (device, bytes) -> free blocks
-size_t g_pool_bytes = 0;
+size_t g_pool_bytes[kMaxDevices] = {};                          // cached bytes per device
+long long g_live[kMaxDevices] = {};                             // this library's live device allocations per device (cached ones excluded)
+size_t g_cap[kMaxDevices] = {};
+bool g_cap_known[kMaxDevices] = {};
 
-size_t pool_cap(int device) {
+// the cap of `device`'s cache, computed once (the caller holds g_pool_mu and `device` is the current device)
+size_t pool_cap_locked(int device) {
+    if (g_cap_known[device]) return g_cap[device];
     static const long long forced = [] { const char *e = getenv("EPH_POOL_MAX_MB"); return e ? atoll(e) : -1LL; }();
-    if (forced >= 0) return (size_t)forced << 20;
-    size_t free_b = 0, total = 0;
-    int current = device;
-    (void)hipGetDevice(&current);
-    if (device != current) (void)hipSetDevice(device);
-    const hipError_t e = hipMemGetInfo(&free_b, &total);
-    if (device != current) (void)hipSetDevice(current);
-    return e == hipSuccess ? total / 4 : 0;
+    size_t cap = 0;
+    if (forced >= 0) {
+        cap = (size_t)forced << 20;
+    } else {
+        size_t free_b = 0, total = 0;
+        if (hipMemGetInfo(&free_b, &total) == hipSuccess) cap = total / 8;
+    }
+    g_cap[device] = cap;
+    g_cap_known[device] = true;
+    return cap;
+}
+// blocks of `device` out of the cache (g_pool_mu held); the caller frees them outside the lock
+void take_device_locked(int device, std::vector<void *> *out) {
+    for (auto it = g_pool.begin(); it != g_pool.end();) {
+        if (it->first.first == device) {
+            out->insert(out->end(), it->second.begin(), it->second.end());
+            it = g_pool.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    g_pool_bytes[device] = 0;
 }
 }  // namespace
 
 int dev_alloc(size_t bytes, void **out) {
     *out = nullptr;
     int device = 0;
-    if (bytes >= kPoolMinBytes && hipGetDevice(&device) == hipSuccess) {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool.find({device, bytes});
-        if (it != g_pool.end() && !it->second.empty()) {
-            *out = it->second.back();
-            it->second.pop_back();
-            g_pool_bytes -= bytes;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) device = -1;
+    if (bytes >= kPoolMinBytes && device >= 0) {
+        void *hit = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            auto it = g_pool.find({device, bytes});
+            if (it != g_pool.end() && !it->second.empty()) {
+                hit = it->second.back();
+                it->second.pop_back();
+                g_pool_bytes[device] -= bytes;
+                g_live[device] += 1;
+            }
+        }
+        if (hit) {
+            // what a fresh allocation looks like (on the legacy default stream: ordered before any handle stream's later work)
+            if (hipMemsetAsync(hit, 0, bytes, nullptr) != hipSuccess) (void)hipGetLastError();
+            *out = hit;
             return EPH_OK;
         }
     }
@@ -61,28 +94,50 @@ int dev_alloc(size_t bytes, void **out) {
         set_last_error("hipMalloc", e);
         return e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_HIP;
     }
+    if (device >= 0) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_live[device] += 1;
+    }
     return EPH_OK;
 }
 
 void dev_free(void *p, size_t bytes) {
     if (!p) return;
-    int device = 0;
-    if (bytes >= kPoolMinBytes && hipGetDevice(&device) == hipSuccess) {
-        const int current = device;
+    int current = 0, device = -1;
+    if (hipGetDevice(&current) == hipSuccess) {
+        device = current;
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, p) == hipSuccess) device = attr.device;
+        else (void)hipGetLastError();
+    }
+    if (device < 0 || device >= kMaxDevices) { (void)hipFree(p); return; }
+    bool cached = false;
+    std::vector<void *> drop;
+    if (bytes >= kPoolMinBytes) {
         // what hipFree would have done before handing the block on: nothing on ITS device may still be using it
         if (device != current) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        if (device != current) (void)hipSetDevice(current);
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool_bytes + bytes <= pool_cap(device)) {
-            g_pool[{device, bytes}].push_back(p);
-            g_pool_bytes += bytes;
-            return;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            if (g_pool_bytes[device] + bytes <= pool_cap_locked(device)) {
+                g_pool[{device, bytes}].push_back(p);
+                g_pool_bytes[device] += bytes;
+                cached = true;
+            }
         }
+        if (device != current) (void)hipSetDevice(current);
     }
-    (void)hipFree(p);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_live[device] > 0) g_live[device] -= 1;
+        if (g_live[device] == 0) take_device_locked(device, &drop);   // the library's last allocation on this device is gone
+    }
+    if (!cached) (void)hipFree(p);
+    if (!drop.empty()) {
+        if (device != current) (void)hipSetDevice(device);
+        for (void *q : drop) (void)hipFree(q);          // (p itself is among them when it had just been cached)
+        if (device != current) (void)hipSetDevice(current);
+    }
 }
 
 size_t release_cached_memory() {
@@ -91,8 +146,7 @@ size_t release_cached_memory() {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         take.swap(g_pool);
-        bytes = g_pool_bytes;
-        g_pool_bytes = 0;
+        for (int d = 0; d < kMaxDevices; ++d) { bytes += g_pool_bytes[d]; g_pool_bytes[d] = 0; }
     }
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -106,7 +160,9 @@ size_t release_cached_memory() {
 
 size_t cached_memory_bytes() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    return g_pool_bytes;
+    size_t bytes = 0;
+    for (int d = 0; d < kMaxDevices; ++d) bytes += g_pool_bytes[d];
+    return bytes;
 }
 
 // ---- pinned, device-mapped staging ------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@
 //   SubstepperIntegrator::advance               integration/src/multistep/mod.rs:97-108
 //   FixedRungeKuttaIntegrator::advance + SRKN   integration/src/runge_kutta/mod.rs:106-126, nystrom/symplectic.rs:69-102
 // The host replays the reference's scalar bookkeeping (time, bound, step counters) with the reference's f64
-// operations; all vector arithmetic runs in the HIP kernels of kernels.hip.
+// operations; all vector arithmetic runs in the HIP kernels of step_wg.hip / step_wave.hip / step_small.hip / fast.hip / solout.hip.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +111,7 @@ int NBodyIntegration::clone(std::unique_ptr<NBodyIntegration> *out) {
     o->h_ = h_; o->h_sub_ = h_sub_; o->time_ = time_; o->bound_ = bound_; o->pv_ = pv_;
     o->starter_i_ = starter_i_; o->lm_i_ = lm_i_; o->evals_ = evals_;
     o->cur_ = cur_; o->pp_ = pp_; o->path_ = path_; o->predicted_ = predicted_;
+    o->failed_ = failed_;                                  // (a handle a gang launch left behind its bookkeeping stays marked in its copies)
     o->lo_ = lo_; o->hi_ = hi_; o->slice_ = slice_; o->xch_ = xch_;   // a clone of a sharded handle shares the ranks
     EPH_HIP(hipStreamCreateWithFlags(&o->stream_, hipStreamNonBlocking));
     EPH_HIP(hipEventCreate(&o->ev0_));
@@ -233,16 +234,23 @@ int64_t NBodyIntegration::steps_available(int64_t k, int *status_after) const {
     return s;
 }
 
+// Every pending pair has BOTH events recorded (lm_batch pushes a pair only behind its closing record). A pair whose query fails
+// (a device error in between) is skipped and recycled with the others: the list is always emptied, so one bad interval can neither
+// stop the accumulation nor fill the list until every later batch fails (advisor, round 4).
 int NBodyIntegration::resolve_timing() {
+    int st = EPH_OK;
     for (auto &e : ev_pending_) {
         float ms = 0;
-        EPH_HIP(hipEventSynchronize(e.second));
-        EPH_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-        kernel_ms_ += ms;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+            kernel_ms_ += ms;
+        } else {
+            set_last_error("timing events", hipGetLastError());
+            st = EPH_ERR_HIP;
+        }
     }
     ev_free_.insert(ev_free_.end(), ev_pending_.begin(), ev_pending_.end());
     ev_pending_.clear();
-    return EPH_OK;
+    return st;
 }
 
 // k x ELM2::advance   second_order/mod.rs:90-131
@@ -273,12 +281,20 @@ int NBodyIntegration::lm_batch(int64_t k) {
     if (collect_ && !persistent) return EPH_ERR_UNSUPPORTED;           // (advance_many checks gang_ready first)
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (timing_ && !collect_) {
-        if (ev_pending_.size() >= 1024 && (st = resolve_timing())) return st;
+        if (ev_pending_.size() >= 1024) (void)resolve_timing();           // (a failed interval is dropped there, not returned here)
         if (!ev_free_.empty()) { ev = ev_free_.back(); ev_free_.pop_back(); }
         else { EPH_HIP(hipEventCreate(&ev.first)); EPH_HIP(hipEventCreate(&ev.second)); }
-        ev_pending_.push_back(ev);
-        EPH_HIP(hipEventRecord(ev.first, stream_));
+        if (hipEventRecord(ev.first, stream_) != hipSuccess) {
+            ev_free_.push_back(ev);
+            set_last_error("hipEventRecord", hipGetLastError());
+            return EPH_ERR_HIP;
+        }
     }
+    // the pair joins the pending list only once its closing event is recorded (below); every earlier return hands it back
+    struct TimingGuard {
+        std::pair<hipEvent_t, hipEvent_t> &ev; std::vector<std::pair<hipEvent_t, hipEvent_t>> &free_list; bool armed;
+        ~TimingGuard() { if (armed && ev.second) free_list.push_back(ev); }
+    } timing_guard{ev, ev_free_, true};
     if (persistent) {
         a.cur = cur_;
         a.pos_cur = P_[pp_].p;
@@ -325,7 +341,11 @@ int NBodyIntegration::lm_batch(int64_t k) {
         predicted_ = leave_prediction;
         if (timing_) kernel_launches_ += (uint64_t)k;
     }
-    if (ev.second) EPH_HIP(hipEventRecord(ev.second, stream_));
+    if (ev.second) {
+        EPH_HIP(hipEventRecord(ev.second, stream_));
+        ev_pending_.push_back(ev);
+        timing_guard.armed = false;
+    }
     if (collect_) deferred_time_steps_ += k;              // advance_many replays them once the gang is launched
     else for (int64_t s = 0; s < k; ++s) time_ = time_ + h_;   // problem.time = problem.time + h, per step (the launch is already queued)
     lm_i_ += (uint32_t)k;

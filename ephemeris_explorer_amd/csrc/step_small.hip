@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
 
     // Every thread runs the pair arithmetic: straight-line code, so the scheduler interleaves it with the predictor's
     // position chain (sum1) instead of executing one exec-masked region after the other. The wrapper-free sqrt /
-    // reciprocal sequences run first and unconditionally; the range test that validates them (device_math.h) is decided
+    // reciprocal sequences run first and unconditionally; the range test that validates them (pair_term.h) is decided
     // behind them, where the branch no longer stalls the wave, and an out-of-range operand anywhere in the wave redoes
     // the term in the full IEEE form.
     // `before_branch()` runs between the wrapper-free results and the (rare, wave-uniform) branch that redoes them in the full

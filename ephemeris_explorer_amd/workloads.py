@@ -123,3 +123,42 @@ def wave_divergence(attempts, wave=64):
     a = np.concatenate([a, np.zeros(pad)]).reshape(-1, wave)
     mx, mean = a.max(axis=1), a.sum(axis=1) / wave
     return float(mx.sum() / max(mean.sum(), 1e-300))
+
+
+# ---- which kernel sources a committed counter file (profiles/traffic*.json) was taken with -------------------------------------------
+# bench.py prints HBM traffic and VALU counts out of committed rocprofv3 passes (they cannot be collected live). A counter file carries
+# the sha256 of the sources of the kernel it describes; bench.py recomputes them and DROPS the figures when a source has changed since.
+PROFILE_SOURCES = {
+    "nbody": ["step_wg.hip", "step_wave.hip", "pair_term.h", "ieee_seq.h", "force_common.h", "chain_tile.inc"],
+    "craft": ["craft_sweep.hip", "craft_device.h", "craft_attempt.inc", "pair_term.h", "ieee_seq.h"],
+    "fast": ["fast.hip", "pair_term.h", "ieee_seq.h", "force_common.h"],
+}
+
+
+def source_hashes(kind):
+    import hashlib
+    from pathlib import Path
+    csrc = Path(__file__).resolve().parent / "csrc"
+    return {f: hashlib.sha256((csrc / f).read_bytes()).hexdigest()[:16] for f in PROFILE_SOURCES[kind]}
+
+
+def profile_stamp(kind):
+    """what scripts/summarize_profile.py writes into a counter file: the sources' hashes and the commit they were read at"""
+    import subprocess
+    from pathlib import Path
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=Path(__file__).resolve().parent, capture_output=True,
+                              text=True).stdout.strip() or None
+    except OSError:
+        head = None
+    return {"profile_commit": head, "source_sha256_16": source_hashes(kind)}
+
+
+def profile_is_current(info, kind):
+    """(True, None) when the counter file `info` was taken with today's kernel sources, else (False, which source changed)"""
+    want = info.get("source_sha256_16")
+    if not want:
+        return False, "the counter file carries no source hashes"
+    have = source_hashes(kind)
+    changed = [f for f in have if want.get(f) != have[f]]
+    return (not changed), (", ".join(changed) + " changed since the profile" if changed else None)

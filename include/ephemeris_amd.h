@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define EPH_ABI_VERSION 1
+/* 2 (round 5): the eph_debug_* hooks left the boundary (csrc/eph_debug.h); eph_pair_variant reports the process-wide default
+ * order new handles take (round 4: the order is a run-time choice), eph_nbody_advance_many / eph_prop_step_n_many only queue. */
+#define EPH_ABI_VERSION 2
 
 /* integration::StepError (integration/src/lib.rs:312-318), NBodyPropagatorError::Solout
  * (ephemeris/src/propagators/nbody.rs:43-47); negative values are library / HIP failures. */
@@ -68,9 +70,11 @@ int32_t eph_device_count(int32_t *count);
 int32_t eph_set_device(int32_t device);
 int32_t eph_device_name(char *buf, int32_t buflen);
 /* The library keeps device blocks of >= 64 MiB that a destroyed handle owned (the knot slabs of a spacecraft batch are GBs) for
- * the next handle that asks for exactly that size, up to a quarter of the device (EPH_POOL_MAX_MB overrides; 0 disables): a
- * sweep loop creates identical batches, and taking GB-sized blocks from the driver and handing them back costs ~100 ms per batch.
- * This call returns the cache to the driver; *bytes (optional) = what was released. */
+ * the next handle that asks for exactly that size: a sweep loop creates identical batches, and taking GB-sized blocks from the
+ * driver and handing them back costs ~100 ms per batch. The cache is per device, at most an eighth of that device's memory
+ * (EPH_POOL_MAX_MB overrides; 0 disables), a reused block is cleared, and the cache does not outlive the library's use of a device:
+ * when the last handle that holds device memory on it is destroyed, its cached blocks return to the driver. While handles are alive,
+ * a process that shares the GPU with another allocator calls this to return the cache; *bytes (optional) = what was released. */
 int32_t eph_release_cached_memory(uint64_t *bytes);
 
 /* ---- coefficient tables (integration/src/methods.rs, ratio.rs:221-228) ---------------------------
@@ -136,7 +140,10 @@ int32_t eph_nbody_sync(eph_nbody *h);
  * steady-state steps of all of them go into one launch with a workgroup per system -- the reference runs its forward and
  * backward propagators concurrently (ephemeris_explorer/src/load/mod.rs:673-687), and ensembles are independent too.
  * Same results as the separate calls; systems that do not qualify (start-up steps, more bodies, a sharded handle, a
- * step that would return a StepError) simply make the call do those. Handles must be distinct and on one device. */
+ * step that would return a StepError) simply make the call do those. Handles must be distinct and on one device.
+ * ASYNCHRONOUS, like eph_nbody_advance: the call queues the launch and returns; completion is eph_nbody_sync / get_state of a
+ * member. A device failure AFTER the members' bookkeeping has moved (the shared launch itself) marks every member failed: all their
+ * later calls -- and those of their clones -- return that status; kernel time of a timed gang accrues to the FIRST handle. */
 int32_t eph_nbody_advance_many(eph_nbody *const *handles, int32_t count, int64_t n_steps);
 
 /* ---- multi-GPU: the massive-body system partitioned by TARGET body over the ranks of one node -----------------
@@ -207,7 +214,8 @@ int32_t eph_prop_shard(eph_prop *p, int32_t rank, int32_t world, const void *rcc
                        void *ctx);
 int32_t eph_prop_shard_peer(eph_prop *p, eph_peer *peer);
 /* eph_prop_step_n(p, n) on `count` propagators at once, their steady-state steps in shared launches
- * (eph_nbody_advance_many); each propagator samples, fits and pushes its own windows. */
+ * (eph_nbody_advance_many); each propagator samples, fits and pushes its own windows. Queues and returns like it: the fits are
+ * settled by the next call that needs them (eph_prop_time, has_reached, take_solution, get_state). */
 int32_t eph_prop_step_n_many(eph_prop *const *props, int32_t count, int64_t n);
 /* IncrementalPropagator::step  nbody.rs:200-207. Executed lazily: the reference's callers step in a loop and read
  * time() / has_reached() after every step (ephemeris_explorer/src/prediction.rs:422-443); both are functions of the number
@@ -444,26 +452,8 @@ int32_t eph_apsides_join(int64_t n_lhs, const double *t_lhs, const double *dista
                          const int32_t *kind_rhs, const int32_t *body_rhs, double at, int64_t capacity, double *t_out,
                          double *distance_out, int32_t *kind_out, int32_t *body_out, int64_t *n_out);
 
-/* Test hook: the hardware's v_rsq_f64(x[i]) and the h ~ 0.5/sqrt(x[i]) left by the square root's coupled refinement
- * step -- the inputs of the error-bound note on inv_r3_seeded (csrc/device_math.h) */
-int32_t eph_debug_rsq(int64_t n, const double *x, double *rsq, double *h);
-/* Test hook: the step-size controller's correctly rounded pow(x[i], y) on the device */
-int32_t eph_debug_pow(int64_t n, const double *x, double y, double *out);
-/* test hook: a[i] / b[i] through the shared-reciprocal division of k_craft_wave and through the compiler's IEEE
- * division */
-int32_t eph_debug_div(int64_t n, const double *a, const double *b, double *fast, double *ieee);
-/* Test hook: 1/(x*sqrt(x)) for n inputs computed by the kernel's in-range fast sequences (NaN where the range
- * guard would send the tile to the IEEE form) and by the compiler's IEEE sqrt/divide expansions. */
-int32_t eph_debug_inv_r3(int64_t n, const double *n2, double *fast, double *ieee);
-/* a / (x * sqrt(x)): the division forms' shared-reciprocal quotient (csrc/pair_term.h) beside the compiler's IEEE division */
-int32_t eph_debug_quot(int64_t n, const double *x, const double *a, double *fast, double *ieee);
-/* Test hook: the same comparison over n operands generated on the device (splitmix64(seed + index): random mantissa,
- * exponent uniform over the guarded range; n is rounded up to a multiple of 2^20). *mismatches = operands whose two
- * results differ in any bit; *example_bits = the IEEE bits of one of them (0 when none). */
-int32_t eph_debug_inv_r3_sweep(uint64_t seed, int64_t n, uint64_t *mismatches, uint64_t *example_bits);
-/* Tuning hook: zeros from the product library. A build with -DEPH_EXPERIMENTS=1 (scripts/build_exp.sh) returns the
- * single-workgroup kernel's per-phase tick accounting of its last launch (EPH_DEBUG_SMALL=4). */
-int32_t eph_debug_wg_cycles(int64_t *out8);
+/* (The test and tuning hooks -- eph_debug_* -- are not part of this boundary: csrc/eph_debug.h, exported by the test-hooks
+ * library libephemeris_amd_testhooks.so and by tuning builds only.) */
 
 #ifdef __cplusplus
 }

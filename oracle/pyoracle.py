@@ -51,7 +51,7 @@ class Vec(tuple):
         return Vec(-self[0], -self[1], -self[2])
 
 
-PAIR_VARIANT = 0   # evaluation order of the unpinned point-mass term, same numbering as eph_oracle.c / device_math.h
+PAIR_VARIANT = 0   # evaluation order of the unpinned point-mass term, same numbering as eph_oracle.c / pair_term.h
 
 
 def set_pair_variant(v):

@@ -11,11 +11,64 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from ephemeris_explorer_amd.workloads import profile_stamp      # sha256 of the kernel sources a counter file was taken with
 tag = sys.argv[1]
 src = ROOT / "gpurun_out" / tag
 dst = ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 
+# the massless sweep's counters (scripts/prof_craft.sh <tag> -> gpurun_out/prof_<tag>/summary.json), if taken this round
+craft = ROOT / "gpurun_out" / f"prof_{tag}" / "summary.json"
+if craft.exists():
+    c = json.loads(craft.read_text())
+    b = c.pop("bench", {})
+    att = float(b.get("attempts", 0)) or None
+    ns = float(c["avg_ns"])
+    q = 4.0                                            # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)
+    f64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    flop = (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + 2.0 * c.get("SQ_INSTS_VALU_FMA_F64", 0.0)) * 64.0
+    simd_cycles = 1024 * ns * 1e-9 * 2.4e9             # 256 CUs x 4 SIMDs at the 2.4 GHz shader clock
+    derived = {
+        "active_inst_any_over_wave_cycles": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+        "active_inst_valu_over_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+        "wait_inst_any_over_wave_cycles": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+        "wait_any_over_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+        "mean_resident_waves_per_simd": c["SQ_WAVE_CYCLES"] * q / simd_cycles,
+        "f64_wave_insts": f64, "f64_share_of_valu": f64 / c["SQ_INSTS_VALU"],
+        "f64_issue_fraction_of_simd_cycles": f64 * 4.0 / simd_cycles,      # a wave64 f64 instruction occupies its SIMD for 4 cycles
+        "valu_lane_ops_per_s": c["SQ_INSTS_VALU"] * 64.0 / (ns * 1e-9),
+        "counted_tflops": flop / (ns * 1e-9) / 1e12,
+        "salu_per_valu": c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"],
+        "fetch_bytes_raw": c.get("FETCH_SIZE", 0.0) * 1024.0, "write_bytes_raw": c.get("WRITE_SIZE", 0.0) * 1024.0,
+    }
+    if att:
+        terms = att * 13.0 * 32.0 / 64.0                # wave-level (craft, stage, body) terms
+        derived.update({"attempts": att, "valu_wave_insts_per_body_term": c["SQ_INSTS_VALU"] / terms,
+                        "f64_wave_insts_per_body_term": f64 / terms,
+                        "write_bytes_per_accepted_step": derived["write_bytes_raw"] / float(b.get("accepted_steps", att))})
+    code_object = {"k_craft_propagate<13,false,false,2>": {"vgpr_count": 256, "vgpr_spill_count": 100, "sgpr_count": 106,
+                                                           "scratch_bytes_per_lane": 384, "waves_per_simd": 2},
+                   "k_craft_propagate<13,false,false,1>": {"vgpr_count": 340, "vgpr_spill_count": 0, "waves_per_simd": 1},
+                   "source": "hipcc -S --cuda-device-only of csrc/craft_sweep.hip (order 0), .amdgpu_metadata"}
+    (dst / f"{tag}_craft_pmc.json").write_text(json.dumps({
+        "command": f"scripts/prof_craft.sh {tag}: scripts/bench_craft.py {b.get('n_craft')} {b.get('days')} under rocprofv3 --kernel-include-regex k_craft, "
+                   "one --pmc pass per line of the script (FETCH_SIZE and WRITE_SIZE in passes of their own)",
+        "note": "sums over the chip for the ONE launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles; FETCH_SIZE / WRITE_SIZE in KiB, "
+                "uncalibrated for this access pattern (scalar loads of coefficient rows, 8-byte knot stores): raw figures",
+        "counters": c, "derived": derived, "code_object": code_object, "bench": b, **profile_stamp("craft")}, indent=1) + "\n")
+    (dst / "traffic_craft.json").write_text(json.dumps({
+        "source": f"profiles/{tag}_craft_pmc.json", "kernel": c["kernel"], "attempts": att,
+        "traffic_bytes_per_attempt": (derived["fetch_bytes_raw"] + derived["write_bytes_raw"]) / att if att else None,
+        "valu_wave_insts_per_attempt": c["SQ_INSTS_VALU"] / att if att else None,
+        "f64_wave_insts_per_attempt": f64 / att if att else None,
+        "active_inst_valu_over_wave_cycles": derived["active_inst_valu_over_wave_cycles"],
+        "waves_per_simd": 2, "vgpr_count": 256, "vgpr_spill_count": 100,
+        "avg_ns_kernel_trace": ns, **profile_stamp("craft")}, indent=1) + "\n")
+    print(json.dumps(derived, indent=1))
+
+if not (src / "stats_kernel_stats.csv").exists():          # only the sweep was profiled so far this round
+    sys.exit(0)
 shutil.copy(src / "stats_kernel_stats.csv", dst / f"{tag}_kernel_stats.csv")
 bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
 (dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1) + "\n")
@@ -87,6 +140,8 @@ main = max(out["kernels"].items(), key=lambda kv: kv[1].get("calls", 0) * kv[1].
     "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)",
     "kernel": main[0], "traffic_bytes_per_launch": main[1].get("traffic_bytes_per_launch"),
     "valu_wave_insts_per_launch": main[1].get("SQ_INSTS_VALU"),
-    "avg_ns_kernel_trace": main[1].get("avg_ns_kernel_trace")}, indent=1) + "\n")
+    "avg_ns_kernel_trace": main[1].get("avg_ns_kernel_trace"),
+    **profile_stamp("nbody")}, indent=1) + "\n")
 print(json.dumps(out, indent=1)[:3000])
 print("bench:", bench["value"], bench["roofline"]["launch_us"])
+

@@ -35,6 +35,13 @@ def gpu(product_lib):
     return ea
 
 
+@pytest.fixture(scope="session")
+def hooks(gpu):
+    """the eph_debug_* test hooks: a library of their own (tests/hooks.py), never the product's"""
+    import hooks as h
+    return h.load()
+
+
 def load_system(name):
     from ephemeris_explorer_amd.systems import load_system as ls
     return ls(SYSTEMS / name)

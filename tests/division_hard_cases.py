@@ -1,7 +1,7 @@
-"""Hard operands for the shared-reciprocal division of the division-form pair orders (csrc/device_math.h: quot_seeded).
+"""Hard operands for the shared-reciprocal division of the division-form pair orders (csrc/pair_term.h: quot_seeded).
 
 The kernels evaluate  a / p,  p = RN(x * RN(sqrt x)),  as
-    r = RN(1 / p)            (inv_r3_seeded: correctly rounded, device_math.h's argument)
+    r = RN(1 / p)            (inv_r3_seeded: correctly rounded, pair_term.h's argument)
     t = RN(a * r) ; e = a - p * t (one fma, exact) ; q = RN(t + e * r)
 -- Markstein's division step. q = RN(a / p) needs t to be close enough to a / p and the residual to be exact; the quotients
 that could break it are the ones closest to a rounding boundary. For a given p (significand B, odd part taken) and a small

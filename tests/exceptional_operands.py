@@ -1,7 +1,7 @@
 """Operands x for which the reciprocal's denominator p = RN(x * RN(sqrt(x))) has a significand at the very top of its
 binade, p = 2^(E+1) - k ulp for small k. k = 1 (all ones) is THE exceptional significand of the reciprocal's closing
 residual step (Markstein): 1/p = 2^-(E+1) (1 + 2^-53 + 2^-106 + ...) sits 2^-106 (relative) above a rounding boundary,
-so an iterate that approaches 1/p from below ends on an exact tie. csrc/device_math.h (inv_r3_seeded / rcp_biased)
+so an iterate that approaches 1/p from below ends on an exact tie. csrc/pair_term.h (inv_r3_seeded / rcp_biased)
 explains how the sequences get this case right; these operands are how the tests check it."""
 import numpy as np
 

@@ -103,3 +103,43 @@ def test_header_is_plain_c_and_the_c_example_links(product_lib, tmp_path):
         assert r.returncode == 77, (r.returncode, r.stderr)
     else:
         assert r.returncode == 0 and "apsides" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_debug_hooks_are_not_in_the_product(product_lib):
+    """csrc/eph_debug.h: the seven eph_debug_* hooks are exported by the test-hooks library (the product's objects + debug_api.o)
+    and by tuning builds, never by libephemeris_amd.so; the product exports the header's functions and no other eph_* name."""
+    hooks_lib = product_lib.LIB_PATH.with_name("libephemeris_amd_testhooks.so")
+    assert hooks_lib.exists(), "ephemeris_explorer_amd.build builds it beside the product"
+    text = (ROOT / "ephemeris_explorer_amd" / "csrc" / "eph_debug.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    debug = sorted(set(re.findall(r"\b(eph_debug_[a-z0-9_]+)\s*\(", text)))
+    assert len(debug) == 7
+    assert not any(n.startswith("eph_debug") for n in header_functions())
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", str(path)]).decode()
+        return set(re.findall(r" T (eph_[a-z0-9_]+)", out))
+    assert exported(hooks_lib) == set(header_functions()) | set(debug)
+    assert not (exported(product_lib.LIB_PATH) & set(debug))
+    # -fvisibility=hidden: no C++ function of the implementation is a dynamic symbol of the product either
+    out = subprocess.check_output(["nm", "-D", "--defined-only", str(product_lib.LIB_PATH)]).decode()
+    leaked = [ln for ln in out.splitlines() if " T " in ln and " T eph_" not in ln and "__device_stub__" not in ln]
+    assert not leaked, leaked[:5]
+    assert product_lib._lib().eph_abi_version() == 2
+
+
+def test_integration_shims_use_only_declared_names():
+    """INTEGRATION.md writes the Rust shims (extern "C" block + trait impls) a maintainer would add; no Rust toolchain exists in the
+    image, so they have never been compiled -- what CAN be checked is that every eph_* function the shim text names is one
+    include/ephemeris_amd.h declares (missing #3)."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    header = (ROOT / "include" / "ephemeris_amd.h").read_text()
+    known = set(re.findall(r"\b(eph_[a-z0-9_]+)\b", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
+    used = set(re.findall(r"\b(eph_[a-z0-9_]+)\b", text))
+    prose = {"eph_oracle", "eph_prop_", "eph_craft_batch_", "eph_nbody_", "eph_solution_", "eph_debug", "eph_debug_"}   # file / prefix mentions
+    unknown = sorted(n for n in used - known - prose if not n.endswith("_"))
+    assert not unknown, f"INTEGRATION.md names functions the header does not declare: {unknown}"
+    fns = set(header_functions())
+    called = {n for n in used if n in fns}
+    assert len(called) >= 50                         # the shims bind most of the boundary (94 - 7 hooks = 87 functions)
+    assert "never been compiled" in text or "never met" in text     # section 0 says so in one line

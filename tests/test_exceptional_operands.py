@@ -1,4 +1,4 @@
-"""Host side of the error-bound note on inv_r3_seeded (csrc/device_math.h, step 5): the denominator p = RN(x RN(sqrt x))
+"""Host side of the error-bound note on inv_r3_seeded (csrc/pair_term.h, step 5): the denominator p = RN(x RN(sqrt x))
 never has an all-ones significand -- the one significand for which a reciprocal's closing residual step can end on a
 tie. No device needed: sqrt and multiply here are the IEEE operations the note talks about."""
 import numpy as np

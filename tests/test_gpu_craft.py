@@ -184,12 +184,12 @@ def test_hermite_eval_kernel(gpu):
             assert np.array_equal(bits(op[k]), bits(r[0])) and np.array_equal(bits(ov[k]), bits(r[1]))
 
 
-def test_controller_pow_is_the_same_correctly_rounded_value(gpu):
+def test_controller_pow_is_the_same_correctly_rounded_value(gpu, hooks):
     rng = np.random.default_rng(8)
     x = np.concatenate([np.exp(rng.uniform(np.log(1e-16), np.log(1e10), 200000)), [0.0, 1.0, np.inf, 1e-300, 5e-324]])
     for k in (4, 5, 7, 8):
         y = -(1.0 / k)
-        dev = gpu.debug_pow(x, y)
+        dev = hooks.debug_pow(x, y)
         ref = np.array([orc.cr_pow(v, y) for v in x])
         assert np.array_equal(bits(dev), bits(ref))
 
@@ -414,8 +414,8 @@ def test_thread_form_on_small_batches(gpu):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-def test_shared_reciprocal_division_is_ieee(gpu):
-    """k_craft_wave divides by a body's spline interval through one refined reciprocal per lane (device_math.h:
+def test_shared_reciprocal_division_is_ieee(gpu, hooks):
+    """k_craft_wave divides by a body's spline interval through one refined reciprocal per lane (pair_term.h:
     rcp_refined / div_refined / div_shared). Quotients must equal IEEE division -- the compiler's on the device and the
     host's -- for the intervals of the committed systems and random ones, numerators spanning the epochs and residues
     that occur plus adversarial values (exact multiples, one ulp around them, zero, tiny and huge values that must
@@ -434,7 +434,7 @@ def test_shared_reciprocal_division_is_ieee(gpu):
         a_parts.append(a)
         b_parts.append(np.full_like(a, b))
     a, b = np.concatenate(a_parts), np.concatenate(b_parts)
-    fast, ieee = gpu.debug_div(a, b)
+    fast, ieee = hooks.debug_div(a, b)
     with np.errstate(over="ignore", under="ignore"):
         want = a / b
     assert np.array_equal(bits(ieee), bits(want))             # device IEEE division == host division

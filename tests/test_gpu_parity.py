@@ -191,7 +191,7 @@ def test_least_squares_fit_kernel(gpu):
                 assert_same_bits(co[w], ref, f"fit degree {degree} window {w}")
 
 
-def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu):
+def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu, hooks):
     """The pair kernel's stripped sqrt / reciprocal sequences (no range-scaling wrappers) must give the IEEE
     correctly rounded results inside the guarded range: compared with the compiler's full expansions on the
     device AND with the host's sqrt/divide (x86 sqrtsd/divsd), over random mantissas across the whole guarded
@@ -205,19 +205,19 @@ def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu):
                         np.ldexp(np.nextafter(2.0, 0), np.arange(-300, 299))])
     # the operands whose denominator p = x sqrt(x) comes closest to the top of its binade, p = 2^(E+1) - k ulp: k = 1 (all
     # ones) is the one significand for which the reciprocal's closing residual step can fail, and it cannot occur
-    # (csrc/device_math.h, note on inv_r3_seeded); k = 2 .. 64 in every binade of the guarded range are here
+    # (csrc/pair_term.h, note on inv_r3_seeded); k = 2 .. 64 in every binade of the guarded range are here
     from exceptional_operands import top_of_binade_operands
     xt, kt = top_of_binade_operands(kmax=64)
     assert len(xt) > 15000 and kt.min() == 2
     x = np.concatenate([x, xt])
-    fast, ieee = gpu.debug_inv_r3(x)
+    fast, ieee = hooks.debug_inv_r3(x)
     host = 1.0 / (x * np.sqrt(x))
     ok = ~np.isnan(fast)
     assert ok.mean() > 0.999                       # only the range ends fall to the IEEE form
     assert_same_bits(ieee, host, "device IEEE expansions vs host")
     assert_same_bits(fast[ok], host[ok], "in-range sequences vs host")
     # the seed the error bound starts from: v_rsq_f64 within its documented 2^-23, h after the coupled step within 2^-45
-    y, h = gpu.debug_rsq(x[:500_000])
+    y, h = hooks.debug_rsq(x[:500_000])
     xl = x[:500_000].astype(np.longdouble)
     assert np.abs((y.astype(np.longdouble) * np.sqrt(xl) - 1).astype(np.float64)).max() < 2.0 ** -23
     assert np.abs((h.astype(np.longdouble) * 2 * np.sqrt(xl) - 1).astype(np.float64)).max() < 2.0 ** -45
@@ -225,21 +225,21 @@ def test_inrange_sqrt_and_reciprocal_sequences_are_ieee(gpu):
     # significand of ITS residual step: correctly rounded on this hardware in every binade
     b = np.ldexp(np.nextafter(2.0, 0), np.arange(-199, 199))
     for a in (1.0, 3.0, np.nextafter(2.0, 0), 1.0 + 2.0 ** -52):
-        qf, qi = gpu.debug_div(np.full_like(b, a), b)
+        qf, qi = hooks.debug_div(np.full_like(b, a), b)
         assert_same_bits(qi, a / b, "compiler division, all-ones denominator")
         assert_same_bits(qf, a / b, "shared-reciprocal division, all-ones denominator")
     # outside the guard the fast form is not used
     out = np.array([0.0, 1e-300, 1e300, np.inf, 5e-324])
-    f2, _ = gpu.debug_inv_r3(out)
+    f2, _ = hooks.debug_inv_r3(out)
     assert np.isnan(f2).all()
 
 
-def test_inrange_sequence_sweep_on_the_device(gpu):
+def test_inrange_sequence_sweep_on_the_device(gpu, hooks):
     """The same comparison over 2^33 device-generated operands (random mantissa, exponent uniform over the guarded range):
-    the in-range 1/(x*sqrt(x)) -- whose reciprocal is seeded from the square root's refinement, device_math.h -- must
+    the in-range 1/(x*sqrt(x)) -- whose reciprocal is seeded from the square root's refinement, pair_term.h -- must
     equal the compiler's IEEE expansion in every bit. (`git show d7efbfa:scripts/r02_twelfth.sh` ran 2.7e11 operands: no mismatch.)"""
     for seed in (1, 0xDEADBEEF):
-        bad, example = gpu.debug_inv_r3_sweep(seed, 1 << 32)
+        bad, example = hooks.debug_inv_r3_sweep(seed, 1 << 32)
         assert bad == 0, f"{bad} mismatches, e.g. operand bits {example:#x}"
 
 

@@ -38,7 +38,7 @@ rng = np.random.default_rng(k)
 for n in (40, 1000, 4096):
     pos, mu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
     assert same(ea.accel_eval(pos, mu), orc.gravity(pos, mu)), ("accel", n)
-# operands that leave the wrapper-free division of the division forms (device_math.h pair_quot): a zero separation
+# operands that leave the wrapper-free division of the division forms (pair_term.h pair_quot): a zero separation
 # component (numerator +-0), a massless source (mu = 0), numerators below 2^-200 -- lane-level IEEE fallback
 for n in (40, 300, 1000):
     epos, emu = rng.normal(size=(n, 3)) * 1e7, rng.uniform(1.0, 1e5, n)
@@ -183,7 +183,7 @@ def test_handles_of_different_orders_coexist(gpu):
         orc.set_pair_variant(0, native=True)
 
 
-def test_seeded_quotient_on_hard_cases(gpu):
+def test_seeded_quotient_on_hard_cases(gpu, hooks):
     """a / p, p = x sqrt(x), through r = RN(1/p) and Markstein's step against the device's IEEE division: numerators whose
     quotient lies k 2^-106 / p' from a rounding boundary (k = 1, 2, 3, 5), and random ones"""
     import math
@@ -202,10 +202,10 @@ def test_seeded_quotient_on_hard_cases(gpu):
                 xs.append(x)
                 as_.append(sgn * a)
     try:
-        gpu.set_pair_variant(4)
-        fast, ieee = gpu.debug_quot(np.array(xs), np.array(as_))
+        hooks.set_pair_variant(4)
+        fast, ieee = hooks.debug_quot(np.array(xs), np.array(as_))
     finally:
-        gpu.set_pair_variant(0)
+        hooks.set_pair_variant(0)
     assert _same(fast, ieee)
     host = np.array(as_) / np.array([dh.p_of(x) for x in xs])
     assert _same(ieee, host)

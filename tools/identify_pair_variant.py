@@ -9,7 +9,7 @@ Answers, in this order:
      every printed bit -- set it, and the library is bit-identical to the Rust binary at this boundary;
   2. otherwise a search over the grammar of tools/pairexpr.py (how |d|^2 is summed, r^3 as n2*sqrt / r*r*r / powf, reciprocal
      or division, where mu multiplies, fused multiply-adds): every tree that reproduces all printed bits is written out as the
-     Rust expression to add as an eighth order (csrc/device_math.h pair_den / pair_apply, oracle/eph_oracle.c point_mass_term);
+     Rust expression to add as an eighth order (csrc/pair_term.h pair_den / pair_apply, oracle/eph_oracle.c point_mass_term);
   3. otherwise the closest trees, with how many of the printed values they reproduce and the largest distance in ulp.
 Separately: whether `acceleration_at::<false>` follows the same order as `acceleration_paired`, and how the platform's powf
 relates to the correctly rounded value the library's step-size controller uses (integration/src/runge_kutta/mod.rs:238-239).
@@ -119,7 +119,8 @@ def main(argv):
                 print("  ---" + (" (platform-dependent libm pow)" if t.platform_dependent else ""))
                 for line in t.describe().splitlines():
                     print("  " + line)
-            print("add it as an eighth order in csrc/device_math.h (pair_den / pair_apply) and oracle/eph_oracle.c (point_mass_term).")
+            print("add it as an eighth order in csrc/pair_term.h (pair_den / pair_apply; kPairVariants in eph_internal.h, the table in "
+                  "dispatch.cpp, N_PAIR_VARIANTS in build.py) and oracle/eph_oracle.c (point_mass_term).")
             chosen = exact[0][2]
         else:
             print("no tree of the grammar reproduces every value; the closest:")

@@ -8,7 +8,7 @@ could plausibly use, as (n2 form, denominator form, application form) triples. P
 math.sqrt` are correctly rounded, so each tree evaluates to exactly the bits the Rust expression would give; `fma` is done in
 exact rational arithmetic. `libm pow` forms are platform dependent and marked so.
 
-The library's seven built orders (csrc/device_math.h, EPH_PAIR_VARIANT) are BUILT[k].  Used by tools/pair_probe.py (generates
+The library's seven built orders (csrc/pair_term.h, EPH_PAIR_VARIANT) are BUILT[k].  Used by tools/pair_probe.py (generates
 the probe set) and tools/identify_pair_variant.py (names the order a print-out from the real crate follows)."""
 import math
 import struct
