@@ -138,8 +138,11 @@ def craft_main(args):
     sysdir = ROOT / "tests/golden/systems/full_solar_system_2433282.5"
     s = load_system(sysdir)
     ship = load_ship(sysdir / "ships" / "Mars Transfer Ship.json")
+    # every rank rebuilds the MB-scale ephemeris itself, bit-identically (no broadcast); timed, max over ranks
+    t_eph0 = time.perf_counter()
     sol = ea.NBodyPropagator.from_system(s).propagate(s.epoch + (args.craft_days + 40.0) * 86400.0)
     eph = ea.Ephemeris(sol, s.mu)
+    eph_rebuild_s = time.perf_counter() - t_eph0
     from ephemeris_explorer_amd.workloads import craft_population, wave_divergence
     pos, vel, family = craft_population(args.population, args.craft, s, ship, order=args.population_order)
     lo, hi = shard_range(args.craft, rank, world)
@@ -192,6 +195,7 @@ def craft_main(args):
     elapsed = time.perf_counter() - t0
     assert table.shape == (args.craft, 7) and np.isfinite(table).all() and (table[:, 0] >= t_end).all()
     units, elapsed = reduce_timing(elapsed, steps_local, dist, device="cuda")
+    _, eph_rebuild_s = reduce_timing(eph_rebuild_s, 0, dist, device="cuda")
     if rank == 0:
         # per craft-attempt 13 evaluations x B bodies x (Horner + index + point mass) ~ 74 flop; 56 B knot
         # written per ACCEPTED step (the ephemeris rows stay in L1/L2)
@@ -224,6 +228,10 @@ def craft_main(args):
                                   "count": "13 stages x 32 bodies x 74 flop per attempt (SURVEY 8(d))"},
                          "note": "rank 0's shard; the sweep is f64-VALU bound (every ephemeris row is an L1 hit), see roofline.fp64"},
             "wall_over_kernel": elapsed / nsweeps / launch_s,
+            "ephemeris_rebuild_s": {"max_over_ranks": eph_rebuild_s, "days": args.craft_days + 40.0,
+                                    "what": "NBodyPropagator of the 32-body system to the sweep's horizon + 40 d and its device table, "
+                                            "done by EVERY rank before the timed region instead of one broadcast (includes the "
+                                            "process's first kernel launches)"},
         }
         out["fp64"] = dict(out["roofline"]["fp64"], bound="fp64_valu")
         # counters of the committed rocprofv3 passes of this kernel (scripts/prof_craft.sh), scaled by the attempts of THIS run;
