@@ -11,7 +11,7 @@ $T 150 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 $T 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --horizon 0 > $OUT/bench_20a.json 2>/dev/null     # the driver's form, twice:
 $T 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --horizon 0 > $OUT/bench_20b.json 2>/dev/null     # repeatability of the median block
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --horizon 0"
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --horizon 0 --no-other-configs"   # the headline kernels only under the profiler
 $T 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > $OUT/stats.log 2>&1
 $T 200 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $OUT -o pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1
 $T 200 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
@@ -28,15 +28,14 @@ $T 150 python bench.py --path fast-rsq > $OUT/bench_fast_rsq.json 2> $OUT/bench_
 $T 150 python bench.py --path f32-pairs > $OUT/bench_f32pairs_4096.json 2> $OUT/bench_f32pairs_4096.err
 $T 150 python bench.py --bodies 65536 --path f32-pairs --steps 20 --warmup 3 > $OUT/bench_f32pairs.json 2> $OUT/bench_f32pairs.err
 $T 150 python bench.py --workload craft --steps 3 > $OUT/bench_craft.json 2> $OUT/bench_craft.err
+$T 240 python bench.py --workload craft --craft 1048576 --steps 1 --warmup 1 > $OUT/bench_craft_1m.json 2> $OUT/bench_craft_1m.err     # SURVEY 8(d)'s full width
 $T 150 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 > $OUT/bench_craft_mixed.json 2> $OUT/bench_craft_mixed.err
-# the same population with craft i on lane / queue position i: the work-queue kernel, and round 2's static form
-EPH_CRAFT_SORT=0 $T 150 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 --no-cpu-baseline > $OUT/bench_craft_mixed_queue.json 2> $OUT/bench_craft_mixed_queue.err
-EPH_CRAFT_SORT=0 EPH_CRAFT_QUEUE=0 $T 150 python bench.py --workload craft --population mixed --craft 524288 --craft-days 2 --steps 2 --no-cpu-baseline > $OUT/bench_craft_mixed_static.json 2> $OUT/bench_craft_mixed_static.err
 $T 150 python bench.py --workload nbody-sharded --steps 20 --warmup 3 > $OUT/bench_sharded.json 2> $OUT/bench_sharded.err
+# configs[4] as stated (binary32 pair arithmetic on a target partition): two ranks sharing this device, direct-write transport
+EPH_BENCH_BACKEND=gloo $T 200 python bench.py --gpus 2 --workload nbody-sharded --path f32-pairs --transport peer --steps 20 --warmup 3 > $OUT/bench_f32pairs_sharded_gpus2_shared_device.json 2> $OUT/bench_f32pairs_sharded.err
 # N > 1 flows on this one-GPU box: bench.py launches its own ranks; they share the device (gloo for the timing reductions),
 # the sharded_4096 figure uses the direct-write transport between the two processes
 EPH_BENCH_BACKEND=gloo $T 150 python bench.py --gpus 2 --steps 50 --warmup 5 --prewarm 0.5 > $OUT/bench_gpus2_shared_device.json 2> $OUT/bench_gpus2.err
-EPH_BENCH_BACKEND=gloo $T 150 python bench.py --gpus 4 --steps 50 --warmup 5 --prewarm 0.5 > $OUT/bench_gpus4_shared_device.json 2> $OUT/bench_gpus4.err
 $T 150 python scripts/time_small.py > $OUT/time_small.txt 2>&1
 $T 150 python scripts/time_sizes.py 512 1024 2048 4096 8192 16384 > $OUT/time_sizes.txt 2>&1
 cd /tmp

@@ -75,7 +75,7 @@ bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
 
 
 for extra in ("bench_fast", "bench_fast_rsq", "bench_craft", "bench_sharded", "bench_f32pairs", "bench_f32pairs_4096",
-              "bench_craft_mixed", "bench_craft_mixed_queue", "bench_craft_mixed_static", "bench_craft_1m", "bench_gpus2_shared_device", "bench_gpus4_shared_device",
+              "bench_craft_mixed", "bench_craft_mixed_queue", "bench_craft_mixed_static", "bench_craft_1m", "bench_f32pairs_sharded_gpus2_shared_device", "bench_gpus2_shared_device", "bench_gpus4_shared_device",
               "bench_20a", "bench_20b"):                                                              # the round's other bench lines
     f = src / f"{extra}.json"
     if f.exists() and f.read_text().strip():
