@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+
 #include "host.h"
 
 namespace eph {
@@ -499,6 +501,23 @@ int NBodyIntegration::advance_many(NBodyIntegration *const *igs, int count, int6
 int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *sc) {
     EPH_HIP(hipSetDevice(device_));
     int st;
+    if (!xch_ && n_ > 0 && (pos || vel)) {
+        // one device: the two transposition kernels write straight into the pinned, device-mapped staging buffer -- one
+        // synchronisation, no copy-engine submissions (the reference's Integration reads the state after every step: 115-119 -> 63 us
+        // per step at N = 4096 with this, scripts/time_boundary.py)
+        const size_t nd = (size_t)n_;
+        PinnedStage stage(sizeof(double) * 6 * nd);
+        if (stage.status()) return stage.status();
+        double *h = static_cast<double *>(stage.host()), *d = static_cast<double *>(stage.dev());
+        if (pos && (st = launch_soa_to_aos(stream_, n_, npad_, Yslot(is_multistep_ ? cur_ : 0), d))) return st;
+        if (vel && (st = launch_soa_to_aos(stream_, n_, npad_, V_.p, d + 3 * nd))) return st;
+        EPH_HIP(hipStreamSynchronize(stream_));
+        if (pos) std::memcpy(pos, h, sizeof(double) * 3 * nd);
+        if (vel) std::memcpy(vel, h + 3 * nd, sizeof(double) * 3 * nd);
+        if (t) *t = time_;
+        if (sc) *sc = step_count();
+        return EPH_OK;
+    }
     if (pos && n_ > 0) {
         if ((st = launch_soa_to_aos(stream_, n_, npad_, Yslot(is_multistep_ ? cur_ : 0), stage_.p))) return st;
         if ((st = gather_stage())) return st;               // sharded: every rank contributes its bodies
@@ -530,29 +549,58 @@ int NBodyIntegration::get_acc(double *acc) {
     return xch_ ? xch_->poll_error() : EPH_OK;
 }
 
-// seam 1: SecondOrderODE::eval for NewtonianGravity, host buffers in and out
+// seam 1: SecondOrderODE::eval for NewtonianGravity, host buffers in and out.
+// The call's device buffers are grow-only scratch kept per device between calls (round 5): six hipMalloc / hipFree pairs per call --
+// each hipFree a device synchronisation -- were most of what a call cost at the app's sizes. One caller at a time per process (the
+// mutex); the scratch is ordinary library memory (eph_release_cached_memory does not touch it; it is a few MB at N = 65 536).
+namespace {
+struct AccelScratch {
+    DevBuf<Body4> P;
+    DevBuf<double> soa, init, out;
+    hipStream_t stream = nullptr;
+};
+std::mutex g_accel_mu;
+AccelScratch *accel_scratch(int device) {
+    static AccelScratch *table[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    if (!table[device]) table[device] = new AccelScratch();          // (lives as long as the process: destroying device memory at exit is the driver's job)
+    return table[device];
+}
+}  // namespace
 int accel_eval_device(int n, const double *pos, const double *mu, double *acc) {
     if (n < 0 || (n > 0 && (!pos || !mu || !acc))) return EPH_ERR_BAD_ARGUMENT;
     int st = check_device();
     if (st) return st;
     if (n == 0) return EPH_OK;
     const int npad = ((n + 63) / 64) * 64;
-    DevBuf<Body4> P;
-    DevBuf<double> aos, soa, init, out, dmu;
-    if ((st = P.alloc(npad)) || (st = aos.alloc((size_t)3 * npad)) || (st = soa.alloc((size_t)3 * npad)) ||
-        (st = init.alloc((size_t)3 * npad)) || (st = out.alloc((size_t)3 * npad)) || (st = dmu.alloc(npad)))
+    int device = 0;
+    EPH_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lk(g_accel_mu);
+    AccelScratch *x = accel_scratch(device);
+    if (!x) return EPH_ERR_BAD_ARGUMENT;
+    if ((st = x->P.reserve(npad)) || (st = x->soa.reserve((size_t)3 * npad)) || (st = x->init.reserve((size_t)3 * npad)) ||
+        (st = x->out.reserve((size_t)3 * npad)))
         return st;
-    hipStream_t s = nullptr;
-    EPH_HIP(hipMemcpyAsync(dmu.p, mu, sizeof(double) * n, hipMemcpyHostToDevice, s));
-    EPH_HIP(hipMemcpyAsync(aos.p, pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
-    if ((st = launch_aos_to_soa(s, n, npad, aos.p, soa.p))) return st;
-    if ((st = launch_pack(s, n, npad, soa.p, dmu.p, P.p))) return st;
-    EPH_HIP(hipMemcpyAsync(aos.p, acc, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
-    if ((st = launch_aos_to_soa(s, n, npad, aos.p, init.p))) return st;
-    if ((st = launch_accel(default_pair_variant(), s, n, npad, P.p, init.p, out.p))) return st;
-    if ((st = launch_soa_to_aos(s, n, npad, out.p, aos.p))) return st;
-    EPH_HIP(hipMemcpyAsync(acc, aos.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
+    if (!x->stream) EPH_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+    hipStream_t s = x->stream;
+    // Host buffers cross the bus through the process-wide pinned, device-mapped staging buffer (mem.cpp): the kernels read the
+    // caller's numbers and write the result THROUGH it, so a call is five launches and one synchronisation -- no copy-engine
+    // submissions (three pageable hipMemcpy in and one out were ~40 us of a 69 us call at 32 bodies: 29 us now; N = 4096: 177 us with the per-call
+    // allocations of round 4, 136 without them, 75-80 through the staging buffer -- of which the force kernel is 40)
+    const size_t nd = (size_t)n;
+    PinnedStage stage(sizeof(double) * 7 * nd);
+    if (stage.status()) return stage.status();
+    double *h = static_cast<double *>(stage.host()), *d = static_cast<double *>(stage.dev());
+    std::memcpy(h, mu, sizeof(double) * nd);
+    std::memcpy(h + nd, pos, sizeof(double) * 3 * nd);
+    std::memcpy(h + 4 * nd, acc, sizeof(double) * 3 * nd);
+    if ((st = launch_aos_to_soa(s, n, npad, d + nd, x->soa.p))) return st;
+    if ((st = launch_pack(s, n, npad, x->soa.p, d, x->P.p))) return st;
+    if ((st = launch_aos_to_soa(s, n, npad, d + 4 * nd, x->init.p))) return st;
+    if ((st = launch_accel(default_pair_variant(), s, n, npad, x->P.p, x->init.p, x->out.p))) return st;
+    if ((st = launch_soa_to_aos(s, n, npad, x->out.p, d + 4 * nd))) return st;
     EPH_HIP(hipStreamSynchronize(s));
+    std::memcpy(acc, h + 4 * nd, sizeof(double) * 3 * nd);
     return EPH_OK;
 }
 

@@ -8,10 +8,10 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 import ephemeris_explorer_amd as ea
 from ephemeris_explorer_amd.workloads import plummer
-for n in (4096, 65536):
-    pos, vel, mu = plummer(n) if n == 4096 else (np.random.default_rng(1).normal(size=(n, 3)), np.zeros((n, 3)), np.full(n, 1.0 / n))
+for n in (32, 4096, 65536):
+    pos, vel, mu = plummer(n) if n <= 4096 else (np.random.default_rng(1).normal(size=(n, 3)), np.zeros((n, 3)), np.full(n, 1.0 / n))
     ea.accel_eval(pos, mu)
-    reps = 200 if n == 4096 else 5
+    reps = 2000 if n == 32 else 200 if n == 4096 else 5
     t = time.time()
     for _ in range(reps):
         ea.accel_eval(pos, mu)
