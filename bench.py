@@ -401,6 +401,66 @@ def sharded_4096(dist, world, rank, steps, backend_is_nccl, usable=None):
     return out
 
 
+def configs4_f32_sharded(dist, world, rank, steps, backend_is_nccl, usable, bodies):
+    """BASELINE.json configs[4] AS STATED, measured by the default N > 1 command: ONE system of `bodies` (65 536) partitioned by target
+    body over the ranks with binary32 pair arithmetic (EPH_PATH_F32_PAIRS on a sharded handle: each rank converts its rows, one
+    all-gather of 16 B per body per step, f64 accumulation in the global slice order, f64 integrator), timed like the main line and
+    compared bit for bit with rank 0's own single-device f32 run of the same steps -- the reference has no f32 path
+    (ephemeris/src/propagators/nbody.rs:13,19), so that is what there is to compare with; the single-device time beside it is the
+    strong-scaling denominator."""
+    import numpy as np
+    import torch
+
+    import ephemeris_explorer_amd as ea
+    from ephemeris_explorer_amd.parallel import reduce_timing, shard_nbody
+    from ephemeris_explorer_amd.workloads import plummer
+    pos, vel, mu = plummer(bodies, seed=20260926)
+    out = {"ranks": world, "bodies": bodies, "bodies_per_gpu": bodies // world, "exchange_bytes_per_step": 16 * bodies,
+           "path": "f32-pairs on a target partition"}
+    order = [t for t in (["rccl", "peer"] if backend_is_nccl else ["peer"]) if usable is None or usable.get(t) == "ok"]
+    if not order:
+        out["error"] = "no transport passed the preflight"
+        return out
+    transport = order[0]
+    out["transport"] = transport
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    g = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+    g.set_path(ea.PATH_F32_PAIRS)
+    shard_nbody(g, dist, transport=transport, device="cuda" if backend_is_nccl else "cpu")
+    g.advance(12 + 3)
+    g.sync()
+
+    def block():
+        g.advance(steps)
+        g.sync()
+
+    blocks = timed_blocks(block, barrier, lambda t: reduce_timing(t, 0, dist, device="cuda")[1], blocks=3)
+    _, med = reduce_timing(blocks[len(blocks) // 2], 0, dist, device="cuda")
+    p, v, t, sc = g.state()                               # collective
+    total = 12 + 3 + steps * len(blocks)
+    out.update(ms_per_step=med / steps * 1e3, body_steps_per_s=bodies * steps / med, blocks=len(blocks), gathers=g.shard_info()[2])
+    if rank == 0:
+        one = ea.NBodyIntegration(pos, vel, mu, 0.0, H)
+        one.set_path(ea.PATH_F32_PAIRS)
+        one.advance(total - steps)
+        one.sync()
+        t0 = time.perf_counter()
+        one.advance(steps)
+        one.sync()
+        single = time.perf_counter() - t0
+        sp, sv = one.state()[:2]
+        out["bit_identical_to_single_device_f32"] = bool(np.array_equal(sp, p) and np.array_equal(sv, v))
+        out["single_device_ms_per_step"] = single / steps * 1e3
+        out["speedup_over_one_gpu"] = single / med
+    del g
+    barrier()
+    return out
+
+
 def other_variants(pos, vel, mu, steps=400):
     """us per step of the same system under the OTHER evaluation orders of the unpinned point-mass term (csrc/pair_term.h): the
     headline is measured on order `pair_variant` (0 unless EPH_PAIR_VARIANT says otherwise); should the Rust binary follow another
@@ -825,7 +885,7 @@ def main():
         # it has never met (instead of raising) must not cost the run its number. On expiry rank 0 prints the line with the
         # leg marked as timed out and every rank leaves without waiting for the others.
         import threading
-        limit = float(os.environ.get("EPH_BENCH_SHARDED_TIMEOUT", "240"))
+        limit = float(os.environ.get("EPH_BENCH_SHARDED_TIMEOUT", "420"))
 
         preflight = {}
         if rank == 0:
@@ -833,7 +893,8 @@ def main():
 
         def expired():
             if rank == 0:
-                out["sharded_4096"] = {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"}
+                out.setdefault("sharded_4096", {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"})
+                out.setdefault("configs4_f32_sharded", {"error": f"no result within {limit:.0f} s (EPH_BENCH_SHARDED_TIMEOUT)"})
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
@@ -844,15 +905,26 @@ def main():
             nccl = os.environ.get("EPH_BENCH_BACKEND", "nccl") == "nccl"
             transport_preflight(dist, world, rank, nccl, preflight)
             strong = sharded_4096(dist, world, rank, args.steps, nccl, usable=preflight)
+            # configs[4] as stated rides along when every rank has its own device (or when asked for: a rehearsal on a shared
+            # device would spend its time slicing the GPU between the ranks' 65 536-body start-ups)
+            c4_bodies = int(os.environ.get("EPH_BENCH_CONFIGS4_BODIES", "65536" if nccl else "0"))
+            c4 = None
+            if c4_bodies > 0 and c4_bodies % (64 * world) == 0:
+                if rank == 0:
+                    out["sharded_4096"] = dict(strong, replica_ms_per_step=elapsed / args.steps * 1e3)   # (kept if the next leg times out)
+                c4 = configs4_f32_sharded(dist, world, rank, args.steps, nccl, preflight, c4_bodies)
         except BaseException as e:                       # (a peer gone, a collective torn down: the group is not usable any more)
             if rank == 0:
-                out["sharded_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                out.setdefault("sharded_4096", {"error": f"{type(e).__name__}: {e}"[:300]})
+                out.setdefault("configs4_f32_sharded", {"error": f"{type(e).__name__}: {e}"[:300]})
                 print(json.dumps(out), flush=True)
             os._exit(0)
         dog.cancel()
         if rank == 0:
             strong["replica_ms_per_step"] = elapsed / args.steps * 1e3
             out["sharded_4096"] = strong
+            if c4 is not None:
+                out["configs4_f32_sharded"] = c4
     if rank == 0 and world == 1 and n == N_BODIES and not sharded and not fast and not args.no_other_configs:
         out["other_variants"] = other_variants(pos, vel, mu)
     if (rank == 0 and world == 1 and n == N_BODIES and not sharded and not fast and not args.no_cpu_baseline

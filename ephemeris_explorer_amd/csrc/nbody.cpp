@@ -542,6 +542,14 @@ int NBodyIntegration::get_acc(double *acc) {
     if (!acc) return EPH_ERR_BAD_ARGUMENT;
     if (n_ == 0) return EPH_OK;
     int st;
+    if (!xch_) {                                          // as get_state: through the pinned, device-mapped staging buffer
+        PinnedStage stage(sizeof(double) * 3 * (size_t)n_);
+        if (stage.status()) return stage.status();
+        if ((st = launch_soa_to_aos(stream_, n_, npad_, is_multistep_ ? Aslot(cur_) : ASR_.p, static_cast<double *>(stage.dev())))) return st;
+        EPH_HIP(hipStreamSynchronize(stream_));
+        std::memcpy(acc, stage.host(), sizeof(double) * 3 * (size_t)n_);
+        return EPH_OK;
+    }
     if ((st = launch_soa_to_aos(stream_, n_, npad_, is_multistep_ ? Aslot(cur_) : ASR_.p, stage_.p))) return st;
     if ((st = gather_stage())) return st;
     EPH_HIP(hipMemcpyAsync(acc, stage_.p, sizeof(double) * 3 * n_, hipMemcpyDeviceToHost, stream_));

@@ -60,6 +60,16 @@ def test_default_line_single_gpu():
     assert oc["configs3_craft_sweep"]["value"] > 1e7 and "craft" in oc["configs3_craft_sweep"]["workload"]
     assert oc["configs3_craft_sweep"]["fp64"]["frac"] > 0.05 and oc["configs3_craft_sweep"]["cpu_baseline"]["cores"] == 1
     assert oc["configs3_craft_sweep"]["wall_over_kernel"] < 1.2
+    # round 5: the shipping system's line has its own CPU baseline (same steps, one thread), parity and a latency roofline
+    c1 = oc["configs1_full_solar_system"]
+    assert c1["cpu_baseline"]["cores"] == 1 and c1["cpu_baseline"]["kind"] == "port" and c1["cpu_baseline"]["seconds"] > c1["seconds"]
+    assert c1["parity"] == {"max_abs_dpos": 0.0, "max_abs_dvel": 0.0, "steps": 1020000, "vs": "oracle (port)"}
+    assert 0.2 < c1["latency_roofline"]["frac"] < 1.0
+    # counter figures are printed only while their kernel's sources are the ones they were counted on
+    r = d["roofline"]
+    assert (r["traffic"] is None) == (r["traffic_stale"] is not None)
+    if r["traffic"] is not None:
+        assert r["traffic_profile_commit"] and r["fp64"]["valu_issue"]["frac"] > 0.3
 
 
 def test_two_ranks_replicas():
@@ -127,3 +137,27 @@ def test_two_ranks_one_sharded_system(transport):
     d = _run(["--workload", "nbody-sharded", "--bodies", "1024", "--transport", transport, "--steps", "5", "--warmup", "2",
               "--prewarm", "0"], 2)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_per_gpu"] == 512
+
+
+def test_two_ranks_f32_pairs_on_a_partition():
+    """BASELINE configs[4] as stated: `--workload nbody-sharded --path f32-pairs` (binary32 pair arithmetic on a target partition)"""
+    d = _run(["--workload", "nbody-sharded", "--path", "f32-pairs", "--bodies", "4096", "--transport", "peer", "--steps", "5",
+              "--warmup", "2", "--prewarm", "0.1"], 2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["path"] == "f32-pairs"
+    assert "all-gather of 65536 B" in d["config"]["parallelism"]            # 16 B per body
+    assert d["roofline"]["binding"] == "fp32_valu" and d["roofline"]["fp32"]["frac"] > 0
+
+
+def test_configs4_leg_of_the_default_multi_rank_line():
+    """With every rank on its own device the default `--gpus N` line also measures configs[4] as stated (65 536 bodies, f32 pairs,
+    partitioned) against rank 0's single-device f32 run; on this one-GPU box the leg is asked for explicitly at a small size."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(EPH_BENCH_BACKEND="gloo", EPH_BENCH_CONFIGS4_BODIES="4096")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--prewarm", "0"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c4 = d["configs4_f32_sharded"]
+    assert c4["ranks"] == 2 and c4["bodies"] == 4096 and c4["exchange_bytes_per_step"] == 16 * 4096 and c4["transport"] == "peer"
+    assert c4["bit_identical_to_single_device_f32"] is True and c4["ms_per_step"] > 0 and c4["single_device_ms_per_step"] > 0
+    assert d["sharded_4096"]["bit_identical_to_single_device"] is True
