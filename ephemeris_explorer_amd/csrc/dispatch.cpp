@@ -41,7 +41,7 @@ int set_default_pair_variant(int pv) {
 }
 
 // ---- the choice of form (measured on MI355X; us per step, QT12, order 0: workgroup form with 4 / 8 / 16 bodies | wave form) ------
-//   n = 512 9.0 | 9.05, 640 9.7 | 10.7, 1024 11.9 | 14.2, 1536 15.4 | 22.2, 2048 18.3 | 25.1, 4096 36.9 | 54, 8192 134 | 143,
+//   n = 512 9.0 | 9.05, 640 9.7 | 10.7, 1024 11.9 | 14.2, 1536 15.4 (14.8 six-wave) | 22.2, 2048 18.3 (17.7) | 25.1, 4096 36.9 | 54, 8192 134 | 143,
 //   16384 511 | 552, 65536 7864 | 8823 (profiles/r03_time_sizes.txt)
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
@@ -61,7 +61,10 @@ int lm_bodies_per_wave(int n) {
 static int wg_bodies(int nt) {
     static const int forced = env_int("EPH_WG_BODIES", 0);
     if (forced == 4 || forced == 8 || forced == 16) return forced;
-    return nt <= 1024 ? 4 : nt <= 2048 ? 8 : 16;
+    if (forced == 9) return 9;
+    // 9 = the six-wave 8-body workgroup (step_wg.hip): 13.2 / 14.8 / 16.3 / 17.7 us at 1280 / 1536 / 1792 / 2048 bodies against the
+    // twelve-wave 8-body form's 14.0 / 15.6 / 17.1 / 18.6 (round 5)
+    return nt <= 1024 ? 4 : nt <= 2048 ? 9 : 16;
 }
 // 1 = one wave per block (step_wave.hip), 2 = workgroup-specialised (step_wg.hip)
 static int force_kernel_kind(int nt, int requested) {
@@ -82,7 +85,8 @@ int launch_accel(int pv, hipStream_t s, int n, int npad, const Body4 *pos, const
     const KickDrift kd = kdp ? *kdp : KickDrift{nullptr, nullptr, 0.0, 0.0, nullptr};
     const int nt = hi - lo;                            // targets of this launch; the kernel choice follows them
     if (n <= 0 || nt <= 0) return EPH_OK;
-    if (force_kernel_kind(nt, kind) == 2) return t->accel_wg(s, wg_bodies(nt), n, npad, pos, acc_init, acc_out, lo, hi, kd);
+    // (the six-wave 8-body form exists for the step kernel only: the start-up's evaluations take the twelve-wave one)
+    if (force_kernel_kind(nt, kind) == 2) return t->accel_wg(s, wg_bodies(nt) == 9 ? 8 : wg_bodies(nt), n, npad, pos, acc_init, acc_out, lo, hi, kd);
     return t->accel_wave(s, lm_bodies_per_wave(nt), n, npad, pos, acc_init, acc_out, lo, hi, kd);
 }
 int launch_lm_step(int pv, hipStream_t s, const LmArgs &a) {

@@ -16,8 +16,9 @@
 //     25 KB LDS tile buffers: pair waves run one 128-source "big tile" ahead of the chain wave;
 //   * the tail wave (k_lm_step_wg) loads the 2 L history values while the others work, receives the new acceleration through
 //     LDS and does Cowell's velocity, the solout sample and the predictor;
-//   * 8- and 4-body workgroups for target counts that would leave CUs without a 16-body workgroup (<= 2048 / <= 1024 targets):
-//     one body per pair wave, the chain wave alone on SIMD 0; the 4-body form with TWO chain waves on alternate tiles.
+//   * 8- and 4-body workgroups for target counts that would leave CUs without a 16-body workgroup (<= 2048 / <= 1024 targets): the
+//     8-body one with SIX waves (four pair waves of two bodies, chain, tail; round 5 -- the twelve-wave form with one body per pair
+//     wave stays selectable, EPH_WG_BODIES=8), the 4-body form with one body per pair wave and TWO chain waves on alternate tiles.
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -54,10 +55,20 @@
 #define EPH_WG_DIAG_PATCH_ON 0
 #endif
 
+// The SIX-WAVE 8-body workgroup (round 5; `DUO` in the templates below, wb code 9 in the launcher): four pair waves x two bodies, a
+// chain wave, a tail wave, 76 KB of LDS. Built to put TWO workgroups on a CU at N = 4096 so that one's barrier drain is covered by
+// the other's arithmetic -- that lost badly (56.9 against 36.1 us: two chain waves and sixteen bodies of pair work share the four
+// SIMDs with no say in the placement) -- but ONE such workgroup per CU beats the twelve-wave 8-body form (one body per pair wave: a
+// bare dependent chain per wave) wherever that one was used: 1280 / 1536 / 1792 / 2048 bodies 13.2 / 14.8 / 16.3 / 17.7 against
+// 14.0 / 15.6 / 17.1 / 18.6 us per step, bit-identical. dispatch.cpp takes it for 1024 < targets <= 2048.
+// profiles/r05_step_kernel_evidence.md.
+
 namespace eph {
 namespace EPH_PV_NS {
 
 constexpr int kWgBodies = 16;
+constexpr int kDuoThreads = 64 * 6;                  // the duo form: waves 0-3 pair (two bodies each), 4 chain, 5 tail
+constexpr int kDuoTailWave = 5;
 constexpr int kWgChainWave = 4;                      // the chain wave (wave 4: lands on SIMD 0)
 constexpr int kWgTailWave = 8;                       // the step kernel's tail wave (SIMD 0 too)
 constexpr int kWgThreads = 64 * 12;
@@ -333,14 +344,20 @@ __device__ __forceinline__ double wg_force_split(PosPtr pos, int n, int i0, doub
 
 // Returns on chain-wave lane ch < 3 * WB: component ch % 3 of body i0 + ch / 3 (init + the reference-order sum over the other
 // bodies). Every thread of the workgroup must call it.
-template <int WB = kWgBodies, typename PosPtr>
+template <int WB = kWgBodies, bool DUO = false, typename PosPtr>
 __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double init, double *C, int tid) {
     constexpr int kRows = 3 * WB, kBuf = kRows * kRow;   // chains of the chain wave, doubles per LDS tile buffer
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = (n + kTile - 1) / kTile;
     const int tdiag = i0 / kTile;
+    if constexpr (DUO) {
+        static_assert(WB == 8, "the duo form is the 8-body workgroup with two bodies per pair wave");
+        const int w = __builtin_amdgcn_readfirstlane(wave);
+        if (w < 4) { wg_pair_wave_big<2>(pos, n, i0, 2 * w, C, lane, tiles, tdiag, kBuf); return 0.0; }
+        if (w == kDuoTailWave) { wg_idle_wave(tiles); return 0.0; }
+    } else
     if constexpr (wg_tile_split(WB)) return wg_force_split<WB>(pos, n, i0, init, C, tid);
-    if constexpr (WB != kWgBodies) {
+    else if constexpr (WB != kWgBodies) {
         // 8 / 4 bodies: one body per pair wave, SIMD 0 left to the chain wave (its cost per tile does not depend on how many of its
         // lanes carry a chain, so with one workgroup per CU the step takes the chain wave's time)
         const int body = wg_small_body<WB>(wave);
@@ -368,7 +385,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     double acc = init, accL = 0.0;
     double2 q[4][8];
     const int TB = big_count(tiles);
-    if constexpr (WB == kWgBodies) __builtin_amdgcn_s_setprio(3);
+    if constexpr (WB == kWgBodies || DUO) __builtin_amdgcn_s_setprio(3);
     __syncthreads();                                  // B_0: tiles 0 and 1 ready
     load_chunk(row, 0, q[0]);
     load_chunk(row, 1, q[1]);
@@ -393,7 +410,7 @@ __device__ __forceinline__ double wg_force(PosPtr pos, int n, int i0, double ini
     }
     return accL + acc;
 }
-constexpr int wg_lds_doubles(int wb) { return (wg_tile_split(wb) ? kWgSplitBufs * 3 * wb * kRow + 128 : kWgTileBufs * 3 * wb * kRow); }
+constexpr int wg_lds_doubles(int wb, bool duo = false) { return (wg_tile_split(wb) && !duo ? kWgSplitBufs * 3 * wb * kRow + 128 : kWgTileBufs * 3 * wb * kRow); }
 
 template <int WB = kWgBodies>
 __global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const Body4 *__restrict__ pos,
@@ -416,15 +433,16 @@ __global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const 
 // this launch evaluates its acceleration (reference-order all-pairs sum), recovers its velocity (Cowell), stores the solout sample
 // if one is due, predicts the positions of the NEXT level and publishes them (ring + packed ping-pong buffer) -- the kernel
 // boundary is the only grid-wide synchronisation a step needs.
-template <int L, int WB = kWgBodies>
-__global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
+template <int L, int WB = kWgBodies, bool DUO = false>
+__global__ void __launch_bounds__(DUO ? kDuoThreads : kWgThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_lm_step_wg(const LmArgs a) {
     constexpr int kRows = 3 * WB;
-    __shared__ __attribute__((aligned(16))) double C[wg_lds_doubles(WB)];
+    __shared__ __attribute__((aligned(16))) double C[wg_lds_doubles(WB, DUO)];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool chain_wave = (tid >> 6) == kWgChainWave;
     // the wave that does the integrator's work around the force; wave-uniform by construction, and told so (a scalar
     // branch keeps the history registers out of the other roles' live ranges)
-    const bool tail_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == kWgTailWave;
+    const bool tail_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == (DUO ? kDuoTailWave : kWgTailWave);
     const int i0 = a.lo + blockIdx.x * WB;
     const int cb = lane / 3, cc = lane % 3;
     const int my_i = i0 + cb;
@@ -445,7 +463,7 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
         // 37.55 vs 37.2 us per step at N = 4096 -- the early arithmetic takes issue slots from the pair wave and the chain wave
         // of this SIMD when they are the critical path, and the tail's work was not on it.)
         const int tiles = (a.n + kTile - 1) / kTile;
-        if constexpr (wg_tile_split(WB)) {
+        if constexpr (wg_tile_split(WB) && !DUO) {
             for (int t = 0; t <= tiles; ++t) __syncthreads();                             // one barrier per tile there
         } else {
             wg_idle_wave(tiles);
@@ -471,7 +489,7 @@ __global__ void __launch_bounds__(kWgThreads) k_lm_step_wg(const LmArgs a) {
             }
         }
     } else {
-        const double anew = wg_force<WB>(a.pos_cur, a.n, i0, 0.0, C, tid);
+        const double anew = wg_force<WB, DUO>(a.pos_cur, a.n, i0, 0.0, C, tid);
         if (chain_wave && lane < kRows) C[lane] = anew;    // every tile buffer is dead after the loop's last barrier
         __syncthreads();
     }
@@ -487,6 +505,13 @@ int accel_wg(hipStream_t s, int wb, int n, int npad, const Body4 *pos, const dou
     return launched("k_accel_wg");
 }
 int lm_step_wg(hipStream_t s, int wb, const LmArgs &a) {
+    if (wb == 9) {                                          // the six-wave 8-body form (dispatch.cpp: 1024 < targets <= 2048; EPH_WG_BODIES=9)
+        const dim3 grid((a.hi - a.lo + 7) / 8), block(kDuoThreads);
+        if (a.L == 12) hipLaunchKernelGGL((k_lm_step_wg<12, 8, true>), grid, block, 0, s, a);
+        else if (a.L == 13) hipLaunchKernelGGL((k_lm_step_wg<13, 8, true>), grid, block, 0, s, a);
+        else return EPH_ERR_UNSUPPORTED;
+        return launched("k_lm_step_wg (six waves)");
+    }
     const dim3 grid((a.hi - a.lo + wb - 1) / wb), block(kWgThreads);
     if (a.L == 12 && wb == 8) hipLaunchKernelGGL((k_lm_step_wg<12, 8>), grid, block, 0, s, a);
     else if (a.L == 13 && wb == 8) hipLaunchKernelGGL((k_lm_step_wg<13, 8>), grid, block, 0, s, a);
