@@ -57,3 +57,27 @@ def test_craft_populations():
     assert np.allclose(d_sun, np.linalg.norm(s.pos[earth] - s.pos[sun]), rtol=1e-12) and r[fam == 3].min() > 1e8
     _, _, fb = craft_population("mixed", 4096, s, ship, order="blocked")
     assert (np.diff(fb) >= 0).all() and np.bincount(fb).tolist() == [1024] * 4
+
+
+def test_counter_files_are_tied_to_their_kernel_sources():
+    """bench.py prints HBM traffic and VALU counts out of committed rocprofv3 passes; each counter file carries the sha256 of the
+    kernel sources it was counted on (workloads.profile_stamp, written by scripts/summarize_profile.py) and is used only while
+    they match (workloads.profile_is_current)."""
+    import json
+    from conftest import ROOT
+    from ephemeris_explorer_amd.workloads import PROFILE_SOURCES, profile_is_current, profile_stamp, source_hashes
+    for kind in PROFILE_SOURCES:
+        stamp = profile_stamp(kind)
+        assert set(stamp["source_sha256_16"]) == set(PROFILE_SOURCES[kind]) and stamp["source_sha256_16"] == source_hashes(kind)
+        assert profile_is_current(stamp, kind) == (True, None)
+        stale = {"source_sha256_16": dict(stamp["source_sha256_16"])}
+        first = PROFILE_SOURCES[kind][0]
+        stale["source_sha256_16"][first] = "0" * 16
+        ok, why = profile_is_current(stale, kind)
+        assert not ok and first in why
+    assert profile_is_current({}, "nbody") == (False, "the counter file carries no source hashes")
+    # the committed counter files of the step kernel and of the sweep kernel carry stamps (whether they are CURRENT is for the
+    # bench line to say: it drops the figures and names the file that changed)
+    for name, kind in (("traffic.json", "nbody"), ("traffic_craft.json", "craft")):
+        info = json.loads((ROOT / "profiles" / name).read_text())
+        assert set(info["source_sha256_16"]) == set(PROFILE_SOURCES[kind]) and info["profile_commit"]
