@@ -41,6 +41,8 @@ __device__ __forceinline__ void small_steps(Step &step, long long &s, long long 
                                               rot = (L - Ks + L - 1) % L, more = ++s <= nsteps, 0)
                                            : 0)...};
 }
+constexpr int kSmallThreads = 512;        // eight waves: one unordered pair per thread (496 at 32 bodies), the 3 n chains x 2 halves in waves 0-2
+constexpr int kSmallThreads2 = 256;       // the TWO form (gangs of more systems than CUs): four waves, two unordered pairs per thread
 constexpr int kSmallMaxN = 32;           // bodies (the reference's shipped system has exactly 32); 33..64 -> k_lm_persistent
 constexpr int kSmallRow = 32 + 2;        // doubles per row: 16-byte aligned rows an odd number of 16-byte units apart
 constexpr int kSmallRows = 3 * kSmallMaxN;
@@ -70,8 +72,8 @@ constexpr int kSmallRows = 3 * kSmallMaxN;
 // MULTI: one workgroup per SYSTEM, its arguments argv[blockIdx.x] (eph_nbody_advance_many / eph_prop_step_n_many: the
 // app runs a forward and a backward propagator concurrently, ephemeris_explorer/src/load/mod.rs:673-687, and ensembles
 // are independent too): K latency-bound single-workgroup systems advance in the time of one.
-template <int L, bool MULTI>
-__global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs *__restrict__ argv, long long nsteps) {
+template <int L, bool MULTI, bool TWO = false>
+__global__ void __launch_bounds__(TWO ? kSmallThreads2 : kSmallThreads) k_lm_small(const LmArgs a0, const LmArgs *__restrict__ argv, long long nsteps) {
     __shared__ __attribute__((aligned(16))) double U[kSmallRows][kSmallRow];    // [body*3 + comp][source]: sources after the body
     __shared__ __attribute__((aligned(16))) double Lw[kSmallRows][kSmallRow];   //                        sources before the body
     __shared__ __attribute__((aligned(32))) Body4 sP[kTile];
@@ -118,16 +120,26 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
         samp_left = samp_m ? samp_m - a.samp.phase[my_i] % samp_m : 0;
         samp_slot = a.samp.offset[my_i];
     }
-    // this thread's unordered pair (i < j), row-major over the strict upper triangle (n <= 32: at most 496 pairs for 512
-    // threads), decoded once. A thread without one runs pair (0, 1) again and stores nothing: straight-line code.
-    int pi0 = 0, pj0 = 1;
-    const bool live0 = tid < npairs && !(wg_flags & 1);    // (wg_flags: tuning switches, EPH_DEBUG_SMALL; 0 in normal runs)
-    if (tid < npairs) {
-        int i = 0;
-        while ((i + 1) * (2 * n - i - 2) / 2 <= tid) ++i;
-        pi0 = i;
-        pj0 = i + 1 + (tid - i * (2 * n - i - 1) / 2);
-    }
+    // this thread's unordered pair (i < j), row-major over the strict upper triangle (n <= 32: at most 496 pairs for 512 threads),
+    // decoded once. A slot without a pair runs pair (0, 1) again and stores nothing: straight-line code.
+    // TWO (round 5): pairs `tid` and `tid + 256` in FOUR waves instead of one pair per thread in eight. Measured for one system it is
+    // SLOWER (0.854 against 0.784 us per step at 32 bodies: one wave's two interleaved interactions cover less latency than two
+    // waves' one each) -- but two such workgroups fit a CU, and a gang of more systems than the chip has CUs gains a third
+    // (1024 systems: 2.63 against 3.51 us per step of the gang, 1.25e10 body-steps/s): lm_small_many takes it above 256 systems.
+    auto decode = [&](int q, int &pi, int &pj) {
+        pi = 0; pj = 1;
+        if (q < npairs) {
+            int i = 0;
+            while ((i + 1) * (2 * n - i - 2) / 2 <= q) ++i;
+            pi = i;
+            pj = i + 1 + (q - i * (2 * n - i - 1) / 2);
+        }
+    };
+    int pi0, pj0, pi1 = 0, pj1 = 1;
+    decode(tid, pi0, pj0);
+    if constexpr (TWO) decode(tid + kSmallThreads2, pi1, pj1);
+    const bool live0 = tid < npairs && !(wg_flags & 1);    // (wg_flags: tuning switches, EPH_DEBUG_SMALL: 1 no pair stores, 4 accounting; 0 in normal runs)
+    const bool live1 = TWO && tid + kSmallThreads2 < npairs && !(wg_flags & 1);
     __syncthreads();
 
     // Every thread runs the pair arithmetic: straight-line code, so the scheduler interleaves it with the predictor's
@@ -138,22 +150,35 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
     // `before_branch()` runs between the wrapper-free results and the (rare, wave-uniform) branch that redoes them in the full
     // IEEE form: the owner waves pin the predictor's position chain there, so that it is emitted in the SAME block as the
     // sequences and fills their issue gaps; without it the compiler places the chain behind the stores (round 5, read off the ISA).
-    auto pair = [&](const double4 &vi, const double4 &vj, auto &&before_branch) {
+    auto pair = [&](const double4 &vi, const double4 &vj, const double4 &wi, const double4 &wj, auto &&before_branch) {
         const double dx = vj.x - vi.x, dy = vj.y - vi.y, dz = vj.z - vi.z;
         const double n2 = dx * dx + dy * dy + dz * dz;
-        double ax, ay, az, bx, by, bz;
+        double ex = 0.0, ey = 0.0, ez = 0.0, m2 = 1.0;
+        if constexpr (TWO) { ex = wj.x - wi.x; ey = wj.y - wi.y; ez = wj.z - wi.z; m2 = ex * ex + ey * ey + ez * ez; }
+        double ax, ay, az, bx, by, bz, cx = 0.0, cy = 0.0, cz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
         {
             const PairDen den = pair_den<true>(n2);
             pair_apply<true>(den, dx, dy, dz, vj.w, ax, ay, az);
             pair_apply<true>(den, -dx, -dy, -dz, vi.w, bx, by, bz);
+            if constexpr (TWO) {
+                const PairDen den1 = pair_den<true>(m2);
+                pair_apply<true>(den1, ex, ey, ez, wj.w, cx, cy, cz);
+                pair_apply<true>(den1, -ex, -ey, -ez, wi.w, gx, gy, gz);
+            }
         }
         // the wrapper-free results exist HERE (otherwise the compiler sinks them into the else-side of the branch below)
         asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz));
+        if constexpr (TWO) asm volatile("" : "+v"(cx), "+v"(cy), "+v"(cz), "+v"(gx), "+v"(gy), "+v"(gz));
         before_branch();
-        if (__builtin_amdgcn_ballot_w64(!in_range(n2)) != 0) {
+        if (__builtin_amdgcn_ballot_w64(!(in_range(n2) && (!TWO || in_range(m2)))) != 0) {
             const PairDen den = pair_den<false>(n2);
             pair_apply<false>(den, dx, dy, dz, vj.w, ax, ay, az);
             pair_apply<false>(den, -dx, -dy, -dz, vi.w, bx, by, bz);
+            if constexpr (TWO) {
+                const PairDen den1 = pair_den<false>(m2);
+                pair_apply<false>(den1, ex, ey, ez, wj.w, cx, cy, cz);
+                pair_apply<false>(den1, -ex, -ey, -ez, wi.w, gx, gy, gz);
+            }
         }
         if (live0) {
             U[pi0 * 3 + 0][pj0] = ax;
@@ -162,6 +187,14 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
             Lw[pj0 * 3 + 0][pi0] = bx;
             Lw[pj0 * 3 + 1][pi0] = by;
             Lw[pj0 * 3 + 2][pi0] = bz;
+        }
+        if (live1) {
+            U[pi1 * 3 + 0][pj1] = cx;
+            U[pi1 * 3 + 1][pj1] = cy;
+            U[pi1 * 3 + 2][pj1] = cz;
+            Lw[pj1 * 3 + 0][pi1] = gx;
+            Lw[pj1 * 3 + 1][pi1] = gy;
+            Lw[pj1 * 3 + 2][pi1] = gz;
         }
     };
 
@@ -197,6 +230,8 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
         double q2[L], s1;                              // (set and read in the owner waves only)
         // the pair's two bodies: the reads are in flight under the products below
         const double4 vi = *reinterpret_cast<const double4 *>(&sP[pi0]), vj = *reinterpret_cast<const double4 *>(&sP[pj0]);
+        double4 wi = vi, wj = vj;
+        if constexpr (TWO) { wi = *reinterpret_cast<const double4 *>(&sP[pi1]); wj = *reinterpret_cast<const double4 *>(&sP[pj1]); }
         if (owner_wave) {
             double p1[L];
             p1[0] = ynew * wa[0];
@@ -207,13 +242,13 @@ __global__ void __launch_bounds__(512) k_lm_small(const LmArgs a0, const LmArgs 
 #pragma unroll
             for (int j = 0; j < L; ++j) s1 = s1 + p1[j];
             // ---- pairs (i < j): one reciprocal cube per unordered pair, both directed contributions
-            pair(vi, vj, [&]() {
+            pair(vi, vj, wi, wj, [&]() {
                 asm volatile("" : "+v"(s1));           // computed HERE, among the sequences
 #pragma unroll
                 for (int j = 1; j < L; ++j) asm volatile("" : "+v"(q2[j]));
             });
         } else {
-            pair(vi, vj, []() {});
+            pair(vi, vj, wi, wj, []() {});
         }
         if constexpr (EPH_SMALL_ACCOUNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SMALL_TICK(1);
@@ -368,15 +403,20 @@ int debug_wg_cycles(long long *out) {
     return EPH_OK;
 }
 int lm_small(hipStream_t s, const LmArgs &a, int64_t nsteps) {
-    if (a.L == 12) hipLaunchKernelGGL((k_lm_small<12, false>), dim3(1), dim3(512), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
-    else if (a.L == 13) hipLaunchKernelGGL((k_lm_small<13, false>), dim3(1), dim3(512), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
+    if (a.L == 12) hipLaunchKernelGGL((k_lm_small<12, false>), dim3(1), dim3(kSmallThreads), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
+    else if (a.L == 13) hipLaunchKernelGGL((k_lm_small<13, false>), dim3(1), dim3(kSmallThreads), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
     else return EPH_ERR_UNSUPPORTED;
     return launched("k_lm_small");
 }
 int lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps) {
     const LmArgs none{};
-    if (L == 12) hipLaunchKernelGGL((k_lm_small<12, true>), dim3((unsigned)count), dim3(512), 0, s, none, argv_dev, (long long)nsteps);
-    else if (L == 13) hipLaunchKernelGGL((k_lm_small<13, true>), dim3((unsigned)count), dim3(512), 0, s, none, argv_dev, (long long)nsteps);
+    // more systems than CUs: the four-wave form, two workgroups per CU (1024 systems 2.63 against 3.51 us per step of the gang)
+    static const int cus = [] { int dev = 0, c = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
+    const bool two = count > cus;
+    if (L == 12 && two) hipLaunchKernelGGL((k_lm_small<12, true, true>), dim3((unsigned)count), dim3(kSmallThreads2), 0, s, none, argv_dev, (long long)nsteps);
+    else if (L == 13 && two) hipLaunchKernelGGL((k_lm_small<13, true, true>), dim3((unsigned)count), dim3(kSmallThreads2), 0, s, none, argv_dev, (long long)nsteps);
+    else if (L == 12) hipLaunchKernelGGL((k_lm_small<12, true>), dim3((unsigned)count), dim3(kSmallThreads), 0, s, none, argv_dev, (long long)nsteps);
+    else if (L == 13) hipLaunchKernelGGL((k_lm_small<13, true>), dim3((unsigned)count), dim3(kSmallThreads), 0, s, none, argv_dev, (long long)nsteps);
     else return EPH_ERR_UNSUPPORTED;
     return launched("k_lm_small (gang)");
 }

@@ -94,3 +94,31 @@ def test_step_n_many_builds_the_same_ephemerides(gpu, count):
     so, sg = o.take_solution(), g1.take_solution()
     for b in range(s.n):
         assert sg.info(b) == so.info(b) and _same(sg.coeffs(b)[0], so.coeffs(b)[0])
+
+
+def test_gang_larger_than_the_chip(gpu):
+    """More systems than the chip has CUs take the four-wave form of k_lm_small (two unordered pairs per thread, two workgroups
+    per CU: step_small.hip, round 5): 300 systems -- the 32-body system forward and backward with different steps, the 10- and the
+    3-body one -- in one launch, every member bit-identical to its own separate advance, a few of them to the restatement."""
+    full, simple, sem = (load_system(n) for n in ("full_solar_system_2433282.5", "simple_solar_system_2433282.5",
+                                                   "sun_earth_moon_2433282.5"))
+
+    def spec(i):
+        s = (full, simple, sem)[i % 3]
+        return s, s.dt * (1.0 + 0.001 * (i // 3)) * (1 if i % 2 == 0 else -1)
+    K = 300
+    gang = [gpu.NBodyIntegration(s.pos, s.vel, s.mu, s.epoch, h) for s, h in map(spec, range(K))]
+    gpu.advance_many(gang, 12)
+    gpu.advance_many(gang, 700)
+    gpu.advance_many(gang, 1)
+    for i in (0, 1, 2, 3, 150, 257, 298, 299):
+        s, h = spec(i)
+        solo = gpu.NBodyIntegration(s.pos, s.vel, s.mu, s.epoch, h)
+        solo.advance(713)
+        (p, v, t, c), (p0, v0, t0, c0) = gang[i].state(), solo.state()
+        assert t == t0 and c == c0 and _same(p, p0) and _same(v, v0) and _same(gang[i].acc(), solo.acc()), i
+    for i in (0, 1, 299):
+        s, h = spec(i)
+        o = orc.NBody(s.pos, s.vel, s.mu, s.epoch, h)
+        assert o.advance(713) == 0
+        assert _same(gang[i].state()[0], o.state()[0]) and _same(gang[i].state()[1], o.state()[1]), i
