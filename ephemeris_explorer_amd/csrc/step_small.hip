@@ -157,6 +157,8 @@ __global__ void __launch_bounds__(TWO ? kSmallThreads2 : kSmallThreads) k_lm_sma
         if constexpr (TWO) { ex = wj.x - wi.x; ey = wj.y - wi.y; ez = wj.z - wi.z; m2 = ex * ex + ey * ey + ez * ez; }
         double ax, ay, az, bx, by, bz, cx = 0.0, cy = 0.0, cz = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
         {
+            // (TWO: the compiler emits the two reciprocal-cube sequences one after the other; writing them stage by stage with the
+            // order pinned, as pair_finish_staged does for the workgroup kernel, was measured: no change, 0.87 us either way)
             const PairDen den = pair_den<true>(n2);
             pair_apply<true>(den, dx, dy, dz, vj.w, ax, ay, az);
             pair_apply<true>(den, -dx, -dy, -dz, vi.w, bx, by, bz);
@@ -402,8 +404,16 @@ int debug_wg_cycles(long long *out) {
 #endif
     return EPH_OK;
 }
+// EPH_SMALL_FORM=4|8 forces the four- / eight-wave form (tuning, tests); default: eight for one system, lm_small_many decides by count
+static int small_form() {
+    static const int f = [] { const char *e = getenv("EPH_SMALL_FORM"); return e ? atoi(e) : 0; }();
+    return f;
+}
 int lm_small(hipStream_t s, const LmArgs &a, int64_t nsteps) {
-    if (a.L == 12) hipLaunchKernelGGL((k_lm_small<12, false>), dim3(1), dim3(kSmallThreads), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
+    const bool two = small_form() == 4;
+    if (a.L == 12 && two) hipLaunchKernelGGL((k_lm_small<12, false, true>), dim3(1), dim3(kSmallThreads2), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
+    else if (a.L == 13 && two) hipLaunchKernelGGL((k_lm_small<13, false, true>), dim3(1), dim3(kSmallThreads2), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
+    else if (a.L == 12) hipLaunchKernelGGL((k_lm_small<12, false>), dim3(1), dim3(kSmallThreads), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
     else if (a.L == 13) hipLaunchKernelGGL((k_lm_small<13, false>), dim3(1), dim3(kSmallThreads), 0, s, a, (const LmArgs *)nullptr, (long long)nsteps);
     else return EPH_ERR_UNSUPPORTED;
     return launched("k_lm_small");
@@ -412,7 +422,7 @@ int lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64
     const LmArgs none{};
     // more systems than CUs: the four-wave form, two workgroups per CU (1024 systems 2.63 against 3.51 us per step of the gang)
     static const int cus = [] { int dev = 0, c = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return c; }();
-    const bool two = count > cus;
+    const bool two = small_form() ? small_form() == 4 : count > cus;
     if (L == 12 && two) hipLaunchKernelGGL((k_lm_small<12, true, true>), dim3((unsigned)count), dim3(kSmallThreads2), 0, s, none, argv_dev, (long long)nsteps);
     else if (L == 13 && two) hipLaunchKernelGGL((k_lm_small<13, true, true>), dim3((unsigned)count), dim3(kSmallThreads2), 0, s, none, argv_dev, (long long)nsteps);
     else if (L == 12) hipLaunchKernelGGL((k_lm_small<12, true>), dim3((unsigned)count), dim3(kSmallThreads), 0, s, none, argv_dev, (long long)nsteps);
