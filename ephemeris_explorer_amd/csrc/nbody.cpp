@@ -562,9 +562,26 @@ int NBodyIntegration::get_acc(double *acc) {
 // each hipFree a device synchronisation -- were most of what a call cost at the app's sizes. One caller at a time per process (the
 // mutex); the scratch is ordinary library memory (eph_release_cached_memory does not touch it; it is a few MB at N = 65 536).
 namespace {
+// grow-only device block taken from the driver directly: it lives as long as the process, so it must not count as a live allocation
+// of the library's block cache (mem.cpp releases the cache with the LAST counted allocation on a device)
+template <typename T>
+struct RawScratch {
+    T *p = nullptr;
+    size_t count = 0;
+    int reserve(size_t n) {
+        if (n <= count) return EPH_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; count = 0;
+        const size_t want = n + n / 2;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; set_last_error("hipMalloc (seam 1 scratch)", e); return e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_HIP; }
+        count = want;
+        return EPH_OK;
+    }
+};
 struct AccelScratch {
-    DevBuf<Body4> P;
-    DevBuf<double> soa, init, out;
+    RawScratch<Body4> P;
+    RawScratch<double> soa, init, out;
     hipStream_t stream = nullptr;
 };
 std::mutex g_accel_mu;

@@ -668,3 +668,54 @@ def test_body_order_of_the_acceleration_sum(gpu):
     for bad in (np.zeros(s.n, dtype=np.int32), np.arange(s.n, dtype=np.int32) + 1):
         with pytest.raises(gpu.EphemerisError):
             b.set_body_order(bad)
+
+
+def test_block_cache_follows_the_handles(gpu):
+    """csrc/mem.cpp: device blocks of >= 64 MiB (the knot slabs of a spacecraft batch) are kept for the next batch of the same shape,
+    per device and bounded; a reused block is cleared; eph_release_cached_memory returns them -- and when the library's LAST
+    allocation on the device goes, so does the cache (a process that shares the GPU with another allocator is not left holding it).
+    Runs in a child process: the accounting is process-wide and other tests' handles are alive in this one."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = r'''
+import gc, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import ephemeris_explorer_amd as ea
+from ephemeris_explorer_amd.systems import load_system, load_ship
+root = sys.argv[1]
+s = load_system(root + "/tests/golden/systems/simple_solar_system_2433282.5")
+ship = load_ship(root + "/tests/golden/systems/full_solar_system_2433282.5/ships/Mars Transfer Ship.json")
+prop = ea.NBodyPropagator.from_system(s)
+sol = prop.propagate(s.epoch + 30 * 86400.0)
+eph = ea.Ephemeris(sol, s.mu)
+n = 20000                                                  # 20000 craft x 600 knots x 8 B = 96 MB per knot row set: cached size class
+pos = ship.pos + np.random.default_rng(1).normal(0.0, 10.0, size=(n, 3))
+vel = np.repeat(ship.vel[None], n, 0)
+def sweep():
+    b = ea.SpacecraftBatch(eph, ship.start, pos, vel, "DormandPrince54", max_knots=600)
+    b.propagate(ship.start + 3600.0)
+    st = b.status()
+    assert (st["status"] == 0).all()
+    kt, ky = b.knot_slabs(0, int(st["nknots"].max()) + 2)   # two rows beyond the last knot of every craft
+    return st["nknots"].copy(), kt, ky
+nk1, kt1, ky1 = sweep()
+gc.collect()
+nk2, kt2, ky2 = sweep()                                      # takes the first batch's blocks out of the cache
+assert np.array_equal(nk1, nk2)
+last = int(nk2.max())
+assert np.array_equal(kt1[:last], kt2[:last]) and np.array_equal(ky1[:last], ky2[:last])
+assert not kt2[last:].any() and not ky2[last:].any(), "rows beyond nknots of a REUSED block must be clear, not the previous batch's"
+gc.collect()
+held = ea.release_cached_memory()
+assert held >= 64 << 20, held                               # the ephemeris is still alive: the batch's blocks were being kept
+assert ea.release_cached_memory() == 0
+sweep()
+del prop, sol, eph
+gc.collect()
+assert ea.release_cached_memory() == 0, "the cache must have gone with the library's last allocation on the device"
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", script, str(ROOT)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
