@@ -116,10 +116,11 @@ int launch_lm_small_many(int pv, hipStream_t s, const LmArgs *argv_dev, int coun
     if (count <= 0 || nsteps <= 0) return EPH_OK;
     return t->lm_small_many(s, argv_dev, count, L, nsteps);
 }
-// slices of the fast path: enough waves for two per SIMD (2048), a multiple of the workgroup's 4, at least 8, at most 64
-int fast_slices(int npad) {
+// slices of the fast path: enough waves for two per SIMD (2048; FOUR for the rsq form, whose shorter dependent chains want them), a
+// multiple of the workgroup's 4, at least 8, at most 64
+int fast_slices(int npad, bool approx) {
     static const int forced = env_int("EPH_FAST_SLICES", 0);
-    int S = forced > 0 ? forced : 2048 / (npad / 64);
+    int S = forced > 0 ? forced : (approx ? 4096 : 2048) / (npad / 64);
     S = std::max(8, std::min(64, S));            // (8 rather than 4 slices at 65 536 bodies, eight waves per SIMD: 1.17 -> 1.13 ms on the f32 path)
     return (S + 3) / 4 * 4;
 }
@@ -133,7 +134,7 @@ int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial,
     if (conv_cnt < 0) { conv_lo = 0; conv_cnt = a.npad; }
     if (f32_stage != 1 && a.hi <= a.lo) return EPH_OK;                  // a rank whose slice is all padding
     static const int unroll = env_int("EPH_FAST_UNROLL", 4) == 8 ? 8 : 4;
-    return t->lm_step_fast(s, a, partial, fast_slices(a.npad), unroll, approx, posf, f32_stage, conv_lo, conv_cnt);
+    return t->lm_step_fast(s, a, partial, fast_slices(a.npad, approx), unroll, approx, posf, f32_stage, conv_lo, conv_cnt);
 }
 int launch_craft(int pv, hipStream_t s, const CraftArgs &a, const CraftLaunch &how) {
     const PairKernels *t = table(pv);

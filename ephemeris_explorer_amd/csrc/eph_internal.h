@@ -106,7 +106,7 @@ int launch_lm_persistent(int pv, hipStream_t s, const LmArgs &a, int64_t nsteps)
 constexpr int kGangMaxN = 32;
 int launch_lm_small_many(int pv, hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);
 // opt-in fast path: slice-parallel partial sums combined in slice order (NOT the reference's summation order)
-int fast_slices(int npad);                                          // S
+int fast_slices(int npad, bool approx = false);                     // S (the rsq form takes twice the waves)
 // posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body. f32_stage 0: the whole step; 1: only the binary32 copy of rows
 // [conv_lo, conv_lo + conv_cnt) (conv_cnt < 0: all); 2: the step on a copy that is complete already (a sharded handle gathers between)
 int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr, int f32_stage = 0,

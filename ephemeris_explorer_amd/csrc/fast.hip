@@ -92,6 +92,49 @@ __device__ __forceinline__ void fast_slice(const __attribute__((address_space(4)
     }
 }
 
+// EPH_PATH_FAST_RSQ, round 5: the path that promises neither the reference's order NOR its IEEE operations is written the way an
+// unconstrained kernel would be -- every multiply-add fused, 1 / r^3 from v_rsq_f64 and ONE third-order correction
+// (e = 1 - n2 y^2; y <- y (1 + e/2 + 3 e^2/8): seed error 2^-23 -> 2^-68), 17 f64 operations + the transcendental per
+// interaction instead of 25 + 1 unfused. (Round 4's form measured 28.3 us per step at N = 4096 against the exact path's 36: "what
+// bit-exactness costs" looked like 20 %; it flattered the exact path)
+template <bool DIAG, bool PAD, int U>
+__device__ __forceinline__ void fast_slice_rsq(const __attribute__((address_space(4))) Body4 *src, int j0, int j1, int n, int i,
+                                               double xi, double yi, double zi, double &ax, double &ay, double &az) {
+    auto fetch = [&](int j, Body4 (&p)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { p[u].x = src[j + u].x; p[u].y = src[j + u].y; p[u].z = src[j + u].z; p[u].mu = src[j + u].mu; }
+    };
+    Body4 nxt[U];
+    fetch(j0, nxt);
+    for (int j = j0; j < j1; j += U) {                 // j1 - j0 is a multiple of U; sources >= n are padding
+        Body4 pj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pj[u] = nxt[u];
+        fetch(min(j + U, j1 - U), nxt);                // next group's scalar loads in flight under this one's arithmetic
+        double dx[U], dy[U], dz[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dx[u] = pj[u].x - xi; dy[u] = pj[u].y - yi; dz[u] = pj[u].z - zi;
+            const double n2 = __builtin_fma(dz[u], dz[u], __builtin_fma(dy[u], dy[u], dx[u] * dx[u]));
+            const double y0 = __builtin_amdgcn_rsq(n2);
+            const double e = __builtin_fma(-(n2 * y0), y0, 1.0);
+            const double c = __builtin_fma(e, 0.375, 0.5) * e;
+            y[u] = __builtin_fma(y0, c, y0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double sc = (pj[u].mu * y[u]) * (y[u] * y[u]);
+            if (DIAG) sc = (j + u == i) ? 0.0 : sc;      // the body itself (n2 = 0 -> NaN): not a source
+            if (PAD && j + u >= n) continue;            // padding rows (wave-uniform; only the slice that reaches past n is compiled with it)
+            ax = __builtin_fma(dx[u], sc, ax);
+            ay = __builtin_fma(dy[u], sc, ay);
+            az = __builtin_fma(dz[u], sc, az);
+        }
+        // (pinning the prefetched group at the end of the trip -- the compiler sinks its scalar loads to the top of the next one --
+        // was measured: no change, four waves per SIMD cover the scalar-cache latency)
+    }
+}
+
 // partial: [S][3][npad] scratch. Two launches per step: the kernel boundary is the release/acquire between the
 // slice sums and their combination. (First version: one launch with a per-block arrival ticket, the last workgroup
 // of a block combining -- measured 66 / 96 / 166 us per step at 16 / 32 / 64 slices, N = 4096: the agent-scope
@@ -111,8 +154,17 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npa
     const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (j0 < j1) {
-        if (j0 < block * 64 + 64 && j1 > block * 64) fast_slice<true, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
-        else fast_slice<false, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        const bool diag = j0 < block * 64 + 64 && j1 > block * 64;
+        if constexpr (APPROX) {
+            const bool pad = j1 > n;                    // wave-uniform
+            if (diag && pad) fast_slice_rsq<true, true, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else if (diag) fast_slice_rsq<true, false, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else if (pad) fast_slice_rsq<false, true, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else fast_slice_rsq<false, false, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        } else {
+            if (diag) fast_slice<true, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else fast_slice<false, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        }
     }
     double *pp = partial + (size_t)slice * 3 * npad + i;
     pp[0] = ax;
@@ -224,14 +276,16 @@ __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, cons
     }
     // all loads of a group of 16 slices in flight before the ordered adds (one load per add would pay the memory
     // latency S times: measured 11 us for this kernel at S = 32)
+    // EVERY slice's load in flight before the first ordered add (S <= kFastMaxSlices; groups of 16 behind one another paid the
+    // memory latency S / 16 times: 7.3 us for this kernel at S = 64, round 5)
     double anew = 0.0;
-    for (int base = 0; base < S; base += 16) {
-        double pv[16];
+    {
+        double pv[kFastMaxSlices];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pv[u] = base + u < S ? partial[(size_t)(base + u) * lvl + off] : 0.0;
+        for (int u = 0; u < kFastMaxSlices; ++u) pv[u] = u < S ? partial[(size_t)u * lvl + off] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (base + u < S) anew = anew + pv[u];
+        for (int u = 0; u < kFastMaxSlices; ++u)
+            if (u < S) anew = anew + pv[u];
     }
     a.A[(size_t)a.cur * lvl + off] = anew;
     {
@@ -257,7 +311,7 @@ __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, cons
 int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unroll, bool approx, float *posf, int f32_stage,
                  int conv_lo, int conv_cnt) {
     int slice_len = (a.npad + S - 1) / S;
-    const int un = posf ? kF32Group : approx ? 4 : unroll;
+    const int un = posf ? kF32Group : approx ? 4 : unroll;   // (8 sources per trip spill 149 SGPRs: the prefetched group is 64 of the 102)
     slice_len = (slice_len + un - 1) / un * un;
     const int block0 = a.lo / 64, nblocks = (a.hi - a.lo + 63) / 64;    // (a.lo is a multiple of 64 on a sharded handle, else 0)
     if (!posf && (a.lo != 0 || a.hi != a.n)) return EPH_ERR_UNSUPPORTED;

@@ -273,7 +273,7 @@ int NBodyIntegration::lm_batch(int64_t k) {
     if (fast && (n_ <= kSmallN || (sharded() && path_ != EPH_PATH_F32_PAIRS))) return EPH_ERR_UNSUPPORTED;
     const bool f32_sharded = sharded() && path_ == EPH_PATH_F32_PAIRS;
     if (fast && !fast_partial_.p) {
-        if ((st = fast_partial_.alloc((size_t)fast_slices(npad_) * 3 * npad_))) return st;
+        if ((st = fast_partial_.alloc((size_t)fast_slices(npad_, true) * 3 * npad_))) return st;      // (the larger of the two slice counts)
     }
     if (path_ == EPH_PATH_F32_PAIRS && !posf_.p) {
         if ((st = posf_.alloc((size_t)4 * npad_))) return st;
