@@ -9,7 +9,7 @@
 //    this library on a device is freed (every handle destroyed), that device's cached blocks go back to the driver, so a process
 //    that shares the GPU with another allocator (PyTorch, RCCL, a second library) is not left holding GBs it does not use; while
 //    handles are alive such a caller calls eph_release_cached_memory() itself. An allocation of ours that fails empties the cache
-//    and retries. A reused block is cleared (what a fresh allocation looks like: no caller is handed another batch's rows).
+//    and retries. A reused block is cleared, synchronously (what a fresh allocation looks like: no caller is handed another batch's rows).
 // 2. One process-wide staging buffer in pinned, device-mapped host memory that KERNELS read and write (no copy engine, no
 //    pinning of short-lived host vectors): the deal's index arrays at batch creation, the reordered knot rows of a dealt batch.
 #include <algorithm>
@@ -78,8 +78,10 @@ int dev_alloc(size_t bytes, void **out) {
             }
         }
         if (hit) {
-            // what a fresh allocation looks like (on the legacy default stream: ordered before any handle stream's later work)
-            if (hipMemsetAsync(hit, 0, bytes, nullptr) != hipSuccess) (void)hipGetLastError();
+            // what a fresh allocation looks like -- COMPLETE before the block is handed out: the handles' streams are non-blocking,
+            // so a clear merely queued on the default stream can land after the new owner's first writes (it did: a batch's knot 0
+            // came back with a zeroed component in one run of test_body_order_of_the_acceleration_sum, round 5)
+            if (hipMemsetAsync(hit, 0, bytes, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) (void)hipGetLastError();
             *out = hit;
             return EPH_OK;
         }
