@@ -394,3 +394,91 @@ def test_erkn_table_satisfies_the_nystrom_order_conditions():
     assert abs(sum(EP)) < tol and abs(sum(EV)) < tol           # both solutions are consistent: their difference is O(h^p)
     assert t["FSAL"] and int(t["ORDER"]) == 7 and int(t["ORDER_EMBEDDED"]) == 5 and C[-1] == 1
     assert BP[:6] == A[6] and BP[6] == 0                       # FSAL: the last stage is the new point
+
+
+# ---- error paths: the two restatements against each other (the GPU is compared with the C one in tests/test_gpu_edge_cases.py) ----
+def _py_state(pr):
+    return (np.array([[float(c) for c in r] for r in pr.y]), np.array([[float(c) for c in r] for r in pr.dy]))
+
+
+@pytest.mark.parametrize("t0,h,method,expect", [
+    (1e20, 1.0, "QuinlanTremaine12", (1, 0.0, 0)),                   # refused before anything moves
+    (2.0 ** 52, 1.0, "QuinlanTremaine12", (1, 0.0, 0)),              # the first sub-step of h/4
+    (2.0 ** 52 - 1.0, 2.0, "QuinlanTremaine12", (1, 1.0, 0)),        # the third sub-step of the first macro step
+    (2.0 ** 52 - 9.0, 2.0, "Stormer13", (1, 9.0, 4)),                # the third sub-step of the fifth macro step
+])
+def test_underflow_inside_the_starter_c_vs_python(t0, h, method, expect):
+    """multistep/mod.rs:201-218 + runge_kutta/mod.rs:112-125: the main test passes, a sub-step of the Substepper fails, and the `?`
+    leaves the problem partly advanced. Both restatements must agree on where: status, time, step count, state -- twice."""
+    rng = np.random.default_rng(5)
+    n = 6
+    pos, vel, mu = rng.normal(size=(n, 3)) * 1e7, rng.normal(size=(n, 3)), rng.uniform(1.0, 1e5, n)
+    c = orc.NBody(pos, vel, mu, t0, h, method)
+    pr = po.Problem(pos, vel, mu, t0)
+    lm = po.LinearMultistep2(method, h, pr)
+    for calls in (30, 1):
+        st_c = c.advance(calls)
+        st_p = 0
+        for _ in range(calls):
+            st_p = lm.advance()
+            if st_p:
+                break
+        assert st_c == st_p == expect[0]
+        pc, vc, tc, sc = c.state()
+        pp, vp = _py_state(pr)
+        assert tc == pr.time == t0 + expect[1] and sc == lm.step_count() == expect[2]
+        assert np.array_equal(pc, pp) and np.array_equal(vc, vp)
+        assert c.eval_count() == pr.evals
+
+
+def test_bound_inside_the_starter_c_vs_python():
+    """the bound is tested by the sub-steps too (runge_kutta/mod.rs:113-115): a bound half way through the fourth macro step"""
+    s = load_system("sun_earth_moon_2433282.5")
+    c = orc.NBody(s.pos, s.vel, s.mu, s.epoch, s.dt)
+    c.set_bound(s.epoch + 3.5 * s.dt)
+    pr = po.Problem(s.pos, s.vel, s.mu, s.epoch)
+    pr.bound = s.epoch + 3.5 * s.dt
+    lm = po.LinearMultistep2("QuinlanTremaine12", s.dt, pr)
+    st = 0
+    for _ in range(10):
+        st = lm.advance()
+        if st:
+            break
+    assert c.advance(10) == st == orc.BOUND_REACHED
+    pc, vc, tc, sc = c.state()
+    pp, vp = _py_state(pr)
+    assert tc == pr.time and sc == lm.step_count() == 3 and np.array_equal(pc, pp) and np.array_equal(vc, vp)
+
+
+@pytest.mark.parametrize("dt,counts", [(0.1, [3]), (0.7, [10]), (0.7, [3, 10, 1, 7])])
+def test_sampling_trigger_that_stops_firing_c_vs_python(dt, counts):
+    """nbody.rs:389-391: `last_sample_time += delta; if last_sample_time == sample_period` on accumulated f64 sums: 0.1 x 3 is
+    reached exactly, 0.7 x 10 is stepped over and that body is never sampled again -- in both restatements."""
+    s = load_system("sun_earth_moon_2433282.5")
+    count = np.array([counts[b % len(counts)] for b in range(s.n)], dtype=np.uint32)
+    degree = np.array([5] * s.n, dtype=np.uint32)
+    a = orc.Propagator(s.pos, s.vel, s.mu, s.epoch, dt, 1, count, degree)
+    b = po.Propagator(s.pos, s.vel, s.mu, s.epoch, dt, 1, count, degree)
+    for _ in range(400):
+        assert a.step() == 0 and b.step() == 0
+    sa, sb = a.take_solution(), b.take_solution()
+    sampled = 0
+    for body in range(s.n):
+        start, interval, npoly = sa.info(body)
+        assert start == sb[body]["start"] and interval == sb[body]["interval"] and npoly == len(sb[body]["polys"])
+        co, nc = sa.coeffs(body)
+        for k, poly in enumerate(sb[body]["polys"]):
+            assert nc[k] == len(poly)
+            assert np.array_equal(co[k, :nc[k]], np.array([[float(x) for x in v] for v in poly]))
+        sampled += npoly > 0
+        acc, fires = 0.0, False
+        for _ in range(4 * int(count[body]) + 8):
+            acc += dt
+            if acc == dt * float(count[body]):
+                fires = True
+                break
+            if acc > dt * float(count[body]):
+                break
+        assert fires == (npoly > 0)
+    if (dt, counts) == (0.7, [10]):
+        assert sampled == 0

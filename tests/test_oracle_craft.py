@@ -185,3 +185,48 @@ def test_oracle_reproduces_the_committed_spacecraft_knots(scenario, method):
     assert len(at) == gm["apsides"]
     assert [[float(t).hex(), float(d).hex(), int(b), int(k)] for t, d, b, k in list(zip(at, ad, ab, ak))[:8]] == \
         gm["first_apsides"]
+
+
+@pytest.mark.parametrize("method", ["Verner87", "DormandPrince54", "Fine45"])
+@pytest.mark.parametrize("which", ["n_max_5", "n_max_40", "h_max_100", "factors", "tolerances", "tiny_h_init", "impossible_tolerance"])
+def test_controller_edge_cases_c_vs_python(scenario, method, which):
+    """The adaptive pair's error paths and non-default parameters in BOTH restatements (runge_kutta/mod.rs:225-243,414-439;
+    spacecraft.rs:479-485,598-609): MaxIterationsReached with the counter reset at manoeuvre boundaries, the h_max clamp, other
+    controller factors, unequal tolerances, StepSizeUnderflow from a tiny h_init and from a tolerance nothing meets. The GPU is
+    compared with the C restatement on the same cases in tests/test_gpu_edge_cases.py."""
+    s, eph, ship, burns = scenario
+    pe = []
+    for b in range(s.n):
+        st, iv, n = eph.info(b)
+        co, nc = eph.coeffs(b)
+        pe.append({"start": st, "interval": iv, "polys": [[po.Vec(*co[p, k]) for k in range(nc[p])] for p in range(n)]})
+    kw = dict(h_init=60.0, h_max=1.7976931348623157e308, tol_pos=1e-3, tol_vel=1e-3, fac_min=0.2, fac_max=5.0, fac=0.9, n_max=1_000_000)
+    kw.update({"n_max_5": dict(n_max=5), "n_max_40": dict(n_max=40), "h_max_100": dict(h_max=100.0),
+               "factors": dict(fac_min=0.5, fac_max=2.0, fac=0.8), "tolerances": dict(tol_pos=1e-6, tol_vel=1.0),
+               "tiny_h_init": dict(h_init=np.spacing(abs(ship.start)) / 4.0),
+               "impossible_tolerance": dict(tol_pos=1e-300, tol_vel=1e-300)}[which])
+    t0 = ship.start
+    earth = s.names.index("Earth")
+    short = [(t0 + 150.0, t0 + 400.0, [2e-4, 1e-4, 0.0], earth), (t0 + 900.0, t0 + 1000.0, [0.0, -1e-4, 2e-5], -1)]
+    orc.set_pow_mode(1)                      # the Python restatement calls math.pow (libm)
+    try:
+        c = orc.Craft(eph, s.mu, t0, ship.pos, ship.vel, method, burns=short, **kw)
+        p = po.Craft(pe, s.mu, t0, ship.pos, ship.vel, method, 1e-3, short, h_init=kw["h_init"], n_max=kw["n_max"])
+        p.h_max, p.fac_min, p.fac_max, p.fac = kw["h_max"], kw["fac_min"], kw["fac_max"], kw["fac"]
+        p.tol_pos, p.tol_vel = kw["tol_pos"], kw["tol_vel"]
+        last = (0, 0)
+        for _ in range(120):
+            last = (c.step(), p.step())
+            assert last[0] == last[1], (which, last)
+            if last[0]:
+                break
+    finally:
+        orc.set_pow_mode(0)
+    expect = {"n_max_5": 2, "n_max_40": 2, "tiny_h_init": 1, "impossible_tolerance": 1}.get(which, 0)
+    assert last == (expect, expect)
+    cs = c.state()
+    assert cs["attempts"] == p.n and cs["next_h"] == p.next_h and cs["t"] == p.t
+    kt, kp, kv = c.knots()
+    assert len(p.knots) == len(kt)
+    for i, (t, y) in enumerate(p.knots):
+        assert kt[i] == t and tuple(kp[i]) == y[:3] and tuple(kv[i]) == y[3:], (which, method, i)
