@@ -12,6 +12,21 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+
+
+def keep_measurement_commit(path, new):
+    """A counter file is re-written every time this script runs; `profile_commit` is the commit the COUNTERS were taken at, so it is
+    carried over from the existing file when the counters and the source hashes are the ones already recorded there."""
+    try:
+        old = json.loads(Path(path).read_text())
+    except (OSError, ValueError):
+        return new
+    same = all(old.get(k) == new.get(k) for k in ("source_sha256_16", "avg_ns_kernel_trace", "traffic_bytes_per_launch",
+                                                   "traffic_bytes_per_attempt", "valu_wave_insts_per_launch"))
+    if same and old.get("profile_commit"):
+        new = dict(new, profile_commit=old["profile_commit"])
+    return new
+
 from ephemeris_explorer_amd.workloads import profile_stamp      # sha256 of the kernel sources a counter file was taken with
 tag = sys.argv[1]
 src = ROOT / "gpurun_out" / tag
@@ -57,14 +72,14 @@ if craft.exists():
         "note": "sums over the chip for the ONE launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles; FETCH_SIZE / WRITE_SIZE in KiB, "
                 "uncalibrated for this access pattern (scalar loads of coefficient rows, 8-byte knot stores): raw figures",
         "counters": c, "derived": derived, "code_object": code_object, "bench": b, **profile_stamp("craft")}, indent=1) + "\n")
-    (dst / "traffic_craft.json").write_text(json.dumps({
+    (dst / "traffic_craft.json").write_text(json.dumps(keep_measurement_commit(dst / "traffic_craft.json", {
         "source": f"profiles/{tag}_craft_pmc.json", "kernel": c["kernel"], "attempts": att,
         "traffic_bytes_per_attempt": (derived["fetch_bytes_raw"] + derived["write_bytes_raw"]) / att if att else None,
         "valu_wave_insts_per_attempt": c["SQ_INSTS_VALU"] / att if att else None,
         "f64_wave_insts_per_attempt": f64 / att if att else None,
         "active_inst_valu_over_wave_cycles": derived["active_inst_valu_over_wave_cycles"],
         "waves_per_simd": 2, "vgpr_count": 256, "vgpr_spill_count": 100,
-        "avg_ns_kernel_trace": ns, **profile_stamp("craft")}, indent=1) + "\n")
+        "avg_ns_kernel_trace": ns, **profile_stamp("craft")}), indent=1) + "\n")
     print(json.dumps(derived, indent=1))
 
 if not (src / "stats_kernel_stats.csv").exists():          # only the sweep was profiled so far this round
@@ -136,12 +151,12 @@ for k, v in pmc.items():
     out["kernels"][k] = e
 (dst / f"{tag}_pmc.json").write_text(json.dumps(out, indent=1) + "\n")
 main = max(out["kernels"].items(), key=lambda kv: kv[1].get("calls", 0) * kv[1].get("avg_ns_kernel_trace", 0))
-(dst / "traffic.json").write_text(json.dumps({
+(dst / "traffic.json").write_text(json.dumps(keep_measurement_commit(dst / "traffic.json", {
     "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes)",
     "kernel": main[0], "traffic_bytes_per_launch": main[1].get("traffic_bytes_per_launch"),
     "valu_wave_insts_per_launch": main[1].get("SQ_INSTS_VALU"),
     "avg_ns_kernel_trace": main[1].get("avg_ns_kernel_trace"),
-    **profile_stamp("nbody")}, indent=1) + "\n")
+    **profile_stamp("nbody")}), indent=1) + "\n")
 print(json.dumps(out, indent=1)[:3000])
 print("bench:", bench["value"], bench["roofline"]["launch_us"])
 
