@@ -1,0 +1,326 @@
+// ephemeris_amd.hpp -- the reference's operator surface in C++, header-only, over the C ABI of ephemeris_amd.h.
+//
+// The reference (Canleskis/ephemeris-explorer) is Rust and the image has no Rust toolchain, so the host side above the C boundary
+// that CAN be compiled here is this one: the same type and method names, argument meaning and error behaviour as the reference's
+// traits, for C++ callers and as the compiled counterpart of INTEGRATION.md's shims (paths relative to the reference root):
+//
+//   integration::StepError, Integrator::advance            integration/src/lib.rs:139-169,315-331       -> StepError, NBodyIntegration::advance
+//   Propagator / IncrementalPropagator / DirectionalPropagator / BoundedPropagator
+//                                                           ephemeris/src/lib.rs:9-79                     -> NBodyPropagator::{step, step_n, step_to, time, has_reached, take_solution, propagate}
+//   Vec<UniformSpline<DVec3>>, EvaluateTrajectory           ephemeris/src/trajectory.rs:337-633           -> Solution::{start, interval, len, state_vector, position, append}
+//   NewtonianGravity::eval (SecondOrderODE)                 ephemeris/src/propagators/nbody.rs:16-39      -> newtonian_gravity_eval
+//   SpacecraftPropagator + CubicHermiteSplineSolout         ephemeris/src/propagators/spacecraft.rs:415-695 -> SpacecraftBatch (n propagators at once)
+//   AdaptiveMethodParams, INITIAL_ADAPTIVE_PARAMS           ephemeris_explorer/src/load/mod.rs:472-486    -> AdaptiveParams
+//
+// Errors: what the reference returns as `Err(StepError::..)` comes back as a StepError VALUE (Result-like: `if (auto e = p.step())`);
+// what would be a panic or has no counterpart (bad arguments, no device, HIP failures) throws ephemeris_amd::Error. There is no CPU
+// fallback: without a gfx950 device every compute call throws Error{EPH_ERR_NO_DEVICE}.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ephemeris_amd.h"
+
+namespace ephemeris_amd {
+
+using DVec3 = std::array<double, 3>;
+
+// a library / device failure (negative status of the C ABI)
+struct Error : std::runtime_error {
+    int32_t status;
+    Error(int32_t st, const char *where)
+        : std::runtime_error(std::string(where) + ": " + eph_status_string(st) + " [" + eph_last_error() + "]"), status(st) {}
+};
+
+// integration::StepError (lib.rs:315-331). `None` = Ok(()).
+enum class StepError : int32_t {
+    None = EPH_OK,
+    StepSizeUnderflow = 1,
+    MaxIterationsReached = 2,
+    BoundReached = 3,
+    EvalFailed = 4,
+    Solout = 5,   // NBodyPropagatorError::Solout / SpacecraftPropagatorError::Solout
+};
+inline const char *to_string(StepError e) { return eph_status_string(static_cast<int32_t>(e)); }
+
+namespace detail {
+inline StepError step_result(int32_t st, const char *where) {
+    if (st < 0) throw Error(st, where);
+    return static_cast<StepError>(st);
+}
+inline void check(int32_t st, const char *where) {
+    if (st != EPH_OK) throw Error(st, where);
+}
+inline const double *flat(const std::vector<DVec3> &v) { return v.empty() ? nullptr : v.front().data(); }
+inline double *flat(std::vector<DVec3> &v) { return v.empty() ? nullptr : v.front().data(); }
+}  // namespace detail
+
+enum class Direction : int32_t { Forward = EPH_FORWARD, Backward = EPH_BACKWARD };
+
+inline int32_t device_count() {
+    int32_t n = 0;
+    detail::check(eph_device_count(&n), "eph_device_count");
+    return n;
+}
+// the evaluation order of the `particular` point-mass term new handles take (0..6)
+inline void set_pair_variant(int32_t k) { detail::check(eph_set_pair_variant(k), "eph_set_pair_variant"); }
+
+// SecondOrderODE::eval for NewtonianGravity: ddy[i] += sum over the other bodies, reference summation order (nbody.rs:22-38)
+inline void newtonian_gravity_eval(const std::vector<DVec3> &y, const std::vector<double> &gravitational_parameters, std::vector<DVec3> &ddy) {
+    if (y.size() != gravitational_parameters.size() || ddy.size() != y.size()) throw std::invalid_argument("newtonian_gravity_eval: sizes differ");
+    detail::check(eph_accel_eval(static_cast<int32_t>(y.size()), detail::flat(y), gravitational_parameters.data(), detail::flat(ddy)), "eph_accel_eval");
+}
+
+// StateVector<DVec3> of one body at one epoch
+struct StateVector {
+    DVec3 position, velocity;
+};
+
+// Vec<UniformSpline<DVec3>>: what NBodyPropagator::take_solution hands over
+class Solution {
+public:
+    explicit Solution(eph_solution *h) : h_(h) {}
+    Solution(Solution &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    Solution &operator=(Solution &&o) noexcept {
+        if (this != &o) { reset(); h_ = std::exchange(o.h_, nullptr); }
+        return *this;
+    }
+    Solution(const Solution &) = delete;
+    Solution &operator=(const Solution &) = delete;
+    ~Solution() { reset(); }
+
+    int32_t bodies() const {
+        int32_t n = 0;
+        detail::check(eph_solution_bodies(h_, &n), "eph_solution_bodies");
+        return n;
+    }
+    // UniformSpline::{start, interval, len}
+    double start(int32_t body) const { return info(body).start; }
+    double interval(int32_t body) const { return info(body).interval; }
+    int64_t len(int32_t body) const { return info(body).npoly; }
+    double end(int32_t body) const {          // start + interval * len, the f64 expression of trajectory.rs:489-491
+        const Info i = info(body);
+        return i.start + i.interval * static_cast<double>(i.npoly);
+    }
+    // EvaluateTrajectory::state_vector: nullopt-like -- `inside == false` where the reference returns None
+    bool state_vector(int32_t body, double at, StateVector &out) const {
+        uint8_t inside = 0;
+        detail::check(eph_solution_eval(h_, body, 1, &at, out.position.data(), out.velocity.data(), &inside), "eph_solution_eval");
+        return inside != 0;
+    }
+    bool position(int32_t body, double at, DVec3 &out) const {
+        uint8_t inside = 0;
+        detail::check(eph_solution_eval(h_, body, 1, &at, out.data(), nullptr, &inside), "eph_solution_eval");
+        return inside != 0;
+    }
+    // many epochs of one body in one launch (what the app's plotting does): returns the `inside` flags
+    std::vector<uint8_t> positions(int32_t body, const std::vector<double> &at, std::vector<DVec3> &out) const {
+        out.resize(at.size());
+        std::vector<uint8_t> inside(at.size());
+        detail::check(eph_solution_eval(h_, body, static_cast<int64_t>(at.size()), at.data(), detail::flat(out), nullptr, inside.data()), "eph_solution_eval");
+        return inside;
+    }
+    // UniformSpline::append / prepend for every body (asserts contiguity in the reference: bad argument here)
+    void append(const Solution &tail, Direction d = Direction::Forward) {
+        detail::check(eph_solution_append(h_, tail.h_, static_cast<int32_t>(d)), "eph_solution_append");
+    }
+    eph_solution *raw() const { return h_; }
+
+private:
+    struct Info { double start, interval; int64_t npoly; };
+    Info info(int32_t body) const {
+        Info i{};
+        detail::check(eph_solution_info(h_, body, &i.start, &i.interval, &i.npoly), "eph_solution_info");
+        return i;
+    }
+    void reset() {
+        if (h_) eph_solution_destroy(h_);
+        h_ = nullptr;
+    }
+    eph_solution *h_;
+};
+
+// Integration<NBodyProblem<DVec3>, M> without a solout: M::new(FixedMethodParams::new(h)).integrate(problem)
+class NBodyIntegration {
+public:
+    NBodyIntegration(const std::vector<DVec3> &y, const std::vector<DVec3> &dy, const std::vector<double> &gravitational_parameters, double time,
+                     double h, const char *method = "QuinlanTremaine12") : n_(static_cast<int32_t>(y.size())) {
+        if (dy.size() != y.size() || gravitational_parameters.size() != y.size()) throw std::invalid_argument("NBodyIntegration: sizes differ");
+        detail::check(eph_nbody_create(n_, detail::flat(y), detail::flat(dy), gravitational_parameters.data(), time, h, method, &h_), "eph_nbody_create");
+    }
+    NBodyIntegration(NBodyIntegration &&o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    NBodyIntegration(const NBodyIntegration &) = delete;
+    NBodyIntegration &operator=(const NBodyIntegration &) = delete;
+    ~NBodyIntegration() { if (h_) eph_nbody_destroy(h_); }
+
+    StepError advance(int64_t n_steps = 1) { return detail::step_result(eph_nbody_advance(h_, n_steps), "eph_nbody_advance"); }   // Integrator::advance
+    void set_bound(double bound) { detail::check(eph_nbody_set_bound(h_, bound), "eph_nbody_set_bound"); }
+    NBodyIntegration clone() const {
+        eph_nbody *c = nullptr;
+        detail::check(eph_nbody_clone(h_, &c), "eph_nbody_clone");
+        return NBodyIntegration(c, n_);
+    }
+    // problem.{time, state.y, state.dy}, IntegratorState::step_count
+    double state(std::vector<DVec3> &y, std::vector<DVec3> &dy, uint32_t *step_count = nullptr) const {
+        y.resize(static_cast<size_t>(n_));
+        dy.resize(static_cast<size_t>(n_));
+        double t = 0.0;
+        detail::check(eph_nbody_get_state(h_, detail::flat(y), detail::flat(dy), &t, step_count), "eph_nbody_get_state");
+        return t;
+    }
+    int32_t bodies() const { return n_; }
+
+private:
+    NBodyIntegration(eph_nbody *h, int32_t n) : h_(h), n_(n) {}
+    eph_nbody *h_ = nullptr;
+    int32_t n_ = 0;
+};
+
+// NBodyPropagator<D, DVec3, M, SplineInterpolators<D, DVec3, LeastSquaresFit>>  (nbody.rs:65-235; celestial.rs:156-186)
+class NBodyPropagator {
+public:
+    // count[b] / degree[b]: ephemeris.json's samples-per-polynomial divisor and fit degree of body b (load/mod.rs:313-330)
+    NBodyPropagator(const std::vector<DVec3> &y, const std::vector<DVec3> &dy, const std::vector<double> &gravitational_parameters, double time,
+                    double delta, Direction direction, const std::vector<uint32_t> &count, const std::vector<uint32_t> &degree,
+                    const char *method = "QuinlanTremaine12") : n_(static_cast<int32_t>(y.size())) {
+        if (dy.size() != y.size() || gravitational_parameters.size() != y.size() || count.size() != y.size() || degree.size() != y.size())
+            throw std::invalid_argument("NBodyPropagator: sizes differ");
+        detail::check(eph_prop_create(n_, detail::flat(y), detail::flat(dy), gravitational_parameters.data(), time, delta,
+                                      static_cast<int32_t>(direction), method, count.data(), degree.data(), &h_), "eph_prop_create");
+    }
+    NBodyPropagator(NBodyPropagator &&o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    NBodyPropagator(const NBodyPropagator &) = delete;
+    NBodyPropagator &operator=(const NBodyPropagator &) = delete;
+    ~NBodyPropagator() { if (h_) eph_prop_destroy(h_); }
+
+    StepError step() { return detail::step_result(eph_prop_step(h_), "eph_prop_step"); }                          // IncrementalPropagator::step
+    StepError step_n(int64_t n) { return detail::step_result(eph_prop_step_n(h_, n), "eph_prop_step_n"); }
+    StepError step_to(double time) { return detail::step_result(eph_prop_step_to(h_, time), "eph_prop_step_to"); }   // lib.rs:49-60
+    double time() const {                                                                                         // DirectionalPropagator::time
+        double t = 0.0;
+        detail::check(eph_prop_time(h_, &t), "eph_prop_time");
+        return t;
+    }
+    bool has_reached(double time) const {
+        int32_t f = 0;
+        detail::check(eph_prop_has_reached(h_, time, &f), "eph_prop_has_reached");
+        return f != 0;
+    }
+    Solution take_solution() {                                                                                    // Propagator::take_solution
+        eph_solution *s = nullptr;
+        detail::check(eph_prop_take_solution(h_, &s), "eph_prop_take_solution");
+        return Solution(s);
+    }
+    // BoundedPropagator::propagate: step_to(to), then take_solution; the StepError (if any) in `error`
+    Solution propagate(double to, StepError *error = nullptr) {
+        eph_solution *s = nullptr;
+        const StepError e = detail::step_result(eph_prop_propagate(h_, to, &s), "eph_prop_propagate");
+        if (error) *error = e;
+        return Solution(s);
+    }
+    NBodyPropagator clone() const {
+        eph_prop *c = nullptr;
+        detail::check(eph_prop_clone(h_, &c), "eph_prop_clone");
+        return NBodyPropagator(c, n_);
+    }
+    int32_t bodies() const { return n_; }
+
+private:
+    NBodyPropagator(eph_prop *h, int32_t n) : h_(h), n_(n) {}
+    eph_prop *h_ = nullptr;
+    int32_t n_ = 0;
+};
+
+// integration::AdaptiveMethodParams with the app's INITIAL_ADAPTIVE_PARAMS as defaults (load/mod.rs:472-486)
+struct AdaptiveParams : eph_adaptive_params {
+    explicit AdaptiveParams(double tolerance = 1e-3) {
+        h_init = 60.0; h_max = 1.7976931348623157e308; tol_position = tolerance; tol_velocity = tolerance;
+        fac_min = 1.0 / 5.0; fac_max = 5.0 / 1.0; fac = 9.0 / 10.0; n_max = 1000000u;
+    }
+};
+
+// Timeline segment with a burn: constant acceleration in the inertial frame (reference = -1) or in the TNB frame relative to a body
+struct Burn {
+    double start, end;
+    DVec3 acceleration;
+    int32_t reference = -1;
+};
+
+// `Bodies`: the massive bodies' splines resident on the device (dynamics/spacecraft.rs:164-228)
+class Ephemeris {
+public:
+    Ephemeris(const Solution &splines, const std::vector<double> &gravitational_parameters) {
+        detail::check(eph_ephemeris_create(splines.raw(), gravitational_parameters.data(), &h_), "eph_ephemeris_create");
+    }
+    Ephemeris(const Ephemeris &) = delete;
+    Ephemeris &operator=(const Ephemeris &) = delete;
+    ~Ephemeris() { if (h_) eph_ephemeris_destroy(h_); }
+    eph_ephemeris *raw() const { return h_; }
+
+private:
+    eph_ephemeris *h_ = nullptr;
+};
+
+// n x SpacecraftPropagator<[StateVector; 1], ReferenceFrame, Bodies, <adaptive ERK pair>, CubicHermiteSplineSolout>: the batch form of
+// INTEGRATION.md 4b (a batch of one is the drop-in for the app's single propagator). Per-craft outcomes are StepError values.
+class SpacecraftBatch {
+public:
+    SpacecraftBatch(const Ephemeris &bodies, double initial_time, const std::vector<StateVector> &initial_states, const char *method = "Verner87",
+                    const AdaptiveParams &params = AdaptiveParams(), const std::vector<std::vector<Burn>> &timelines = {}, int32_t max_knots = 4096)
+        : n_(static_cast<int64_t>(initial_states.size())) {
+        std::vector<double> t0(initial_states.size(), initial_time), pos, vel;
+        for (const StateVector &sv : initial_states) {
+            pos.insert(pos.end(), sv.position.begin(), sv.position.end());
+            vel.insert(vel.end(), sv.velocity.begin(), sv.velocity.end());
+        }
+        std::vector<int64_t> off(initial_states.size() + 1, 0);
+        std::vector<double> bs{0.0}, be{0.0}, ba{0.0, 0.0, 0.0};
+        std::vector<int32_t> br{0};
+        if (!timelines.empty()) {
+            if (timelines.size() != initial_states.size()) throw std::invalid_argument("SpacecraftBatch: one timeline per craft");
+            bs.clear(); be.clear(); ba.clear(); br.clear();
+            for (size_t i = 0; i < timelines.size(); ++i) {
+                for (const Burn &b : timelines[i]) {
+                    bs.push_back(b.start); be.push_back(b.end); br.push_back(b.reference);
+                    ba.insert(ba.end(), b.acceleration.begin(), b.acceleration.end());
+                }
+                off[i + 1] = static_cast<int64_t>(bs.size());
+            }
+            if (bs.empty()) { bs = {0.0}; be = {0.0}; ba = {0.0, 0.0, 0.0}; br = {0}; }
+        }
+        detail::check(eph_craft_batch_create(bodies.raw(), n_, t0.data(), pos.data(), vel.data(), method, &params, off.data(), bs.data(), be.data(),
+                                             ba.data(), br.data(), max_knots, &h_), "eph_craft_batch_create");
+    }
+    SpacecraftBatch(const SpacecraftBatch &) = delete;
+    SpacecraftBatch &operator=(const SpacecraftBatch &) = delete;
+    ~SpacecraftBatch() { if (h_) eph_craft_batch_destroy(h_); }
+
+    void step_to(double time) { detail::check(eph_craft_batch_propagate(h_, time), "eph_craft_batch_propagate"); }   // every craft: IncrementalPropagator::step_to
+    void step(uint32_t n_steps = 1) { detail::check(eph_craft_batch_step_n(h_, n_steps), "eph_craft_batch_step_n"); }
+    // per craft: Ok / the StepError its propagator returned (EPH_KNOTS_FULL = 6: drain the knots and resume)
+    std::vector<int32_t> status(std::vector<int32_t> *nknots = nullptr) const {
+        std::vector<int32_t> st(static_cast<size_t>(n_)), nk(static_cast<size_t>(n_));
+        std::vector<uint32_t> at(static_cast<size_t>(n_)), sp(static_cast<size_t>(n_));
+        detail::check(eph_craft_batch_status(h_, st.data(), nk.data(), at.data(), sp.data()), "eph_craft_batch_status");
+        if (nknots) *nknots = nk;
+        return st;
+    }
+    // CubicHermiteSpline of one craft: knot times, positions, velocities (trajectory.rs:698-855)
+    void knots(int64_t craft, int32_t nknots, std::vector<double> &t, std::vector<DVec3> &position, std::vector<DVec3> &velocity) const {
+        t.resize(static_cast<size_t>(nknots));
+        position.resize(static_cast<size_t>(nknots));
+        velocity.resize(static_cast<size_t>(nknots));
+        detail::check(eph_craft_batch_knots(h_, craft, t.data(), detail::flat(position), detail::flat(velocity)), "eph_craft_batch_knots");
+    }
+    int64_t len() const { return n_; }
+
+private:
+    eph_craft_batch *h_ = nullptr;
+    int64_t n_ = 0;
+};
+
+}  // namespace ephemeris_amd

@@ -105,6 +105,27 @@ def test_header_is_plain_c_and_the_c_example_links(product_lib, tmp_path):
         assert r.returncode == 0 and "apsides" in r.stdout, (r.stdout, r.stderr)
 
 
+def test_cpp_operator_surface_compiles_and_links(product_lib, tmp_path):
+    """include/ephemeris_amd.hpp (the reference's trait surface over the C ABI, header-only C++17) compiles warning-free and
+    examples/propagate.cpp links against the product alone; without a device its first compute call throws
+    Error{EPH_ERR_NO_DEVICE} (exit 77): the wrapper has no CPU path either."""
+    import subprocess
+    from conftest import ROOT
+    libdir = ROOT / "ephemeris_explorer_amd"
+    exe = tmp_path / "propagate_cpp"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}",
+                           str(ROOT / "examples" / "propagate.cpp"), f"-L{libdir}", "-lephemeris_amd",
+                           f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    import ephemeris_explorer_amd as ea
+    if ea.device_count() < 1:
+        assert r.returncode == 77 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+    else:
+        assert r.returncode == 0 and "inside=1" in r.stdout, (r.stdout, r.stderr)
+    text = (ROOT / "include" / "ephemeris_amd.hpp").read_text()
+    assert "oracle" not in text and "torch" not in text
+
+
 def test_debug_hooks_are_not_in_the_product(product_lib):
     """csrc/eph_debug.h: the seven eph_debug_* hooks are exported by the test-hooks library (the product's objects + debug_api.o)
     and by tuning builds, never by libephemeris_amd.so; the product exports the header's functions and no other eph_* name."""

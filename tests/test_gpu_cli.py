@@ -111,6 +111,52 @@ def test_c_example_runs_on_the_device(gpu, tmp_path):
     assert np.abs(got - want).max() < 1e-3 + 1e-12 * np.abs(want).max()
 
 
+def test_cpp_example_runs_on_the_device(gpu, tmp_path):
+    """examples/propagate.cpp: the reference's trait surface (include/ephemeris_amd.hpp) from C++ -- NewtonianGravity::eval,
+    a bounded NBodyPropagator::propagate, EvaluateTrajectory::state_vector, a SpacecraftPropagator::step_to with a burn.
+    It prints hex floats: every value equals the CPU restatement's bit for bit."""
+    import re
+    import subprocess
+    from conftest import ROOT, load_system
+    exe = tmp_path / "propagate_cpp"
+    libdir = ROOT / "ephemeris_explorer_amd"
+    subprocess.check_call(["g++", "-std=c++17", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "propagate.cpp"), f"-L{libdir}",
+                           "-lephemeris_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    hx = r"(-?0x[0-9a-fp.+-]+)"
+
+    def floats(m):
+        return np.array([float.fromhex(x) for x in m.groups()])
+    s = load_system("sun_earth_moon_2433282.5")
+    t0 = s.epoch
+    m = re.search(rf"ddy\[2\] = {hx} {hx} {hx}", r.stdout)
+    assert m, r.stdout
+    assert np.array_equal(bits(floats(m)), bits(orc.gravity(s.pos, s.mu)[2]))
+    o = orc.Propagator(s.pos, s.vel, s.mu, t0, s.dt, 1, s.count, s.degree)
+    assert o.step_to(t0 + 40 * 86400.0) == 0
+    m = re.search(rf"reached {hx}; Earth spline: (\d+) polynomials of (\d+) s; inside=1", r.stdout)
+    assert m, r.stdout
+    assert float.fromhex(m.group(1)) == o.time()
+    eph = o.take_solution()
+    start, interval, npoly = eph.info(1)
+    assert int(m.group(2)) == npoly and float(m.group(3)) == interval
+    m = re.search(rf"earth\(day 10\) = {hx} {hx} {hx} \| {hx} {hx} {hx}", r.stdout)
+    assert m, r.stdout
+    wp, wv = eph.eval(1, t0 + 10 * 86400.0)[:2]
+    assert np.array_equal(bits(floats(m)), bits(np.concatenate([np.ravel(wp), np.ravel(wv)])))
+    c = orc.Craft(eph, s.mu, t0, [-27204249.668775786, 132947582.43848978, 57641619.74241204],
+                  [-22.207539106181895, -5.189518219791726, -2.2515617105336263], "Verner87",
+                  burns=[(t0 + 7200.0, t0 + 7260.0, [5e-4, 0.0, 0.0], 1)])
+    assert c.step_to(t0 + 3 * 86400.0) == 0
+    kt, kp, kv = c.knots()
+    m = re.search(rf"craft: status 0 \(\w+\), knots (\d+), last knot t = {hx} r = {hx} {hx} {hx}", r.stdout)
+    assert m, r.stdout
+    assert int(m.group(1)) == len(kt)
+    got = np.array([float.fromhex(x) for x in m.groups()[1:]])
+    assert np.array_equal(bits(got), bits(np.concatenate([[kt[-1]], kp[-1]])))
+
+
 def test_c_spacecraft_example_runs_on_the_device(gpu, tmp_path):
     """examples/craft.c: INTEGRATION.md 4b's batch-of-one spacecraft propagator driven from plain C -- create, the app's
     solout, a step_n loop until has_reached, knots + events. Everything it prints equals the restatement stepped the same
