@@ -7,6 +7,7 @@
 //
 // Values are printed as hex floats: the GPU test compares them bit for bit with the CPU restatement.
 #include <cstdio>
+#include <limits>
 
 #include "ephemeris_amd.hpp"
 
@@ -51,6 +52,30 @@ int main() try {
     craft.knots(0, nknots[0], kt, kp, kv);
     std::printf("craft: status %d (%s), knots %d, last knot t = %a r = %a %a %a\n", (int)status[0], eph_status_string(status[0]), (int)nknots[0], kt.back(),
                 kp.back()[0], kp.back()[1], kp.back()[2]);
+
+    // the app's flow (prediction.rs:422-443): SpacecraftSolout events, a snapshot (Clone) resumed later, a long propagation drained in
+    // pieces and stitched with SpacecraftPropagator::join
+    ea::SpacecraftBatch ship(bodies, t0, {craft0}, "Verner87", ea::AdaptiveParams(1e-3), {{ea::Burn{t0 + 7200.0, t0 + 7260.0, {5e-4, 0.0, 0.0}, 1}}});
+    ship.enable_events({std::numeric_limits<double>::infinity(), 909153.0740387321, 68800.06030265747});
+    ea::SpacecraftBatch snapshot = ship.clone();
+    ship.step_to(t0 + 1.5 * day);
+    snapshot.step_to(t0 + 1.5 * day);                       // the resumed snapshot takes the same steps
+    ea::CubicHermiteSpline whole = snapshot.trajectory(0);
+    snapshot.reset_knots();                                 // newest knot becomes knot 0 of an empty slab
+    snapshot.step_to(t0 + 3.0 * day);
+    whole.join(snapshot.trajectory(0));
+    ea::StateVector at2{};
+    const bool in2 = whole.state_vector(t0 + 2.0 * day, at2);
+    ea::SoiTransitions tr;
+    ea::Apsides ap;
+    const int32_t ev = snapshot.events(0, tr, ap);
+    std::printf("joined: knots %zu (first leg %zu), inside=%d, r(day 2) = %a %a %a\n", whole.len(), ship.trajectory(0).len(), (int)in2, at2.position[0],
+                at2.position[1], at2.position[2]);
+    std::printf("events: status %d, transitions %zu, apsides %zu, first apsis at %a\n", (int)ev, tr.time.size(), ap.time.size(), ap.time.empty() ? 0.0 : ap.time.front());
+    const double restart = ea::divergence_time_before({ea::Burn{t0 + 7200.0, t0 + 7260.0, {5e-4, 0.0, 0.0}, 1}},
+                                                      {ea::Burn{t0 + 7200.0, t0 + 7260.0, {5e-4, 0.0, 0.0}, 1}, ea::Burn{t0 + 2.0 * day, t0 + 2.0 * day + 30.0, {0.0, 1e-4, 0.0}, -1}},
+                                                      t0 + 3.0 * day);
+    std::printf("flight plan edit restarts at t0 + %.1f s\n", restart - t0);
     return 0;
 } catch (const ea::Error &e) {
     std::fprintf(stderr, "%s\n", e.what());

@@ -128,6 +128,24 @@ public:
     void append(const Solution &tail, Direction d = Direction::Forward) {
         detail::check(eph_solution_append(h_, tail.h_, static_cast<int32_t>(d)), "eph_solution_append");
     }
+    // UniformSpline::clear_before / clear_after at `at`, on every body's spline (trajectory.rs:536-549)
+    void clear_before(double at) { detail::check(eph_solution_clear(h_, -1, at, 0), "eph_solution_clear"); }
+    void clear_after(double at) { detail::check(eph_solution_clear(h_, -1, at, 1), "eph_solution_clear"); }
+    // UniformSpline::between for every body; `ok == false` where the reference returns None for any of them
+    Solution between(double from, double to, bool &ok) const {
+        eph_solution *o = nullptr;
+        detail::check(eph_solution_between(h_, from, to, &o), "eph_solution_between");
+        ok = o != nullptr;
+        return Solution(o);
+    }
+    // the Polynomials of one body: coefficient k of polynomial p at coeffs[(p*8 + k)*3 + c], lengths after trim() in ncoef
+    void polynomials(int32_t body, std::vector<double> &coeffs, std::vector<int32_t> &ncoef) const {
+        const int64_t np = len(body);
+        coeffs.assign(static_cast<size_t>(np) * 24, 0.0);
+        ncoef.assign(static_cast<size_t>(np), 0);
+        detail::check(eph_solution_coeffs(h_, body, coeffs.data(), ncoef.data()), "eph_solution_coeffs");
+    }
+    explicit operator bool() const { return h_ != nullptr; }
     eph_solution *raw() const { return h_; }
 
 private:
@@ -250,6 +268,50 @@ struct Burn {
     int32_t reference = -1;
 };
 
+// CubicHermiteSpline<DVec3> (trajectory.rs:698-855): a craft's trajectory as its knots
+struct CubicHermiteSpline {
+    std::vector<double> t;
+    std::vector<DVec3> position, velocity;
+
+    size_t len() const { return t.size(); }
+    bool is_empty() const { return t.empty(); }
+    double start() const { return t.front(); }
+    double end() const { return t.back(); }
+    // EvaluateTrajectory::state_vector (trajectory.rs:766-797), evaluated on the device; false where the reference returns None
+    bool state_vector(double at, StateVector &out) const {
+        uint8_t inside = 0;
+        detail::check(eph_hermite_eval(static_cast<int64_t>(t.size()), t.data(), detail::flat(position), detail::flat(velocity), 1, &at,
+                                       out.position.data(), out.velocity.data(), &inside), "eph_hermite_eval");
+        return inside != 0;
+    }
+    // SpacecraftPropagator::join(lhs = *this, rhs): clear_after(rhs.start()) then extend(rhs)  (spacecraft.rs:558-561)
+    void join(const CubicHermiteSpline &rhs) {
+        const int64_t cap = static_cast<int64_t>(t.size() + rhs.t.size());
+        std::vector<double> ot(static_cast<size_t>(cap));
+        std::vector<DVec3> op(static_cast<size_t>(cap)), ov(static_cast<size_t>(cap));
+        int64_t n = 0;
+        detail::check(eph_hermite_join(static_cast<int64_t>(t.size()), t.data(), detail::flat(position), detail::flat(velocity),
+                                       static_cast<int64_t>(rhs.t.size()), rhs.t.data(), detail::flat(rhs.position), detail::flat(rhs.velocity), cap,
+                                       ot.data(), detail::flat(op), detail::flat(ov), &n), "eph_hermite_join");
+        ot.resize(static_cast<size_t>(n)); op.resize(static_cast<size_t>(n)); ov.resize(static_cast<size_t>(n));
+        t.swap(ot); position.swap(op); velocity.swap(ov);
+    }
+};
+
+// SoiTransitions / Apsides of the app's SpacecraftSolution (dynamics/spacecraft.rs:303-451)
+struct SoiTransitions {
+    std::vector<double> time;
+    std::vector<int32_t> body;
+};
+enum class ApsisKind : int32_t { Periapsis = 0, Apoapsis = 1 };
+struct Apsides {
+    std::vector<double> time, distance;
+    std::vector<int32_t> body, kind;
+};
+
+// Timeline::divergence_time_before (spacecraft.rs:179-213): the epoch a flight plan edited from `old_burns` to `new_burns` restarts from
+inline double divergence_time_before(const std::vector<Burn> &old_burns, const std::vector<Burn> &new_burns, double before);
+
 // `Bodies`: the massive bodies' splines resident on the device (dynamics/spacecraft.rs:164-228)
 class Ephemeris {
 public:
@@ -316,11 +378,70 @@ public:
         velocity.resize(static_cast<size_t>(nknots));
         detail::check(eph_craft_batch_knots(h_, craft, t.data(), detail::flat(position), detail::flat(velocity)), "eph_craft_batch_knots");
     }
+    CubicHermiteSpline trajectory(int64_t craft) const {
+        std::vector<int32_t> nk;
+        (void)status(&nk);
+        CubicHermiteSpline sp;
+        knots(craft, nk[static_cast<size_t>(craft)], sp.t, sp.position, sp.velocity);
+        return sp;
+    }
+    // problem.{time, state} and the controller's next step size of every craft
+    void state(std::vector<double> &t, std::vector<DVec3> &position, std::vector<DVec3> &velocity, std::vector<double> *next_h = nullptr) const {
+        const size_t n = static_cast<size_t>(n_);
+        t.resize(n); position.resize(n); velocity.resize(n);
+        if (next_h) next_h->resize(n);
+        detail::check(eph_craft_batch_state(h_, t.data(), detail::flat(position), detail::flat(velocity), next_h ? next_h->data() : nullptr), "eph_craft_batch_state");
+    }
+    // the app's SpacecraftSolout (SOI transitions + apsides) instead of the library's CubicHermiteSplineSolout; before the first step
+    void enable_events(const std::vector<double> &soi_radius, int32_t max_transitions = 64, int32_t max_apsides = 256) {
+        detail::check(eph_craft_batch_enable_events(h_, soi_radius.data(), max_transitions, max_apsides), "eph_craft_batch_enable_events");
+    }
+    // one craft's event lists; returns EPH_OK or EPH_EVENTS_FULL (read, reset_events(), resume)
+    int32_t events(int64_t craft, SoiTransitions &transitions, Apsides &apsides) const {
+        const size_t n = static_cast<size_t>(n_), c = static_cast<size_t>(craft);
+        std::vector<int32_t> ntr(n), nap(n), st(n);
+        detail::check(eph_craft_batch_event_counts(h_, ntr.data(), nap.data(), st.data()), "eph_craft_batch_event_counts");
+        transitions.time.assign(static_cast<size_t>(ntr[c]), 0.0);
+        transitions.body.assign(static_cast<size_t>(ntr[c]), 0);
+        apsides.time.assign(static_cast<size_t>(nap[c]), 0.0);
+        apsides.distance.assign(static_cast<size_t>(nap[c]), 0.0);
+        apsides.body.assign(static_cast<size_t>(nap[c]), 0);
+        apsides.kind.assign(static_cast<size_t>(nap[c]), 0);
+        detail::check(eph_craft_batch_events(h_, craft, transitions.time.data(), transitions.body.data(), apsides.time.data(), apsides.distance.data(),
+                                             apsides.body.data(), apsides.kind.data()), "eph_craft_batch_events");
+        return st[c];
+    }
+    void reset_knots() { detail::check(eph_craft_batch_reset_knots(h_), "eph_craft_batch_reset_knots"); }      // drain point of a long propagation
+    void reset_events() { detail::check(eph_craft_batch_reset_events(h_), "eph_craft_batch_reset_events"); }
+    // the order Bodies::acceleration adds the massive bodies' terms in (an EntityHashMap upstream: unspecified); default = table order
+    void set_body_order(const std::vector<int32_t> &order) { detail::check(eph_craft_batch_set_body_order(h_, order.data()), "eph_craft_batch_set_body_order"); }
+    SpacecraftBatch clone() const {                                                                            // #[derive(Clone)]: the UI's snapshots
+        eph_craft_batch *c = nullptr;
+        detail::check(eph_craft_batch_clone(h_, &c), "eph_craft_batch_clone");
+        return SpacecraftBatch(c, n_);
+    }
+    SpacecraftBatch(SpacecraftBatch &&o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
     int64_t len() const { return n_; }
 
 private:
+    SpacecraftBatch(eph_craft_batch *h, int64_t n) : h_(h), n_(n) {}
     eph_craft_batch *h_ = nullptr;
     int64_t n_ = 0;
 };
+
+inline double divergence_time_before(const std::vector<Burn> &old_burns, const std::vector<Burn> &new_burns, double before) {
+    struct Csr { std::vector<double> s, e, a; std::vector<int32_t> r; };
+    auto pack = [](const std::vector<Burn> &b) {
+        Csr c;
+        for (const Burn &x : b) { c.s.push_back(x.start); c.e.push_back(x.end); c.r.push_back(x.reference); c.a.insert(c.a.end(), x.acceleration.begin(), x.acceleration.end()); }
+        return c;
+    };
+    const Csr o = pack(old_burns), n = pack(new_burns);
+    double at = 0.0;
+    detail::check(eph_timeline_divergence_time(static_cast<int64_t>(old_burns.size()), o.s.data(), o.e.data(), o.a.data(), o.r.data(),
+                                               static_cast<int64_t>(new_burns.size()), n.s.data(), n.e.data(), n.a.data(), n.r.data(), before, &at),
+                  "eph_timeline_divergence_time");
+    return at;
+}
 
 }  // namespace ephemeris_amd
