@@ -50,7 +50,9 @@ ABI_SYMBOLS = [
     "eph_prop_propagate", "eph_prop_clone", "eph_prop_destroy", "eph_prop_integrator",
     "eph_solution_bodies", "eph_solution_info", "eph_solution_coeffs", "eph_solution_eval", "eph_solution_append", "eph_solution_create", "eph_solution_clear", "eph_solution_between",
     "eph_solution_destroy", "eph_least_squares_fit",
-    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_set_body_order", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
+    "eph_ephemeris_create", "eph_ephemeris_destroy", "eph_ephemeris_append", "eph_ephemeris_merge", "eph_ephemeris_clear", "eph_ephemeris_info",
+    "eph_ephemeris_is_valid_at", "eph_ephemeris_export", "eph_ephemeris_import", "eph_craft_batch_retry_failed",
+    "eph_ephemeris_interpolation_errors", "eph_craft_batch_create", "eph_craft_batch_set_body_order", "eph_craft_batch_propagate", "eph_craft_batch_step_n",
     "eph_craft_batch_status", "eph_craft_batch_state", "eph_craft_batch_summary", "eph_craft_batch_knots", "eph_craft_batch_kernel_time",
     "eph_craft_batch_clone", "eph_craft_batch_knot_slabs", "eph_craft_batch_reset_knots", "eph_craft_batch_reset_events", "eph_timeline_divergence_time", "eph_craft_batch_enable_events", "eph_craft_batch_event_counts", "eph_craft_batch_events",
     "eph_craft_batch_destroy", "eph_hermite_eval", "eph_hermite_join", "eph_transitions_join", "eph_apsides_join", "eph_plot_points",
@@ -185,6 +187,14 @@ def _lib():
     L.eph_ephemeris_interpolation_errors.argtypes = [vp, vp, i64, _dp, C.POINTER(i64)]
     L.eph_ephemeris_destroy.argtypes = [vp]
     L.eph_ephemeris_destroy.restype = None
+    L.eph_ephemeris_append.argtypes = [vp, vp, i32]
+    L.eph_ephemeris_merge.argtypes = [vp, vp, i32]
+    L.eph_ephemeris_clear.argtypes = [vp, i32, f64, i32]
+    L.eph_ephemeris_info.argtypes = [vp, i32, _dp, _dp, _i64p, C.POINTER(C.c_uint64)]
+    L.eph_ephemeris_is_valid_at.argtypes = [vp, f64, _i32p]
+    L.eph_ephemeris_export.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.eph_ephemeris_import.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.eph_craft_batch_retry_failed.argtypes = [vp]
     L.eph_craft_batch_create.argtypes = [vp, i64, _dp, _dp, _dp, C.c_char_p, C.POINTER(AdaptiveParams), _i64p, _dp, _dp,
                                          _dp, _i32p, i32, C.POINTER(vp)]
     L.eph_craft_batch_propagate.argtypes = [vp, f64]
@@ -214,7 +224,7 @@ def _lib():
     L.eph_transitions_join.argtypes = [i64, _dp, _i32p, i64, _dp, _i32p, f64, i64, _dp, _i32p, _i64p]
     L.eph_apsides_join.argtypes = [i64, _dp, _dp, _i32p, _i32p, i64, _dp, _dp, _i32p, _i32p, f64, i64, _dp, _dp, _i32p,
                                    _i32p, _i64p]
-    if L.eph_abi_version() != 2:
+    if L.eph_abi_version() != 3:
         raise ImportError("libephemeris_amd.so ABI version mismatch")
     _L = L
     return L
@@ -670,6 +680,70 @@ class Ephemeris:
         self._h = h_
         self.n_bodies = len(mu)
 
+    # ---- the table is LIVE, like the reference's Arc<RwLock<PredictionTrajectory>> (dynamics/mod.rs:84-85): every batch bound to
+    # it sees the new extent at its next call
+    def append(self, tail, direction=FORWARD):
+        """UniformSpline::append (FORWARD) / prepend (BACKWARD) for every body (trajectory.rs:515-534); raises ValueError where the
+        reference's assert_eq! would panic, the table untouched."""
+        st = self._L.eph_ephemeris_append(self._h, tail._h, int(direction))
+        if st == ERR_BAD_ARGUMENT:
+            raise ValueError("eph_ephemeris_append: not contiguous (trajectory.rs:517-518,530-531)")
+        _check(st, "eph_ephemeris_append")
+        return self
+
+    def merge(self, propagated, direction=FORWARD):
+        """PredictionTarget::merge for the bodies (dynamics/celestial.rs:198-204 Forward, :220-226 Backward)."""
+        st = self._L.eph_ephemeris_merge(self._h, propagated._h, int(direction))
+        if st == ERR_BAD_ARGUMENT:
+            raise ValueError("eph_ephemeris_merge: not contiguous (trajectory.rs:517-518,530-531)")
+        _check(st, "eph_ephemeris_merge")
+        return self
+
+    def clear_before(self, at, body=-1):
+        _check(self._L.eph_ephemeris_clear(self._h, int(body), float(at), 0), "eph_ephemeris_clear")
+        return self
+
+    def clear_after(self, at, body=-1):
+        _check(self._L.eph_ephemeris_clear(self._h, int(body), float(at), 1), "eph_ephemeris_clear")
+        return self
+
+    def info(self, body):
+        """(start, interval, npoly) of one body's spline as it is now"""
+        s_, iv, npoly = C.c_double(), C.c_double(), C.c_int64()
+        _check(self._L.eph_ephemeris_info(self._h, int(body), C.byref(s_), C.byref(iv), C.byref(npoly), None), "eph_ephemeris_info")
+        return s_.value, iv.value, npoly.value
+
+    @property
+    def revision(self):
+        r = C.c_uint64()
+        _check(self._L.eph_ephemeris_info(self._h, -1, None, None, None, C.byref(r)), "eph_ephemeris_info")
+        return r.value
+
+    def is_valid_at(self, t):
+        """Bodies::is_valid_at (dynamics/spacecraft.rs:206-208)"""
+        f = C.c_int32()
+        _check(self._L.eph_ephemeris_is_valid_at(self._h, float(t), C.byref(f)), "eph_ephemeris_is_valid_at")
+        return bool(f.value)
+
+    def export_image(self):
+        """One contiguous image of the table (numpy uint8): what rank 0 broadcasts (parallel.broadcast_ephemeris)."""
+        need = C.c_uint64()
+        self._L.eph_ephemeris_export(self._h, None, 0, C.byref(need))
+        buf = np.empty(need.value, dtype=np.uint8)
+        _check(self._L.eph_ephemeris_export(self._h, buf.ctypes.data_as(C.c_void_p), need.value, C.byref(need)), "eph_ephemeris_export")
+        return buf
+
+    @classmethod
+    def from_image(cls, image):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        L = _lib()
+        h_ = C.c_void_p()
+        _check(L.eph_ephemeris_import(image.ctypes.data_as(C.c_void_p), image.size, C.byref(h_)), "eph_ephemeris_import")
+        e = object.__new__(cls)
+        e._L, e._h = L, h_
+        e.n_bodies = int(np.frombuffer(image[8:16].tobytes(), dtype=np.uint64)[0])
+        return e
+
     def interpolation_errors(self, integration, n_steps):
         """debug.rs:182-238: advance `integration` (NBodyIntegration over the same bodies) up to n_steps steps, or to its
         bound, and return (max |position - spline position| per body in metres, steps taken)."""
@@ -724,6 +798,12 @@ class SpacecraftBatch:
         c = object.__new__(SpacecraftBatch)
         c._L, c.ephemeris, c.n, c.params, c._h = self._L, self.ephemeris, self.n, self.params, h_
         return c
+
+    def retry_failed(self):
+        """Re-arm: the NEXT propagate / step_n steps the craft whose last step returned a StepError too -- the reference's next
+        step() on a propagator that returned Err (how a stored ship propagator resumes once the ephemeris has grown)."""
+        _check(self._L.eph_craft_batch_retry_failed(self._h), "eph_craft_batch_retry_failed")
+        return self
 
     def propagate(self, t_end):
         """step_to(t_end) for every craft; per-craft outcomes in status()"""

@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "craft_device.h"
@@ -686,14 +688,28 @@ static int craft_launch(int pv, hipStream_t s, const CraftArgs &a, bool heteroge
 
 using namespace eph;
 
+// The device-resident Vec<UniformSpline> of the massive bodies. LIVE, like the reference's: GravitationalBody.trajectory is
+// Trajectory(Arc<RwLock<PredictionTrajectory>>) (ephemeris_explorer/src/dynamics/spacecraft.rs:52-74, dynamics/mod.rs:84-85), merged
+// N-body snapshots grow it (dynamics/celestial.rs:198-204,220-226 -> UniformSpline::append / prepend / clear_*,
+// ephemeris/src/trajectory.rs:515-549) and every spacecraft propagator holding the context sees the new extent at its next
+// evaluation. Here: `splines` is the authoritative host copy (the reference's own operations, host.h), the device table follows it
+// incrementally -- body b owns rows [base[b], base[b] + cap[b]) of `coeffs` / `ncoef` with its polynomials at coeff_off .. +npoly, so
+// an append uploads the new rows only and a clear moves two integers; a region that overflows re-lays the table with headroom
+// proportional to its size (amortised O(1) per polynomial). `mu` is the RwLock: sweeps, plots and scans hold it shared for the
+// whole (synchronous) call, append / clear exclusively -- a writer never changes rows a kernel is reading.
 struct eph_ephemeris {
     int device = 0;
     int n_bodies = 0;
+    mutable std::shared_mutex mu;
+    uint64_t revision = 0;                     // bumped by every append / clear
+    std::vector<UniformSpline> splines;
+    std::vector<double> gm;
     DevBuf<BodyEntry> bodies;
     DevBuf<double> coeffs;
     DevBuf<int> ncoef;
-    std::vector<BodyEntry> host_bodies;
-    std::vector<double> host_coeffs;           // the coefficient rows as uploaded (host-side estimates only, never results)
+    std::vector<BodyEntry> host_bodies;        // what `bodies` holds (rinv: filled on the device only)
+    std::vector<long long> base, cap;          // body b's region of rows
+    std::vector<char> grows_front;             // body b has been prepended to: keep headroom in front as well
 };
 
 struct eph_craft_batch {
@@ -706,7 +722,7 @@ struct eph_craft_batch {
     int max_knots = 0;
     ErkCoeffs rk{};
     eph_adaptive_params params{};
-    DevBuf<double> time, y, next_h, klast, last_knot, knot_t, knot_y;
+    DevBuf<double> time, y, next_h, klast, kfirst, last_knot, knot_t, knot_y;   // klast / kfirst: the FSAL pairs' k[S-1] / k[0] between calls
     DevBuf<unsigned> n_attempts, rk_i, steps;
     DevBuf<int> cur_seg, status, nknots;
     DevBuf<long long> seg_off;
@@ -715,7 +731,10 @@ struct eph_craft_batch {
     DevBuf<eph_craft_record> summary;         // eph_craft_batch_summary's device-side records (a clone's: on first use)
     DevBuf<unsigned long long> queue;         // k_craft_queue's work queue (one counter)
     bool heterogeneous = false;               // the craft's dynamical time scales differ widely (craft_time_scales): queue form
-    DevBuf<BodyEntry> bodies_ordered;         // eph_craft_batch_set_body_order: the ephemeris's table permuted (empty: table order)
+    DevBuf<BodyEntry> bodies_ordered;         // eph_craft_batch_set_body_order: the ephemeris's table permuted (empty: table order),
+    DevBuf<int> body_order_dev;               //   re-gathered from the live table before every sweep
+    std::vector<int32_t> body_order;
+    bool retry = false;                       // eph_craft_batch_retry_failed: the next sweep steps the craft whose last step failed
     DevBuf<int> perm, slot_of;                // heterogeneous batches: lane / queue position -> craft by dynamical time, and back
     std::vector<int> h_slot;                  //   (craft_sort); the knot slabs' columns are lane positions
     // SpacecraftSolout events (optional)
@@ -803,6 +822,31 @@ __global__ void __launch_bounds__(256) k_rows_to_craft_order(long long rows, lon
     const long long col = slot_of[i];
     for (long long r = 0; r < rows; ++r) dst[r * n + i] = src[r * n + col];
 }
+// one 80-byte record per craft from the SoA state arrays (coalesced reads, one record per thread written as ten 8-byte words)
+__global__ void __launch_bounds__(256) k_craft_summary(long long n, const double *__restrict__ time, const double *__restrict__ y,
+                                                       const double *__restrict__ next_h, const int *__restrict__ status,
+                                                       const int *__restrict__ nknots, const unsigned *__restrict__ attempts,
+                                                       const unsigned *__restrict__ steps, eph_craft_record *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    eph_craft_record r;
+    r.t = time[i];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { r.pos[d] = y[d * n + i]; r.vel[d] = y[(3 + d) * n + i]; }
+    r.next_h = next_h[i];
+    r.status = status[i];
+    r.nknots = nknots[i];
+    r.attempts = attempts[i];
+    r.steps = steps[i];
+    out[i] = r;
+}
+// the ephemeris's table entries in the order Bodies::acceleration visits them (eph_craft_batch_set_body_order), gathered from the LIVE
+// table before every sweep: the entries change when the ephemeris grows
+__global__ void __launch_bounds__(64) k_permute_bodies(int n, const int *__restrict__ order, const BodyEntry *__restrict__ table,
+                                                       BodyEntry *__restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = table[order[q]];
+}
 // Which craft a lane integrates is free (craft are independent, every craft's operations are the reference's whoever runs them),
 // so every thread-per-craft batch is dealt to the lanes in the order of k_craft_tau's estimate -- a stable radix sort on the host,
 // shortest orbit first (most steps first). The lanes of a wave then carry craft of similar step counts: on the mixed population
@@ -876,23 +920,26 @@ static int craft_sort(eph_craft_batch *b) {
 }
 
 static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const double *t0, const double *pos) {
-    if (n < 128 || e.host_coeffs.empty()) return false;
+    if (n < 128 || e.splines.empty()) return false;
     auto tau_of = [&](long long i) {
         double best = INFINITY;
-        for (const BodyEntry &b : e.host_bodies) {
-            if (!(b.mu > 0.0) || b.npoly <= 0) continue;
-            const double local = t0[i] - b.start;
-            if (!(local >= 0.0) || local > b.span) continue;
-            long long idx = (long long)std::ceil(local / b.interval) - 1;
-            idx = std::min(std::max<long long>(idx, 0), b.npoly - 1);
-            const double tq = (local - b.interval * (double)idx) / b.interval;
-            const double *c = &e.host_coeffs[(size_t)(b.coeff_off + idx) * kDiv * 3];
+        for (size_t q = 0; q < e.splines.size(); ++q) {
+            const UniformSpline &u = e.splines[q];
+            const double mu = e.gm[q];
+            const long long npoly = (long long)u.polynomials.size();
+            if (!(mu > 0.0) || npoly <= 0) continue;
+            const double local = t0[i] - u.start;
+            if (!(local >= 0.0) || local > u.span()) continue;
+            long long idx = (long long)std::ceil(local / u.interval) - 1;
+            idx = std::min(std::max<long long>(idx, 0), npoly - 1);
+            const double tq = (local - u.interval * (double)idx) / u.interval;
+            const Polynomial &p = u.polynomials[(size_t)idx];
             double bp[3] = {0.0, 0.0, 0.0};
-            for (int k = kDiv - 1; k >= 0; --k)
-                for (int d = 0; d < 3; ++d) bp[d] = bp[d] * tq + c[k * 3 + d];
+            for (int k = std::min(std::max(p.ncoef, 0), kDiv) - 1; k >= 0; --k)
+                for (int d = 0; d < 3; ++d) bp[d] = bp[d] * tq + p.c[k][d];
             const double dx = pos[3 * i] - bp[0], dy = pos[3 * i + 1] - bp[1], dz = pos[3 * i + 2] - bp[2];
             const double d2 = dx * dx + dy * dy + dz * dz;
-            best = std::min(best, std::sqrt(d2 * std::sqrt(d2) / b.mu));
+            best = std::min(best, std::sqrt(d2 * std::sqrt(d2) / mu));
         }
         return best;
     };
@@ -909,6 +956,94 @@ static bool craft_time_scales_differ(const eph_ephemeris &e, long long n, const 
         if (hi > 4.0 * lo) return true;
     }
     return false;
+}
+
+// ---- the device table behind an eph_ephemeris ---------------------------------------------------------------------------
+// one polynomial -> one zero-padded row of 8 x 3 doubles (rows >= ncoef stay +0.0: craft_rhs runs Horner over all kDiv rows)
+static void eph_fill_row(const Polynomial &p, double *row, int *nc) {
+    std::memset(row, 0, sizeof(double) * kDiv * 3);
+    std::memcpy(row, &p.c[0][0], sizeof(double) * 3 * (size_t)std::min(std::max(p.ncoef, 0), kDiv));
+    *nc = p.ncoef;
+}
+// polynomials [first, first + count) of body b's host spline -> device rows starting at `row`
+static int eph_upload_rows(eph_ephemeris *e, int b, size_t first, size_t count, long long row) {
+    if (count == 0) return EPH_OK;
+    std::vector<double> co(count * kDiv * 3);
+    std::vector<int> nc(count);
+    const UniformSpline &u = e->splines[(size_t)b];
+    for (size_t k = 0; k < count; ++k) eph_fill_row(u.polynomials[first + k], &co[k * kDiv * 3], &nc[k]);
+    EPH_HIP(hipMemcpy(e->coeffs.p + (size_t)row * kDiv * 3, co.data(), sizeof(double) * co.size(), hipMemcpyHostToDevice));
+    EPH_HIP(hipMemcpy(e->ncoef.p + row, nc.data(), sizeof(int) * nc.size(), hipMemcpyHostToDevice));
+    return EPH_OK;
+}
+// host_bodies -> the device table (+ the refined reciprocals of the intervals, formed on the device like the sweep kernels would)
+static int eph_upload_bodies(eph_ephemeris *e) {
+    const int nb = e->n_bodies;
+    for (int b = 0; b < nb; ++b) {
+        const UniformSpline &u = e->splines[(size_t)b];
+        BodyEntry &be = e->host_bodies[(size_t)b];
+        be.start = u.start; be.interval = u.interval; be.mu = e->gm[(size_t)b];
+        be.npoly = (long long)u.polynomials.size();
+        be.span = u.interval * (double)u.polynomials.size();     // interval.scaled(len): the product UniformSpline::span() forms
+        be.rinv = 0.0; be.pad_ = 0.0;
+    }
+    if (!nb) return EPH_OK;
+    EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * (size_t)nb, hipMemcpyHostToDevice));
+    k_body_reciprocals<<<(nb + 63) / 64, 64>>>(nb, e->bodies.p);
+    EPH_HIP(hipGetLastError());
+    EPH_HIP(hipStreamSynchronize(nullptr));
+    return EPH_OK;
+}
+// lay the table out afresh from the host splines: every body's region gets room for as many polynomials again behind it (and in
+// front, for a body that grows backwards)
+static int eph_rebuild(eph_ephemeris *e) {
+    const int nb = e->n_bodies;
+    e->host_bodies.assign((size_t)std::max(nb, 0), BodyEntry{});
+    e->base.assign((size_t)nb, 0);
+    e->cap.assign((size_t)nb, 0);
+    long long total = 0;
+    for (int b = 0; b < nb; ++b) {
+        const long long np = (long long)e->splines[(size_t)b].polynomials.size();
+        const long long room = std::max<long long>(np, 32);
+        const long long front = e->grows_front[(size_t)b] ? room : 0;
+        e->base[(size_t)b] = total;
+        e->cap[(size_t)b] = front + np + room;
+        e->host_bodies[(size_t)b].coeff_off = total + front;
+        total += e->cap[(size_t)b];
+    }
+    DevBuf<double> co;
+    DevBuf<int> nc;
+    int st;
+    if ((st = co.alloc((size_t)std::max<long long>(total, 1) * kDiv * 3)) || (st = nc.alloc((size_t)std::max<long long>(total, 1)))) return st;
+    std::swap(e->coeffs.p, co.p); std::swap(e->coeffs.count, co.count);
+    std::swap(e->ncoef.p, nc.p); std::swap(e->ncoef.count, nc.count);
+    if (!e->bodies.p && (st = e->bodies.alloc((size_t)std::max(nb, 1)))) return st;
+    for (int b = 0; b < nb; ++b)
+        if ((st = eph_upload_rows(e, b, 0, e->splines[(size_t)b].polynomials.size(), e->host_bodies[(size_t)b].coeff_off))) return st;
+    return eph_upload_bodies(e);
+}
+// the device table after the host splines changed: `back[b]` / `front[b]` polynomials were added behind / in front of body b,
+// `dropped_front[b]` removed from its front (clear_before); a truncation (clear_after) needs no row traffic at all
+static int eph_follow(eph_ephemeris *e, const std::vector<long long> &front, const std::vector<long long> &back,
+                      const std::vector<long long> &dropped_front) {
+    const int nb = e->n_bodies;
+    bool fits = true;
+    for (int b = 0; b < nb && fits; ++b) {
+        const BodyEntry &be = e->host_bodies[(size_t)b];
+        const long long off = be.coeff_off - e->base[(size_t)b] + dropped_front[(size_t)b];
+        const long long np = (long long)e->splines[(size_t)b].polynomials.size();     // already the new count
+        if (front[(size_t)b] > off || off - front[(size_t)b] + np > e->cap[(size_t)b]) fits = false;
+    }
+    if (!fits) return eph_rebuild(e);
+    int st;
+    for (int b = 0; b < nb; ++b) {
+        BodyEntry &be = e->host_bodies[(size_t)b];
+        be.coeff_off += dropped_front[(size_t)b] - front[(size_t)b];
+        const size_t np = e->splines[(size_t)b].polynomials.size();
+        if ((st = eph_upload_rows(e, b, 0, (size_t)front[(size_t)b], be.coeff_off))) return st;
+        if ((st = eph_upload_rows(e, b, np - (size_t)back[(size_t)b], (size_t)back[(size_t)b], be.coeff_off + (long long)np - back[(size_t)b]))) return st;
+    }
+    return eph_upload_bodies(e);
 }
 
 // Timeline::new  ephemeris/src/propagators/spacecraft.rs:129-152: stable sort by start, coast segments in the gaps,
@@ -951,40 +1086,217 @@ int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_epheme
         EPH_HIP(hipGetDevice(&e->device));
         const int nb = (int)s->s.splines.size();
         e->n_bodies = nb;
-        long long total = 0;
-        for (int b = 0; b < nb; ++b) {
-            const UniformSpline &u = s->s.splines[b];
-            BodyEntry be{u.start, u.interval, mu[b], (long long)u.polynomials.size(), total,
-                         u.interval * (double)u.polynomials.size(), 0.0, 0.0};
-            e->host_bodies.push_back(be);
-            total += be.npoly;
-        }
-        std::vector<double> co((size_t)std::max<long long>(total, 1) * kDiv * 3, 0.0);
-        std::vector<int> nc((size_t)std::max<long long>(total, 1), 0);
-        long long q = 0;
-        for (int b = 0; b < nb; ++b)
-            for (const Polynomial &p : s->s.splines[b].polynomials) {
-                nc[q] = p.ncoef;
-                // rows >= ncoef stay +0.0: craft_rhs runs Horner over all kDiv rows
-                std::memcpy(&co[q * kDiv * 3], &p.c[0][0], sizeof(double) * 3 * (size_t)std::min(std::max(p.ncoef, 0), kDiv));
-                ++q;
-            }
-        if ((st = e->bodies.alloc(std::max(nb, 1))) || (st = e->coeffs.alloc(co.size())) || (st = e->ncoef.alloc(nc.size())))
-            return st;
-        if (nb) {
-            EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * nb, hipMemcpyHostToDevice));
-            k_body_reciprocals<<<(nb + 63) / 64, 64>>>(nb, e->bodies.p);
-            EPH_HIP(hipGetLastError());
-            EPH_HIP(hipDeviceSynchronize());
-        }
-        EPH_HIP(hipMemcpy(e->coeffs.p, co.data(), sizeof(double) * co.size(), hipMemcpyHostToDevice));
-        EPH_HIP(hipMemcpy(e->ncoef.p, nc.data(), sizeof(int) * nc.size(), hipMemcpyHostToDevice));
-        e->host_coeffs = std::move(co);
+        e->splines = s->s.splines;
+        for (const UniformSpline &u : e->splines)
+            if (u.ghost) return EPH_ERR_BAD_ARGUMENT;             // (only inside a propagator; never in a Solution handed out)
+        e->gm.assign(mu, mu + nb);
+        e->grows_front.assign((size_t)nb, 0);
+        if ((st = eph_rebuild(e.get()))) return st;
         *out = e.release();
         return EPH_OK;
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 void eph_ephemeris_destroy(eph_ephemeris *e) { delete e; }
+
+// UniformSpline::append (direction > 0) / prepend (< 0) for every body  trajectory.rs:515-534; the asserts become EPH_ERR_BAD_ARGUMENT
+// with the table untouched
+int32_t eph_ephemeris_append(eph_ephemeris *e, const eph_solution *tail, int32_t direction) {
+    try {
+        if (!e || !tail || direction == 0 || tail->s.splines.size() != e->splines.size()) return EPH_ERR_BAD_ARGUMENT;
+        std::unique_lock<std::shared_mutex> lock(e->mu);
+        const size_t nb = e->splines.size();
+        for (size_t b = 0; b < nb; ++b) {
+            const UniformSpline &x = e->splines[b], &y = tail->s.splines[b];
+            if (y.ghost || x.interval != y.interval) return EPH_ERR_BAD_ARGUMENT;
+            if (direction > 0 ? (x.end() != y.start) : (x.start != y.end())) return EPH_ERR_BAD_ARGUMENT;
+        }
+        EPH_HIP(hipSetDevice(e->device));
+        std::vector<long long> front(nb, 0), back(nb, 0), none(nb, 0);
+        for (size_t b = 0; b < nb; ++b) {
+            UniformSpline &x = e->splines[b];
+            const UniformSpline &y = tail->s.splines[b];
+            if (direction > 0) {
+                x.polynomials.insert(x.polynomials.end(), y.polynomials.begin(), y.polynomials.end());
+                back[b] = (long long)y.polynomials.size();
+            } else {
+                x.start = y.start;
+                x.polynomials.insert(x.polynomials.begin(), y.polynomials.begin(), y.polynomials.end());
+                front[b] = (long long)y.polynomials.size();
+                if (front[b]) e->grows_front[b] = 1;
+            }
+        }
+        e->revision += 1;
+        return eph_follow(e, front, back, none);
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+// UniformSpline::clear_before (after = 0, trajectory.rs:536-542) / clear_after (after != 0, :544-549) on body's spline or on all (body < 0)
+int32_t eph_ephemeris_clear(eph_ephemeris *e, int32_t body, double at, int32_t after) {
+    try {
+        if (!e || body >= e->n_bodies) return EPH_ERR_BAD_ARGUMENT;
+        std::unique_lock<std::shared_mutex> lock(e->mu);
+        EPH_HIP(hipSetDevice(e->device));
+        const size_t nb = e->splines.size();
+        std::vector<long long> none(nb, 0), dropped(nb, 0);
+        for (size_t b = 0; b < nb; ++b) {
+            if (body >= 0 && (size_t)body != b) continue;
+            UniformSpline &u = e->splines[b];
+            const size_t before = u.polynomials.size();
+            if (after) u.clear_after(at);
+            else { u.clear_before(at); dropped[b] = (long long)(before - u.polynomials.size()); }
+        }
+        e->revision += 1;
+        return eph_follow(e, none, none, dropped);
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+// CelestialTrajectory::merge  ephemeris_explorer/src/dynamics/celestial.rs:198-204 (Forward: clear_after(propagated.start()) then
+// append) and :220-226 (Backward: clear_before(propagated.end()) then prepend), body by body
+int32_t eph_ephemeris_merge(eph_ephemeris *e, const eph_solution *propagated, int32_t direction) {
+    try {
+        if (!e || !propagated || direction == 0 || propagated->s.splines.size() != e->splines.size()) return EPH_ERR_BAD_ARGUMENT;
+        std::unique_lock<std::shared_mutex> lock(e->mu);
+        const size_t nb = e->splines.size();
+        // the reference's asserts, evaluated on copies of the bounds first so that a refusal leaves the table untouched
+        for (size_t b = 0; b < nb; ++b) {
+            const UniformSpline &y = propagated->s.splines[b];
+            UniformSpline x;
+            x.start = e->splines[b].start; x.interval = e->splines[b].interval;
+            x.ghost = e->splines[b].polynomials.size();            // bounds only: no polynomial is copied
+            if (y.ghost || x.interval != y.interval) return EPH_ERR_BAD_ARGUMENT;
+            if (direction > 0) {
+                uint64_t idx;
+                if (x.get_index_local(y.start - x.start, &idx) && idx < x.ghost) x.ghost = idx;       // clear_after
+                if (x.end() != y.start) return EPH_ERR_BAD_ARGUMENT;
+            } else {
+                uint64_t idx;
+                if (x.get_index_local_exclusive((y.end() + x.interval) - x.start, &idx)) {             // clear_before
+                    x.start += x.interval * (double)idx;
+                    x.ghost -= std::min<uint64_t>(idx, x.ghost);
+                }
+                if (x.start != y.end()) return EPH_ERR_BAD_ARGUMENT;
+            }
+        }
+        EPH_HIP(hipSetDevice(e->device));
+        std::vector<long long> front(nb, 0), back(nb, 0), dropped(nb, 0);
+        for (size_t b = 0; b < nb; ++b) {
+            UniformSpline &x = e->splines[b];
+            const UniformSpline &y = propagated->s.splines[b];
+            if (direction > 0) {
+                x.clear_after(y.start);
+                x.polynomials.insert(x.polynomials.end(), y.polynomials.begin(), y.polynomials.end());
+                back[b] = (long long)y.polynomials.size();
+            } else {
+                const size_t before = x.polynomials.size();
+                x.clear_before(y.end());
+                dropped[b] = (long long)(before - x.polynomials.size());
+                x.start = y.start;
+                x.polynomials.insert(x.polynomials.begin(), y.polynomials.begin(), y.polynomials.end());
+                front[b] = (long long)y.polynomials.size();
+                if (front[b]) e->grows_front[b] = 1;
+            }
+        }
+        e->revision += 1;
+        return eph_follow(e, front, back, dropped);
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+int32_t eph_ephemeris_info(const eph_ephemeris *e, int32_t body, double *start, double *interval, int64_t *npoly, uint64_t *revision) {
+    if (!e || body >= e->n_bodies) return EPH_ERR_BAD_ARGUMENT;
+    std::shared_lock<std::shared_mutex> lock(e->mu);
+    if (body >= 0) {
+        const UniformSpline &u = e->splines[(size_t)body];
+        if (start) *start = u.start;
+        if (interval) *interval = u.interval;
+        if (npoly) *npoly = (int64_t)u.polynomials.size();
+    } else if (start || interval || npoly) return EPH_ERR_BAD_ARGUMENT;
+    if (revision) *revision = e->revision;
+    return EPH_OK;
+}
+// Bodies::is_valid_at  dynamics/spacecraft.rs:199-201: every body's trajectory.contains(t) (trajectory.rs:437-441:
+// local.is_positive() && local <= span -- ftime's Duration::is_positive is f64::is_sign_positive, duration.rs:78-80: the sign BIT,
+// so the start itself (+0.0) is contained)
+int32_t eph_ephemeris_is_valid_at(const eph_ephemeris *e, double t, int32_t *flag) {
+    if (!e || !flag) return EPH_ERR_BAD_ARGUMENT;
+    std::shared_lock<std::shared_mutex> lock(e->mu);
+    bool all = true;
+    for (const UniformSpline &u : e->splines) {
+        const double local = t - u.start;
+        all = all && (!std::signbit(local) && local <= u.span());
+    }
+    *flag = all ? 1 : 0;
+    return EPH_OK;
+}
+// One contiguous, position-independent image of the table (what rank 0 broadcasts to the other ranks of a sweep):
+// header, per body {start, interval, mu, npoly}, then every polynomial's zero-padded row and coefficient count.
+namespace {
+struct EphImageHeader { uint64_t magic, n_bodies, n_polys, reserved; };
+constexpr uint64_t kEphImageMagic = 0x3130485045485045ull;     // "EPHEPH01"
+struct EphImageBody { double start, interval, mu; int64_t npoly; };
+}
+int32_t eph_ephemeris_export(const eph_ephemeris *e, void *buf, uint64_t capacity, uint64_t *bytes) {
+    try {
+        if (!e || !bytes) return EPH_ERR_BAD_ARGUMENT;
+        std::shared_lock<std::shared_mutex> lock(e->mu);
+        uint64_t polys = 0;
+        for (const UniformSpline &u : e->splines) polys += u.polynomials.size();
+        const uint64_t need = sizeof(EphImageHeader) + sizeof(EphImageBody) * e->splines.size() +
+                              polys * (sizeof(double) * kDiv * 3 + sizeof(int64_t));
+        *bytes = need;
+        if (!buf || capacity < need) return EPH_ERR_BAD_ARGUMENT;
+        char *w = static_cast<char *>(buf);
+        const EphImageHeader h{kEphImageMagic, (uint64_t)e->splines.size(), polys, 0};
+        std::memcpy(w, &h, sizeof(h)); w += sizeof(h);
+        for (size_t b = 0; b < e->splines.size(); ++b) {
+            const UniformSpline &u = e->splines[b];
+            const EphImageBody ib{u.start, u.interval, e->gm[b], (int64_t)u.polynomials.size()};
+            std::memcpy(w, &ib, sizeof(ib)); w += sizeof(ib);
+        }
+        for (const UniformSpline &u : e->splines)
+            for (const Polynomial &p : u.polynomials) {
+                double row[kDiv * 3];
+                int nc;
+                eph_fill_row(p, row, &nc);
+                const int64_t nc64 = nc;
+                std::memcpy(w, row, sizeof(row)); w += sizeof(row);
+                std::memcpy(w, &nc64, sizeof(nc64)); w += sizeof(nc64);
+            }
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+int32_t eph_ephemeris_import(const void *buf, uint64_t bytes, eph_ephemeris **out) {
+    try {
+        if (!buf || !out || bytes < sizeof(EphImageHeader)) return EPH_ERR_BAD_ARGUMENT;
+        *out = nullptr;
+        const char *r = static_cast<const char *>(buf);
+        EphImageHeader h;
+        std::memcpy(&h, r, sizeof(h)); r += sizeof(h);
+        if (h.magic != kEphImageMagic || h.n_bodies > 0x7fffffffu) return EPH_ERR_BAD_ARGUMENT;
+        const uint64_t need = sizeof(EphImageHeader) + sizeof(EphImageBody) * h.n_bodies + h.n_polys * (sizeof(double) * kDiv * 3 + sizeof(int64_t));
+        if (h.n_polys > (1ull << 40) || bytes < need) return EPH_ERR_BAD_ARGUMENT;
+        eph_solution sol;
+        std::vector<double> mu((size_t)h.n_bodies);
+        sol.s.splines.resize((size_t)h.n_bodies);
+        std::vector<int64_t> np((size_t)h.n_bodies);
+        uint64_t total = 0;
+        for (size_t b = 0; b < (size_t)h.n_bodies; ++b) {
+            EphImageBody ib;
+            std::memcpy(&ib, r, sizeof(ib)); r += sizeof(ib);
+            if (ib.npoly < 0) return EPH_ERR_BAD_ARGUMENT;
+            sol.s.splines[b].start = ib.start; sol.s.splines[b].interval = ib.interval;
+            mu[b] = ib.mu; np[b] = ib.npoly; total += (uint64_t)ib.npoly;
+        }
+        if (total != h.n_polys) return EPH_ERR_BAD_ARGUMENT;
+        for (size_t b = 0; b < (size_t)h.n_bodies; ++b)
+            for (int64_t k = 0; k < np[b]; ++k) {
+                Polynomial p;
+                int64_t nc64;
+                std::memcpy(&p.c[0][0], r, sizeof(double) * kDiv * 3); r += sizeof(double) * kDiv * 3;
+                std::memcpy(&nc64, r, sizeof(nc64)); r += sizeof(nc64);
+                if (nc64 < 0 || nc64 > kDiv) return EPH_ERR_BAD_ARGUMENT;
+                p.ncoef = (int32_t)nc64;
+                sol.s.splines[b].polynomials.push_back(p);
+            }
+        return eph_ephemeris_create(&sol, mu.data(), out);
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
 
 int32_t eph_ephemeris_interpolation_errors(const eph_ephemeris *e, eph_nbody *h, int64_t n_steps, double *max_error_m,
                                            int64_t *steps_done) {
@@ -993,6 +1305,7 @@ int32_t eph_ephemeris_interpolation_errors(const eph_ephemeris *e, eph_nbody *h,
         NBodyIntegration *g = h->p;
         const int n = g->n();
         if (n != e->n_bodies || g->sharded()) return EPH_ERR_BAD_ARGUMENT;
+        std::shared_lock<std::shared_mutex> table_lock(e->mu);
         EPH_HIP(hipSetDevice(g->device()));
         DevBuf<double> err;
         DevBuf<int> failed;
@@ -1044,6 +1357,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
         }
         int st = check_device();
         if (st) return st;
+        std::shared_lock<std::shared_mutex> table_lock(e->mu);       // (the deal to the lanes reads the table)
         std::unique_ptr<eph_craft_batch> b(new eph_craft_batch());
         if (!find_erk(method, &b->rk) || !b->rk.has_embedded) return EPH_ERR_BAD_ARGUMENT;
         // ERKN integrates y'' = f(t, y) (P::ODE: SecondOrderODE, nystrom/explicit.rs:60): the spacecraft model is one
@@ -1085,7 +1399,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
         seg_off[n] = (long long)segs.size();
         const size_t nn = (size_t)std::max<long long>(n, 1);
         if ((st = b->time.alloc(nn)) || (st = b->y.alloc(6 * nn)) || (st = b->next_h.alloc(nn)) ||
-            (st = b->klast.alloc(6 * nn)) || (st = b->last_knot.alloc(nn)) || (st = b->n_attempts.alloc(nn)) ||
+            (st = b->klast.alloc(6 * nn)) || (st = b->kfirst.alloc(6 * nn)) || (st = b->last_knot.alloc(nn)) || (st = b->n_attempts.alloc(nn)) ||
             (st = b->rk_i.alloc(nn)) || (st = b->steps.alloc(nn)) || (st = b->cur_seg.alloc(nn)) ||
             (st = b->status.alloc(nn)) || (st = b->nknots.alloc(nn)) || (st = b->seg_off.alloc(n + 1)) ||
             (st = b->segs.alloc(std::max<size_t>(segs.size(), 1))) || (st = b->knot_t.alloc(nn * max_knots)) ||
@@ -1102,6 +1416,7 @@ int32_t eph_craft_batch_create(const eph_ephemeris *e, int64_t n_craft, const do
             EPH_HIP(hipMemcpy(b->last_knot.p, t0, sizeof(double) * n, hipMemcpyHostToDevice));
             EPH_HIP(hipMemcpy(b->y.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
             EPH_HIP(hipMemcpy(b->klast.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+            EPH_HIP(hipMemcpy(b->kfirst.p, ysoa.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice));   // from_problem: k = [state; STAGES]
             EPH_HIP(hipMemcpy(b->next_h.p, hs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
             EPH_HIP(hipMemset(b->n_attempts.p, 0, sizeof(unsigned) * n));
             EPH_HIP(hipMemset(b->rk_i.p, 0, sizeof(unsigned) * n));
@@ -1133,13 +1448,24 @@ static int32_t craft_run(eph_craft_batch *b, double t_end, unsigned step_limit) 
     if (!b) return EPH_ERR_BAD_ARGUMENT;
     if (b->n == 0) return EPH_OK;
     EPH_HIP(hipSetDevice(b->device));
+    // the reference's RwLock read guard (dynamics/mod.rs:84-85), held for the whole synchronous sweep: the table as it is NOW --
+    // every append since the last call is seen, and none lands while the kernels read
+    std::shared_lock<std::shared_mutex> table_lock(b->eph->mu);
+    if (!b->body_order.empty()) {
+        hipLaunchKernelGGL(k_permute_bodies, dim3((unsigned)((b->eph->n_bodies + 63) / 64)), dim3(64), 0, b->stream, b->eph->n_bodies,
+                           b->body_order_dev.p, b->eph->bodies.p, b->bodies_ordered.p);
+        hipError_t pe = hipGetLastError();
+        if (pe != hipSuccess) { set_last_error("k_permute_bodies", pe); return EPH_ERR_HIP; }
+    }
     CraftArgs a{};
     a.n_craft = b->n;
     a.n_bodies = b->eph->n_bodies;
     a.bodies = b->bodies_ordered.p ? b->bodies_ordered.p : b->eph->bodies.p;
     a.bodies_by_index = b->eph->bodies.p;
     a.coeffs = b->eph->coeffs.p; a.ncoef = b->eph->ncoef.p;
-    a.time = b->time.p; a.y = b->y.p; a.next_h = b->next_h.p; a.klast = b->klast.p; a.last_knot_t = b->last_knot.p;
+    a.time = b->time.p; a.y = b->y.p; a.next_h = b->next_h.p; a.klast = b->klast.p; a.kfirst = b->kfirst.p; a.last_knot_t = b->last_knot.p;
+    a.retry = b->retry ? 1 : 0;
+    b->retry = false;
     a.n_attempts = b->n_attempts.p; a.rk_i = b->rk_i.p; a.steps = b->steps.p;
     a.cur_seg = b->cur_seg.p; a.status = b->status.p; a.nknots = b->nknots.p;
     a.seg_off = b->seg_off.p; a.segs = b->segs.p;
@@ -1210,24 +1536,6 @@ int32_t eph_craft_batch_state(eph_craft_batch *b, double *t, double *pos, double
     return EPH_OK;
 }
 
-// one 80-byte record per craft from the SoA state arrays (coalesced reads, one record per thread written as ten 8-byte words)
-__global__ void __launch_bounds__(256) k_craft_summary(long long n, const double *__restrict__ time, const double *__restrict__ y,
-                                                       const double *__restrict__ next_h, const int *__restrict__ status,
-                                                       const int *__restrict__ nknots, const unsigned *__restrict__ attempts,
-                                                       const unsigned *__restrict__ steps, eph_craft_record *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    eph_craft_record r;
-    r.t = time[i];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { r.pos[d] = y[d * n + i]; r.vel[d] = y[(3 + d) * n + i]; }
-    r.next_h = next_h[i];
-    r.status = status[i];
-    r.nknots = nknots[i];
-    r.attempts = attempts[i];
-    r.steps = steps[i];
-    out[i] = r;
-}
 // One 80-byte record per craft packed on the device, one copy into the caller's memory.
 // Round 3's "2-38 ms in summary()" (profiles/r04_sweep_evidence.md): the FIRST read-back after a burst of batch creations starts
 // 15-40 ms late ON THE DEVICE -- rocprofv3 shows the pack kernel's launch issued 1 ms after the sweep kernel ended and the kernel
@@ -1263,24 +1571,35 @@ int32_t eph_craft_batch_summary(eph_craft_batch *b, eph_craft_record *out) {
 // unspecified upstream). Table (file) order by default -- the library test's IndexMap; a maintainer who wants the bits of a given
 // app run passes that run's iteration order here. Burn reference bodies, SOI radii and event body indices keep the table's numbering.
 int32_t eph_craft_batch_set_body_order(eph_craft_batch *b, const int32_t *order) {
+    try {
+        if (!b) return EPH_ERR_BAD_ARGUMENT;
+        EPH_HIP(hipSetDevice(b->device));
+        EPH_HIP(hipStreamSynchronize(b->stream));
+        if (!order) { b->bodies_ordered.release(); b->body_order_dev.release(); b->body_order.clear(); return EPH_OK; }
+        const int n = b->eph->n_bodies;
+        std::vector<char> seen((size_t)std::max(n, 1), 0);
+        for (int q = 0; q < n; ++q) {
+            if (order[q] < 0 || order[q] >= n || seen[(size_t)order[q]]) return EPH_ERR_BAD_ARGUMENT;   // not a permutation
+            seen[(size_t)order[q]] = 1;
+        }
+        // the sweep kernels walk a.bodies front to back: a permuted COPY of the ephemeris's table costs the kernels nothing (an index
+        // array read inside the body loop cost the thread-per-craft kernel 5 %: 35.0 against 33.4 ms); craft_run re-gathers it from
+        // the live table before every sweep (k_permute_bodies)
+        int st;
+        if ((st = b->bodies_ordered.alloc((size_t)std::max(n, 1))) || (st = b->body_order_dev.alloc((size_t)std::max(n, 1)))) return st;
+        b->body_order.assign(order, order + n);
+        if (n) EPH_HIP(hipMemcpy(b->body_order_dev.p, order, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+        return EPH_OK;
+    } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
+}
+// IncrementalPropagator::step on a propagator whose last step returned Err (ephemeris/src/propagators/spacecraft.rs:598-615): nothing
+// in the reference remembers the failure -- the next step() simply runs AdaptiveRungeKuttaIntegrator::advance again from the state the
+// failed attempt left (runge_kutta/mod.rs:414-439). A sweep must not do that implicitly (a drain loop would re-attempt the failed craft
+// of a batch on every pass, and a failed attempt is not idempotent: see the header), so the batch keeps a StepError sticky until this
+// call re-arms it: the NEXT propagate / step_n then steps every craft whatever its last status.
+int32_t eph_craft_batch_retry_failed(eph_craft_batch *b) {
     if (!b) return EPH_ERR_BAD_ARGUMENT;
-    EPH_HIP(hipSetDevice(b->device));
-    EPH_HIP(hipStreamSynchronize(b->stream));
-    if (!order) { b->bodies_ordered.release(); return EPH_OK; }
-    const int n = b->eph->n_bodies;
-    std::vector<char> seen((size_t)std::max(n, 1), 0);
-    for (int q = 0; q < n; ++q) {
-        if (order[q] < 0 || order[q] >= n || seen[(size_t)order[q]]) return EPH_ERR_BAD_ARGUMENT;   // not a permutation
-        seen[(size_t)order[q]] = 1;
-    }
-    // the sweep kernels walk a.bodies front to back: a permuted COPY of the ephemeris's table costs the kernels nothing (an index
-    // array read inside the body loop cost the thread-per-craft kernel 5 %: 35.0 against 33.4 ms)
-    std::vector<BodyEntry> table((size_t)std::max(n, 1)), perm((size_t)std::max(n, 1));
-    EPH_HIP(hipMemcpy(table.data(), b->eph->bodies.p, sizeof(BodyEntry) * (size_t)n, hipMemcpyDeviceToHost));
-    for (int q = 0; q < n; ++q) perm[(size_t)q] = table[(size_t)order[q]];
-    int st;
-    if ((st = b->bodies_ordered.alloc(perm.size()))) return st;
-    EPH_HIP(hipMemcpy(b->bodies_ordered.p, perm.data(), sizeof(BodyEntry) * perm.size(), hipMemcpyHostToDevice));
+    b->retry = true;
     return EPH_OK;
 }
 
@@ -1423,13 +1742,14 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
         c->pv = b->pv; c->eph = b->eph; c->device = b->device; c->n = b->n; c->max_knots = b->max_knots; c->rk = b->rk;
         c->params = b->params; c->events = b->events; c->max_tr = b->max_tr; c->max_ap = b->max_ap;
         c->heterogeneous = b->heterogeneous;
+        c->retry = b->retry; c->body_order = b->body_order;
         EPH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         EPH_HIP(hipEventCreate(&c->ev0));
         EPH_HIP(hipEventCreate(&c->ev1));
         hipStream_t s = c->stream;
         int st;
         if ((st = clone_buf(b->time, c->time, s)) || (st = clone_buf(b->y, c->y, s)) || (st = clone_buf(b->next_h, c->next_h, s)) ||
-            (st = clone_buf(b->klast, c->klast, s)) || (st = clone_buf(b->last_knot, c->last_knot, s)) ||
+            (st = clone_buf(b->klast, c->klast, s)) || (st = clone_buf(b->kfirst, c->kfirst, s)) || (st = clone_buf(b->last_knot, c->last_knot, s)) ||
             (st = clone_buf(b->knot_t, c->knot_t, s)) || (st = clone_buf(b->knot_y, c->knot_y, s)) ||
             (st = clone_buf(b->n_attempts, c->n_attempts, s)) || (st = clone_buf(b->rk_i, c->rk_i, s)) ||
             (st = clone_buf(b->steps, c->steps, s)) || (st = clone_buf(b->cur_seg, c->cur_seg, s)) ||
@@ -1441,7 +1761,7 @@ int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out) {
             (st = clone_buf(b->ntr, c->ntr, s)) || (st = clone_buf(b->nap, c->nap, s)) ||
             (st = clone_buf(b->ev_status, c->ev_status, s)) || (st = clone_buf(b->tr_body, c->tr_body, s)) ||
             (st = clone_buf(b->ap_body, c->ap_body, s)) || (st = clone_buf(b->ap_kind, c->ap_kind, s)) ||
-            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = clone_buf(b->bodies_ordered, c->bodies_ordered, s)) || (st = c->queue.alloc(1)))
+            (st = clone_buf(b->perm, c->perm, s)) || (st = clone_buf(b->slot_of, c->slot_of, s)) || (st = clone_buf(b->bodies_ordered, c->bodies_ordered, s)) || (st = clone_buf(b->body_order_dev, c->body_order_dev, s)) || (st = c->queue.alloc(1)))
             return st;
         c->h_slot = b->h_slot;
         EPH_HIP(hipStreamSynchronize(s));
@@ -1557,6 +1877,7 @@ int32_t eph_plot_points(const eph_ephemeris *e, const eph_plot_view *view, int64
         int st = check_device();
         if (st) return st;
         if (n_plots == 0) return EPH_OK;
+        std::shared_lock<std::shared_mutex> table_lock(e->mu);
         EPH_HIP(hipSetDevice(e->device));
         const size_t nk = (size_t)std::max<int64_t>(n_knots, 1), np = (size_t)n_plots, cap = (size_t)std::max<int64_t>(capacity, 1);
         DevBuf<eph_plot_request> d_req;

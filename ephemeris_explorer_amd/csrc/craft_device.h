@@ -33,7 +33,10 @@ struct CraftArgs {
     const double *coeffs;     // [poly][8][3]
     const int *ncoef;
     // per craft (SoA)
-    double *time, *y /*[6][n]*/, *next_h, *klast /*[6][n] FSAL carry*/, *last_knot_t;
+    double *time, *y /*[6][n]*/, *next_h, *klast /*[6][n] FSAL carry: k[S-1]*/, *last_knot_t;
+    double *kfirst;           // [6][n] k[0] of an FSAL pair between calls: after a FAILED attempt (EvalFailed inside the stages) the reference's
+                              // next advance swaps k[0] and k[S-1] once more (explicit.rs:76-79), which brings back whatever k[0] held
+    int retry;                // step the craft whose last step returned a StepError (eph_craft_batch_retry_failed), else they are skipped
     unsigned *n_attempts, *rk_i, *steps;
     int *cur_seg, *status, *nknots;
     const long long *seg_off;

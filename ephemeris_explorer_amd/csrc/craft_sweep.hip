@@ -250,7 +250,7 @@ k_craft_propagate(const CraftArgs a) {
     const long long i = a.perm ? a.perm[slot] : slot;
     const long long n = a.n_craft;
     int status = a.status[i];
-    if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
+    if (status != EPH_OK && status != EPH_KNOTS_FULL && !a.retry) return;    // a failed craft stays failed until the batch is re-armed
     status = EPH_OK;
 
     double time = a.time[i], y[6];
@@ -266,7 +266,7 @@ k_craft_propagate(const CraftArgs a) {
     double k[S][6];
     if (FSAL) {
 #pragma unroll
-        for (int d = 0; d < 6; ++d) k[S - 1][d] = a.klast[d * n + i];
+        for (int d = 0; d < 6; ++d) { k[S - 1][d] = a.klast[d * n + i]; k[0][d] = a.kfirst[d * n + i]; }
     }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
 
@@ -350,7 +350,7 @@ k_craft_propagate(const CraftArgs a) {
     a.status[i] = status;
     if (FSAL) {
 #pragma unroll
-        for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+        for (int d = 0; d < 6; ++d) { a.klast[d * n + i] = k[S - 1][d]; a.kfirst[d * n + i] = k[0][d]; }
     }
 }
 
@@ -390,7 +390,7 @@ k_craft_queue(const CraftArgs a) {
 
     auto load = [&]() -> bool {                         // craft i -> registers; false: nothing to do for it
         status = a.status[i];
-        if (status != EPH_OK && status != EPH_KNOTS_FULL) return false;    // a failed craft stays failed
+        if (status != EPH_OK && status != EPH_KNOTS_FULL && !a.retry) return false;    // a failed craft stays failed until re-armed
         status = EPH_OK;
         time = a.time[i];
 #pragma unroll
@@ -404,7 +404,7 @@ k_craft_queue(const CraftArgs a) {
         bound = sg.end;
         if (FSAL) {
 #pragma unroll
-            for (int d = 0; d < 6; ++d) k[S - 1][d] = a.klast[d * n + i];
+            for (int d = 0; d < 6; ++d) { k[S - 1][d] = a.klast[d * n + i]; k[0][d] = a.kfirst[d * n + i]; }
         }
         taken = 0;
         in_step = false;
@@ -424,7 +424,7 @@ k_craft_queue(const CraftArgs a) {
         a.status[i] = status;
         if (FSAL) {
 #pragma unroll
-            for (int d = 0; d < 6; ++d) a.klast[d * n + i] = k[S - 1][d];
+            for (int d = 0; d < 6; ++d) { a.klast[d * n + i] = k[S - 1][d]; a.kfirst[d * n + i] = k[0][d]; }
         }
     };
 
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
     const long long i = blockIdx.x, n = a.n_craft;
     const int lane = threadIdx.x;
     int status = a.status[i];
-    if (status != EPH_OK && status != EPH_KNOTS_FULL) return;    // a failed craft stays failed
+    if (status != EPH_OK && status != EPH_KNOTS_FULL && !a.retry) return;    // a failed craft stays failed until the batch is re-armed
     status = EPH_OK;
     const auto *rc = (const __attribute__((address_space(4))) ErkCoeffs *)(unsigned long long)a.rkd;
     const int S = a.rk.stages;
@@ -564,10 +564,11 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
     SegmentDev sg = segs[cur];
     double bound = sg.end;
     if (FSAL) {
-        double kl[6];
+        double kl[6], kf[6];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) kl[d] = a.klast[d * n + i];
+        for (int d = 0; d < 6; ++d) { kl[d] = a.klast[d * n + i]; kf[d] = a.kfirst[d * n + i]; }
         put_k(S - 1, kl);
+        put_k(0, kf);
     }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
     LaneBody lb;
@@ -632,7 +633,8 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
                         }
                     }
                     ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
-                    const double dk[6] = {out[3], out[4], out[5], 0.0, 0.0, 0.0};
+                    // (an Err leaves dk[s] as `self.dk[s].zero()` made it: explicit_generalized.rs:109-111)
+                    const double dk[6] = {ok ? out[3] : 0.0, ok ? out[4] : 0.0, ok ? out[5] : 0.0, 0.0, 0.0, 0.0};
                     put_k(s, dk);
                     continue;
                 }
@@ -645,6 +647,10 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
                     for (int d = 0; d < 6; ++d) yi[d] = yi[d] + K[j * 6 + d] * ha;
                 }
                 ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
+                if (!ok) {                            // an Err leaves k[s] as `self.k[s].zero()` made it  explicit.rs:92
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) out[d] = 0.0;
+                }
                 put_k(s, out);
             }
             if (!ok) { status = EPH_EVAL_FAILED; failed = true; break; }
@@ -734,7 +740,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
         a.status[i] = status;
         if (FSAL) {
 #pragma unroll
-            for (int d = 0; d < 6; ++d) a.klast[d * n + i] = K[(S - 1) * 6 + d];
+            for (int d = 0; d < 6; ++d) { a.klast[d * n + i] = K[(S - 1) * 6 + d]; a.kfirst[d * n + i] = K[d]; }
         }
     }
 }

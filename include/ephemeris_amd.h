@@ -12,8 +12,10 @@
  *  - vectors are AoS xyz f64 (the layout of Vec<glam::DVec3>), units km, km/s, km^3/s^2, seconds.
  *  - time is f64 seconds since 1958-01-01 TAI (ftime::Epoch::as_offset_seconds, ftime/src/epoch.rs).
  *  - every function returns an eph_status; errors are values, nothing throws or aborts.
- *  - a handle is not thread-safe; distinct handles may be used from distinct threads. Each handle owns one
- *    HIP stream on the device that was current when it was created.
+ *  - a handle is not thread-safe; distinct handles may be used from distinct threads (the reference runs its forward and
+ *    backward propagators and one task per ship concurrently, ephemeris_explorer/src/prediction.rs:385-391). Each handle
+ *    owns one HIP stream on the device that was current when it was created. The one handle meant to be SHARED between
+ *    threads is eph_ephemeris: it carries the reference's RwLock (see there).
  *  - results are bit-identical to the reference algorithm's f64 arithmetic (same operation order, no FMA
  *    contraction); see DESIGN.md for the one unpinned formula (the `particular` pair interaction).
  */
@@ -28,7 +30,9 @@ extern "C" {
 
 /* 2 (round 5): the eph_debug_* hooks left the boundary (csrc/eph_debug.h); eph_pair_variant reports the process-wide default
  * order new handles take (round 4: the order is a run-time choice), eph_nbody_advance_many / eph_prop_step_n_many only queue. */
-#define EPH_ABI_VERSION 2
+/* 3 (round 6): the device ephemeris is LIVE (eph_ephemeris_append / _merge / _clear / _info / _is_valid_at, _export / _import);
+ * eph_craft_batch_retry_failed; an FSAL pair's first stage is part of a batch's state. */
+#define EPH_ABI_VERSION 3
 
 /* integration::StepError (integration/src/lib.rs:312-318), NBodyPropagatorError::Solout
  * (ephemeris/src/propagators/nbody.rs:43-47); negative values are library / HIP failures. */
@@ -268,7 +272,7 @@ void eph_solution_destroy(eph_solution *s);
 int32_t eph_least_squares_fit(int32_t degree, int32_t backward, int64_t nwin, const double *samples,
                               double *coeffs, int32_t *ncoef);
 
-/* ---- massless bodies: a batch of independent spacecraft propagated against a fixed ephemeris ------------------
+/* ---- massless bodies: a batch of independent spacecraft propagated against the (live) ephemeris ----------------
  * ephemeris::SpacecraftPropagator<[StateVector<DVec3>;1], ReferenceFrame, Bodies, AdaptiveRungeKutta<ERK pair>,
  * CubicHermiteSplineSolout> (ephemeris/src/propagators/spacecraft.rs:224-695) with the app's acceleration model
  * and burn frames (ephemeris_explorer/src/dynamics/spacecraft.rs:70-74,218-293,609-641), one device thread per
@@ -281,6 +285,40 @@ typedef struct eph_craft_batch eph_craft_batch;
 /* uploads the splines of `s` (Vec<UniformSpline>) with the bodies' mu; `s` may be destroyed afterwards */
 int32_t eph_ephemeris_create(const eph_solution *s, const double *mu, eph_ephemeris **out);
 void eph_ephemeris_destroy(eph_ephemeris *e);
+/* The table is LIVE, like the reference's context: GravitationalBody.trajectory is Trajectory(Arc<RwLock<PredictionTrajectory>>)
+ * (ephemeris_explorer/src/dynamics/spacecraft.rs:52-74, dynamics/mod.rs:84-85); merged N-body snapshots grow it
+ * (dynamics/celestial.rs:198-204,220-226), auto_extend asks for more every frame (auto_extend.rs:182-202), and every spacecraft
+ * propagator that holds the context -- stored ones and clones included (prediction.rs:378) -- evaluates against the new extent from
+ * then on. So here: every eph_craft_batch (and clone) bound to `e`, eph_plot_points and the error scan see the table as it is when
+ * THEIR call starts. eph_ephemeris is the one handle that may be shared between threads: readers hold its lock shared for their
+ * whole (synchronous) call, the calls below take it exclusively -- the reference's RwLock. Only the new polynomials travel to the
+ * device (amortised O(1) per polynomial).
+ *   eph_ephemeris_append   UniformSpline::append (direction = EPH_FORWARD) / prepend (EPH_BACKWARD) for every body,
+ *                          ephemeris/src/trajectory.rs:515-534; the reference's assert_eq! contiguity / interval checks become
+ *                          EPH_ERR_BAD_ARGUMENT with the table untouched. `tail` is left unchanged.
+ *   eph_ephemeris_merge    the app's PredictionTarget::merge for the bodies: Forward clear_after(propagated.start()) then append
+ *                          (dynamics/celestial.rs:198-204), Backward clear_before(propagated.end()) then prepend (:220-226).
+ *   eph_ephemeris_clear    UniformSpline::clear_before (after = 0, trajectory.rs:536-542) / clear_after (after = 1, :544-549) at
+ *                          epoch `at` on body's spline, or on every spline (body < 0).
+ *   eph_ephemeris_info     UniformSpline{start, interval, polynomials.len()} of one body (body >= 0) and / or the table's revision
+ *                          (a counter that every call above increments; body < 0: revision only). Any pointer may be NULL.
+ *   eph_ephemeris_is_valid_at   Bodies::is_valid_at (dynamics/spacecraft.rs:199-201): every body's spline contains(t)
+ *                          (trajectory.rs:437-441: sign bit of t - start clear and t - start <= span); what
+ *                          flight_plan.rs:363-395 tests before it restarts a ship's prediction.
+ * A craft that ran off the table's end holds EPH_EVAL_FAILED (spacecraft.rs:264-281); after the table has grown,
+ * eph_craft_batch_retry_failed + the next propagate continue it exactly as the reference's next step() would. */
+int32_t eph_ephemeris_append(eph_ephemeris *e, const eph_solution *tail, int32_t direction);
+int32_t eph_ephemeris_merge(eph_ephemeris *e, const eph_solution *propagated, int32_t direction);
+int32_t eph_ephemeris_clear(eph_ephemeris *e, int32_t body, double at, int32_t after);
+int32_t eph_ephemeris_info(const eph_ephemeris *e, int32_t body, double *start, double *interval, int64_t *npoly,
+                           uint64_t *revision);
+int32_t eph_ephemeris_is_valid_at(const eph_ephemeris *e, double t, int32_t *flag);
+/* One contiguous, position-independent image of the table: what rank 0 of a multi-GPU sweep builds once and broadcasts (SURVEY
+ * 8(e); ephemeris_explorer_amd/parallel.py broadcast_ephemeris) instead of every rank integrating the bodies again. *bytes = the
+ * image's size; with buf == NULL or capacity too small nothing is written and the status is EPH_ERR_BAD_ARGUMENT. An imported table
+ * is bit-identical to the exported one (bounds, mu, every coefficient), lives on the current device and is independent of it. */
+int32_t eph_ephemeris_export(const eph_ephemeris *e, void *buf, uint64_t capacity, uint64_t *bytes);
+int32_t eph_ephemeris_import(const void *buf, uint64_t bytes, eph_ephemeris **out);
 /* The debug window's interpolation-error scan (ephemeris_explorer/src/ui/windows/debug.rs:182-238): advance `h` (an
  * eph_nbody over the same bodies, e.g. QuinlanTremaine12 with the ephemeris dt and a bound) step by step and, after
  * every step, compare each body's position with its spline in `e` at that epoch; max_error_m[b] = the maximum of
@@ -319,6 +357,19 @@ int32_t eph_craft_batch_propagate(eph_craft_batch *b, double t_end);
 /* IncrementalPropagator::step n_steps times for every craft (ephemeris/src/lib.rs:40-47, spacecraft.rs:598-615): each
  * craft takes exactly n_steps accepted steps (one knot each) unless it fails or its knot slab fills. */
 int32_t eph_craft_batch_step_n(eph_craft_batch *b, uint32_t n_steps);
+/* A craft whose last step returned a StepError keeps that status and is NOT stepped by later propagate / step_n calls (a sweep's
+ * drain loop must not re-attempt the failed craft of a batch on every pass). The reference's propagator remembers nothing: calling
+ * step() again runs AdaptiveRungeKuttaIntegrator::advance once more from what the failed attempt left
+ * (integration/src/runge_kutta/mod.rs:414-439) -- that is how a stored ship propagator resumes after the bodies' ephemeris has been
+ * extended (prediction.rs:378). This call re-arms the batch: the NEXT propagate / step_n steps every craft whatever its status (a
+ * craft that has reached t_end already returns EPH_OK, like step_to). What a failed attempt leaves, and the library keeps bit for bit:
+ * time, state and the step counters of the last accepted step (`n` counts completed attempts only: mod.rs:427-428 returns before
+ * n += 1); next_h after the rejections that preceded the failure and the clamp to the bound (:422-424); and the stage registers --
+ * for an FSAL pair k[0] and k[S-1] were ALREADY swapped (explicit.rs:76-79), the failing stage is zeroed (:92), so the retry's swap
+ * brings back the stage-0 derivative of the step BEFORE as its k[0]. That is a quirk of the reference (the retried step starts from a
+ * stale first stage; the embedded error estimate usually rejects it once); it is restated, not repaired. Retrying
+ * StepSizeUnderflow / MaxIterationsReached / BoundReached changes nothing and returns the same error. */
+int32_t eph_craft_batch_retry_failed(eph_craft_batch *b);
 /* per craft: status (eph_status or EPH_KNOTS_FULL), knots in the slab, attempts of the current integrator (n),
  * accepted steps since creation. Any pointer may be NULL. */
 int32_t eph_craft_batch_status(eph_craft_batch *b, int32_t *status, int32_t *nknots, uint32_t *attempts,
@@ -355,7 +406,8 @@ int32_t eph_craft_batch_events(eph_craft_batch *b, int64_t craft, double *tr_tim
                                double *ap_distance, int32_t *ap_body, int32_t *ap_kind);
 /* SpacecraftPropagator: Clone -- the UI snapshots a propagator and later resumes from the snapshot
  * (ephemeris_explorer/src/prediction.rs:224-229,378). A deep copy: state, knots and events; the clone refers to the
- * same eph_ephemeris (which must outlive both). */
+ * same (live) eph_ephemeris, which must outlive both: a clone taken before an eph_ephemeris_append resumes against the
+ * extended table. */
 int32_t eph_craft_batch_clone(eph_craft_batch *b, eph_craft_batch **out);
 /* Bulk read of the knot slabs for sweeps (one copy instead of one strided gather per craft): knots first_knot ..
  * first_knot + n_knots - 1 of EVERY craft in the device layout, knot_t[k][craft] and knot_y[k][d][craft] (d = x, y, z,

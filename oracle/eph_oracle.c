@@ -687,6 +687,31 @@ int orc_solution_append(orc_solution *a, const orc_solution *b, int direction) {
     }
     return 1;
 }
+/* UniformSpline::clear_before (after = 0, trajectory.rs:536-542) / clear_after (after != 0, :544-549) with get_index_local
+ * (:591-598: None when negative or time >= span) and get_index_local_exclusive (:600-607: None when negative or time > span);
+ * body < 0: every spline */
+static uint64_t as_usize(double x) { return !(x > 0.0) ? 0 : (x >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)x); }
+void orc_solution_clear(orc_solution *so, int body, double at, int after) {
+    for (int k = 0; k < so->n; ++k) {
+        if (body >= 0 && body != k) continue;
+        spline_t *s = &so->s[k];
+        if (after) {
+            const double time = at - s->start;                       /* get_index(at) */
+            if (signbit(time) || time >= spline_span(s)) continue;
+            const uint64_t idx = as_usize(time / s->interval);       /* index_local :609-612 */
+            if (idx < (uint64_t)s->len) s->len = (int64_t)idx;       /* truncate(idx) */
+        } else {
+            const double time = (at + s->interval) - s->start;       /* get_index_exclusive(at + self.interval) */
+            if (signbit(time) || time > spline_span(s)) continue;
+            const uint64_t c = as_usize(ceil(time / s->interval));   /* index_local_exclusive :614-617 */
+            const uint64_t idx = c == 0 ? 0 : c - 1;
+            s->start += s->interval * (double)idx;                   /* self.start += self.interval.scaled(idx as f64) */
+            const int64_t drop = idx < (uint64_t)s->len ? (int64_t)idx : s->len;   /* drain(0..idx) */
+            s->off += drop; s->len -= drop;
+        }
+    }
+}
+orc_solution *orc_solution_clone(const orc_solution *src) { return solution_clone(src); }
 
 /* ------------------------------------------------------------------------------------------------ */
 /* LeastSquaresFit::interpolate  ephemeris_explorer/src/dynamics/celestial.rs:24-135                */
@@ -1022,7 +1047,10 @@ static int erkng_advance(erk_t *r, double h, double *time, double *state, ode_fn
         }
         if (evals) (*evals)++;
         int st = f(ctx, ti, sv, out);                         /* ddy = context + manoeuvre (spacecraft.rs:319-331) */
-        if (st) return st;
+        if (st) {                                             /* `self.dk[s].zero()` ran before eval returned Err  :109-111 */
+            for (int d = 0; d < 3; ++d) r->k[s][d] = 0.0;
+            return st;
+        }
         for (int d = 0; d < 3; ++d) r->k[s][d] = out[3 + d];
     }
     for (int d = 0; d < 3; ++d) y[d] = y[d] + dy[d] * h;
@@ -1058,7 +1086,10 @@ static int erkn_advance(erk_t *r, double h, double *time, double *state, ode_fn 
         }
         if (evals) (*evals)++;
         int st = f(ctx, ti, sv, out);                         /* problem.ode.eval(ti, &self.yi, self.dk[s].zero())  :97 */
-        if (st) return st;
+        if (st) {                                             /* the zeroed dk[s] stays */
+            for (int d = 0; d < 3; ++d) r->k[s][d] = 0.0;
+            return st;
+        }
         for (int d = 0; d < 3; ++d) r->k[s][d] = out[3 + d];
     }
     for (int d = 0; d < 3; ++d) y[d] = y[d] + dy[d] * h;      /* :102-104 */

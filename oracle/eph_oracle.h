@@ -106,6 +106,8 @@ void orc_solution_coeffs(const orc_solution *, int body, double *coeffs, int32_t
 int orc_solution_eval(const orc_solution *, int body, double at, double *pos, double *vel);
 /* append b to a (UniformSpline::append / prepend, trajectory.rs:515-539); returns 0 on contiguity failure */
 int orc_solution_append(orc_solution *a, const orc_solution *b, int direction);
+void orc_solution_clear(orc_solution *so, int body, double at, int after);
+orc_solution *orc_solution_clone(const orc_solution *src);
 
 /* LeastSquaresFit::interpolate (ephemeris_explorer/src/dynamics/celestial.rs:24-135):
  * ts[m], xs[m*3] -> coeffs[8*3] (zero padded), returns ncoef after trim, or -1 on Err(()) */

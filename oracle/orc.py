@@ -102,6 +102,10 @@ def lib(native=False):
     L.orc_solution_coeffs.restype = None
     L.orc_solution_eval.argtypes = [vp, C.c_int, C.c_double, _dp, _dp]
     L.orc_solution_append.argtypes = [vp, vp, C.c_int]
+    L.orc_solution_clear.argtypes = [vp, C.c_int, C.c_double, C.c_int]
+    L.orc_solution_clear.restype = None
+    L.orc_solution_clone.argtypes = [vp]
+    L.orc_solution_clone.restype = vp
     L.orc_least_squares_fit.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     L.orc_poly_eval_and_deriv.argtypes = [C.c_int, _dp, C.c_double, _dp, _dp]
     L.orc_poly_eval_and_deriv.restype = None
@@ -265,6 +269,15 @@ class Solution:
 
     def append(self, other, direction=1):
         return bool(self.L.orc_solution_append(self.h, other.h, direction))
+
+    def clear_before(self, at, body=-1):
+        self.L.orc_solution_clear(self.h, int(body), float(at), 0)
+
+    def clear_after(self, at, body=-1):
+        self.L.orc_solution_clear(self.h, int(body), float(at), 1)
+
+    def clone(self):
+        return Solution(self.L, self.L.orc_solution_clone(self.h))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -463,9 +463,11 @@ class Erk:
             for j in range(s):
                 ha = h * self.A[s][j]
                 yi = [a + kk * ha for a, kk in zip(yi, self.k[j])]
-            self.k[s] = f(ti, yi)
-            if self.k[s] is None:
+            out = f(ti, yi)
+            if out is None:                      # `self.k[s].zero()` ran before eval returned Err  explicit.rs:92
+                self.k[s] = [0.0] * len(yi)
                 return None
+            self.k[s] = out
         for i in range(S):
             hb = h * self.B[i]
             y = [a + kk * hb for a, kk in zip(y, self.k[i])]
@@ -512,7 +514,8 @@ class Erkng:
                 yi = [a + kk * hhap for a, kk in zip(yi, self.k[j])]
                 dyi = [a + kk * hav for a, kk in zip(dyi, self.k[j])]
             out = f(ti, yi + dyi)
-            if out is None:
+            if out is None:                      # the zeroed dk[s] stays
+                self.k[s] = [0.0] * 3
                 return None
             self.k[s] = out[3:]
         y = [a + v * h for a, v in zip(y, dy)]
@@ -562,7 +565,8 @@ class Erkn(Erkng):
                 hha = h * h * self.A[s][j]
                 yi = [a + kk * hha for a, kk in zip(yi, self.k[j])]
             out = f(ti, yi + list(dy))
-            if out is None:
+            if out is None:                      # the zeroed dk[s] stays
+                self.k[s] = [0.0] * 3
                 return None
             self.k[s] = out[3:]
         y = [a + v * h for a, v in zip(y, dy)]

@@ -146,7 +146,7 @@ def test_debug_hooks_are_not_in_the_product(product_lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", str(product_lib.LIB_PATH)]).decode()
     leaked = [ln for ln in out.splitlines() if " T " in ln and " T eph_" not in ln and "__device_stub__" not in ln]
     assert not leaked, leaked[:5]
-    assert product_lib._lib().eph_abi_version() == 2
+    assert product_lib._lib().eph_abi_version() == 3
 
 
 def test_integration_shims_use_only_declared_names():
