@@ -876,6 +876,7 @@ static int craft_sort(eph_craft_batch *b) {
     if ((st = b->perm.alloc(n4)) || (st = b->slot_of.alloc(n4))) return st;
     PinnedStage stage(2 * n4 * sizeof(int));
     if (stage.status()) return stage.status();
+    StreamIdleOnExit idle(b->stream);
     const unsigned cgrid = (unsigned)std::min<size_t>((n4 / 4 + 255) / 256, 4096);
     hipLaunchKernelGGL(k_copy16, dim3(cgrid), dim3(256), 0, b->stream, (long long)(n4 / 4), (const double2 *)tau.p, (double2 *)stage.dev());
     EPH_HIP(hipStreamSynchronize(b->stream));
@@ -1788,6 +1789,7 @@ int32_t eph_craft_batch_knot_slabs(eph_craft_batch *b, int32_t first_knot, int32
             const double *src = part == 0 ? b->knot_t.p + (size_t)first_knot * n : b->knot_y.p + (size_t)first_knot * 6 * n;
             PinnedStage stage((size_t)std::min(rows, rows_per_pass) * row_bytes);
             if (stage.status()) return stage.status();
+            StreamIdleOnExit idle(b->stream);
             for (long long r0 = 0; r0 < rows; r0 += rows_per_pass) {
                 const long long nr = std::min(rows_per_pass, rows - r0);
                 hipLaunchKernelGGL(k_rows_to_craft_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, nr, (long long)n,

@@ -27,19 +27,36 @@ int dev_alloc(size_t bytes, void **out);
 void dev_free(void *p, size_t bytes);
 size_t release_cached_memory();
 size_t cached_memory_bytes();
-// The process-wide pinned, device-mapped staging buffer, held for the life of the object (one read-back at a time): a kernel
-// stores through dev(), the host reads host() after synchronising the kernel's stream.
+// A pinned, device-mapped staging buffer taken from the library's pool for the life of the object (mem.cpp; one per concurrent user,
+// so handles driven from distinct threads do not wait for each other): a kernel stores through dev(), the host reads host() after
+// synchronising the kernel's stream. The stream must be idle with respect to the buffer before the object is destroyed.
 class PinnedStage {
 public:
     explicit PinnedStage(size_t bytes);
+    ~PinnedStage();
+    PinnedStage(const PinnedStage &) = delete;
+    PinnedStage &operator=(const PinnedStage &) = delete;
     int status() const { return status_; }
     void *host() const { return host_; }
     void *dev() const { return dev_; }
 
 private:
-    std::unique_lock<std::mutex> lock_;
     void *host_ = nullptr, *dev_ = nullptr;
+    size_t bytes_ = 0;
     int status_ = EPH_OK;
+};
+
+// Declared AFTER a PinnedStage (or a scratch lease) whose buffer kernels on `s` use: an early error return leaves the scope only once
+// the stream is idle, so no kernel still in flight writes a buffer that has gone back to the pool. disarm() after the happy path's own
+// synchronisation.
+struct StreamIdleOnExit {
+    hipStream_t s;
+    bool armed = true;
+    explicit StreamIdleOnExit(hipStream_t stream) : s(stream) {}
+    StreamIdleOnExit(const StreamIdleOnExit &) = delete;
+    StreamIdleOnExit &operator=(const StreamIdleOnExit &) = delete;
+    ~StreamIdleOnExit() { if (armed) (void)hipStreamSynchronize(s); }
+    void disarm() { armed = false; }
 };
 
 template <typename T>

@@ -10,8 +10,9 @@
 //    that shares the GPU with another allocator (PyTorch, RCCL, a second library) is not left holding GBs it does not use; while
 //    handles are alive such a caller calls eph_release_cached_memory() itself. An allocation of ours that fails empties the cache
 //    and retries. A reused block is cleared, synchronously (what a fresh allocation looks like: no caller is handed another batch's rows).
-// 2. One process-wide staging buffer in pinned, device-mapped host memory that KERNELS read and write (no copy engine, no
-//    pinning of short-lived host vectors): the deal's index arrays at batch creation, the reordered knot rows of a dealt batch.
+// 2. A pool of staging buffers in pinned, device-mapped host memory that KERNELS read and write (no copy engine, no pinning of
+//    short-lived host vectors): seam 1's operands, state read-backs, the deal's index arrays at batch creation, the reordered knot
+//    rows of a dealt batch. One buffer per concurrent user: threads driving distinct handles never wait for each other here.
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -81,9 +82,14 @@ int dev_alloc(size_t bytes, void **out) {
             // what a fresh allocation looks like -- COMPLETE before the block is handed out: the handles' streams are non-blocking,
             // so a clear merely queued on the default stream can land after the new owner's first writes (it did: a batch's knot 0
             // came back with a zeroed component in one run of test_body_order_of_the_acceleration_sum, round 5)
-            if (hipMemsetAsync(hit, 0, bytes, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) (void)hipGetLastError();
-            *out = hit;
-            return EPH_OK;
+            if (hipMemsetAsync(hit, 0, bytes, nullptr) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess) {
+                *out = hit;
+                return EPH_OK;
+            }
+            (void)hipGetLastError();                     // the clear failed: the block is not handed out uncleared -- back to the driver,
+            (void)hipFree(hit);                          // and a fresh allocation below
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            g_live[device] -= 1;
         }
     }
     hipError_t e = hipMalloc(out, bytes);
@@ -172,33 +178,78 @@ size_t cached_memory_bytes() {
 }
 
 // ---- pinned, device-mapped staging ------------------------------------------------------------------------------------------
+// A POOL of buffers, one per concurrent user (round 6): the reference runs its forward and backward propagators and one task per ship
+// on a thread pool (ephemeris_explorer/src/prediction.rs:385-391), so two handles' read-backs must not wait for each other -- round 5's
+// single buffer was held across a hipStreamSynchronize of the caller's stream, i.e. for as long as that handle's queued steps took.
+// g_stage_mu covers the free list only; a PinnedStage owns its buffer until it is destroyed. Buffers are portable (every device may
+// map them); at most kStageKeep idle ones (kStageKeepBytes in all) are kept.
 namespace {
+struct StageBuf { void *host; size_t bytes; };
+constexpr size_t kStageKeep = 8;
+constexpr size_t kStageKeepBytes = (size_t)384 << 20;      // idle pinned memory kept (one 256 MB knot-slab pass + the small ones)
 std::mutex g_stage_mu;
-void *g_stage_host = nullptr, *g_stage_dev = nullptr;
-size_t g_stage_bytes = 0;
+std::vector<StageBuf> g_stage_free;
+size_t g_stage_free_bytes = 0;
 }  // namespace
 
-PinnedStage::PinnedStage(size_t bytes) : lock_(g_stage_mu) {
-    if (bytes > g_stage_bytes) {
-        if (g_stage_host) (void)hipHostFree(g_stage_host);
-        g_stage_host = g_stage_dev = nullptr;
-        g_stage_bytes = 0;
+PinnedStage::PinnedStage(size_t bytes) {
+    StageBuf got{nullptr, 0};
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        size_t best = g_stage_free.size();
+        for (size_t i = 0; i < g_stage_free.size(); ++i)               // smallest idle buffer that is large enough
+            if (g_stage_free[i].bytes >= bytes && (best == g_stage_free.size() || g_stage_free[i].bytes < g_stage_free[best].bytes)) best = i;
+        if (best < g_stage_free.size()) {
+            got = g_stage_free[best];
+            g_stage_free_bytes -= got.bytes;
+            g_stage_free.erase(g_stage_free.begin() + (long)best);
+        } else if (!g_stage_free.empty()) {                            // none fits: the largest idle one makes way for a bigger one
+            size_t big = 0;
+            for (size_t i = 1; i < g_stage_free.size(); ++i) if (g_stage_free[i].bytes > g_stage_free[big].bytes) big = i;
+            drop = g_stage_free[big].host;
+            g_stage_free_bytes -= g_stage_free[big].bytes;
+            g_stage_free.erase(g_stage_free.begin() + (long)big);
+        }
+    }
+    if (drop) (void)hipHostFree(drop);
+    if (!got.host) {
         const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
-        void *h = nullptr, *d = nullptr;
-        hipError_t e = hipHostMalloc(&h, want, hipHostMallocMapped);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+        void *h = nullptr;
+        hipError_t e = hipHostMalloc(&h, want, hipHostMallocMapped | hipHostMallocPortable);
         if (e != hipSuccess) {
-            if (h) (void)hipHostFree(h);
             set_last_error("hipHostMalloc (staging)", e);
             status_ = e == hipErrorOutOfMemory ? EPH_ERR_OUT_OF_MEMORY : EPH_ERR_HIP;
             return;
         }
-        g_stage_host = h;
-        g_stage_dev = d;
-        g_stage_bytes = want;
+        got = StageBuf{h, want};
     }
-    host_ = g_stage_host;
-    dev_ = g_stage_dev;
+    void *d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, got.host, 0);           // as the CURRENT device sees it
+    if (e != hipSuccess) {
+        (void)hipHostFree(got.host);
+        set_last_error("hipHostGetDevicePointer (staging)", e);
+        status_ = EPH_ERR_HIP;
+        return;
+    }
+    host_ = got.host;
+    dev_ = d;
+    bytes_ = got.bytes;
+}
+
+PinnedStage::~PinnedStage() {
+    if (!host_) return;
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        if (g_stage_free.size() < kStageKeep && g_stage_free_bytes + bytes_ <= kStageKeepBytes) {
+            g_stage_free.push_back(StageBuf{host_, bytes_});
+            g_stage_free_bytes += bytes_;
+        } else {
+            drop = host_;
+        }
+    }
+    if (drop) (void)hipHostFree(drop);
 }
 
 }  // namespace eph

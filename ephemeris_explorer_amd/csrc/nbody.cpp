@@ -506,12 +506,14 @@ int NBodyIntegration::get_state(double *pos, double *vel, double *t, uint32_t *s
         // synchronisation, no copy-engine submissions (the reference's Integration reads the state after every step: 115-119 -> 63 us
         // per step at N = 4096 with this, scripts/time_boundary.py)
         const size_t nd = (size_t)n_;
-        PinnedStage stage(sizeof(double) * 6 * nd);
+        PinnedStage stage(sizeof(double) * 6 * nd);       // this call's own buffer: a second handle's read-back does not wait for ours
         if (stage.status()) return stage.status();
+        StreamIdleOnExit idle(stream_);
         double *h = static_cast<double *>(stage.host()), *d = static_cast<double *>(stage.dev());
         if (pos && (st = launch_soa_to_aos(stream_, n_, npad_, Yslot(is_multistep_ ? cur_ : 0), d))) return st;
         if (vel && (st = launch_soa_to_aos(stream_, n_, npad_, V_.p, d + 3 * nd))) return st;
         EPH_HIP(hipStreamSynchronize(stream_));
+        idle.disarm();
         if (pos) std::memcpy(pos, h, sizeof(double) * 3 * nd);
         if (vel) std::memcpy(vel, h + 3 * nd, sizeof(double) * 3 * nd);
         if (t) *t = time_;
@@ -545,8 +547,10 @@ int NBodyIntegration::get_acc(double *acc) {
     if (!xch_) {                                          // as get_state: through the pinned, device-mapped staging buffer
         PinnedStage stage(sizeof(double) * 3 * (size_t)n_);
         if (stage.status()) return stage.status();
+        StreamIdleOnExit idle(stream_);
         if ((st = launch_soa_to_aos(stream_, n_, npad_, is_multistep_ ? Aslot(cur_) : ASR_.p, static_cast<double *>(stage.dev())))) return st;
         EPH_HIP(hipStreamSynchronize(stream_));
+        idle.disarm();
         std::memcpy(acc, stage.host(), sizeof(double) * 3 * (size_t)n_);
         return EPH_OK;
     }
@@ -559,8 +563,10 @@ int NBodyIntegration::get_acc(double *acc) {
 
 // seam 1: SecondOrderODE::eval for NewtonianGravity, host buffers in and out.
 // The call's device buffers are grow-only scratch kept per device between calls (round 5): six hipMalloc / hipFree pairs per call --
-// each hipFree a device synchronisation -- were most of what a call cost at the app's sizes. One caller at a time per process (the
-// mutex); the scratch is ordinary library memory (eph_release_cached_memory does not touch it; it is a few MB at N = 65 536).
+// each hipFree a device synchronisation -- were most of what a call cost at the app's sizes. Round 6: a POOL of scratch sets per
+// device, one leased per call with its own stream, so concurrent callers (the reference evaluates the RHS from every integrator
+// thread) neither wait for each other nor share a buffer; the mutex covers the free list only. The scratch is ordinary library
+// memory (eph_release_cached_memory does not touch it; it is a few MB at N = 65 536, and as many sets exist as calls ever overlapped).
 namespace {
 // grow-only device block taken from the driver directly: it lives as long as the process, so it must not count as a live allocation
 // of the library's block cache (mem.cpp releases the cache with the LAST counted allocation on a device)
@@ -584,13 +590,25 @@ struct AccelScratch {
     RawScratch<double> soa, init, out;
     hipStream_t stream = nullptr;
 };
+constexpr int kAccelDevices = 64;
 std::mutex g_accel_mu;
-AccelScratch *accel_scratch(int device) {
-    static AccelScratch *table[64] = {};
-    if (device < 0 || device >= 64) return nullptr;
-    if (!table[device]) table[device] = new AccelScratch();          // (lives as long as the process: destroying device memory at exit is the driver's job)
-    return table[device];
-}
+std::vector<AccelScratch *> g_accel_free[kAccelDevices];             // (live as long as the process: destroying device memory at exit is the driver's job)
+struct AccelLease {                                                  // one scratch set of `device` for the life of the object
+    int device;
+    AccelScratch *x = nullptr;
+    explicit AccelLease(int dev) : device(dev) {
+        std::lock_guard<std::mutex> lk(g_accel_mu);
+        auto &fl = g_accel_free[device];
+        if (!fl.empty()) { x = fl.back(); fl.pop_back(); }
+        else x = new AccelScratch();
+    }
+    ~AccelLease() {
+        std::lock_guard<std::mutex> lk(g_accel_mu);
+        g_accel_free[device].push_back(x);
+    }
+    AccelLease(const AccelLease &) = delete;
+    AccelLease &operator=(const AccelLease &) = delete;
+};
 }  // namespace
 int accel_eval_device(int n, const double *pos, const double *mu, double *acc) {
     if (n < 0 || (n > 0 && (!pos || !mu || !acc))) return EPH_ERR_BAD_ARGUMENT;
@@ -600,21 +618,22 @@ int accel_eval_device(int n, const double *pos, const double *mu, double *acc) {
     const int npad = ((n + 63) / 64) * 64;
     int device = 0;
     EPH_HIP(hipGetDevice(&device));
-    std::lock_guard<std::mutex> lk(g_accel_mu);
-    AccelScratch *x = accel_scratch(device);
-    if (!x) return EPH_ERR_BAD_ARGUMENT;
+    if (device < 0 || device >= kAccelDevices) return EPH_ERR_BAD_ARGUMENT;
+    AccelLease lease(device);
+    AccelScratch *x = lease.x;
+    if (!x->stream) EPH_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+    hipStream_t s = x->stream;
     if ((st = x->P.reserve(npad)) || (st = x->soa.reserve((size_t)3 * npad)) || (st = x->init.reserve((size_t)3 * npad)) ||
         (st = x->out.reserve((size_t)3 * npad)))
         return st;
-    if (!x->stream) EPH_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
-    hipStream_t s = x->stream;
-    // Host buffers cross the bus through the process-wide pinned, device-mapped staging buffer (mem.cpp): the kernels read the
-    // caller's numbers and write the result THROUGH it, so a call is five launches and one synchronisation -- no copy-engine
-    // submissions (three pageable hipMemcpy in and one out were ~40 us of a 69 us call at 32 bodies: 29 us now; N = 4096: 177 us with the per-call
-    // allocations of round 4, 136 without them, 75-80 through the staging buffer -- of which the force kernel is 40)
+    // Host buffers cross the bus through a pinned, device-mapped staging buffer (mem.cpp): the kernels read the caller's numbers and
+    // write the result THROUGH it, so a call is five launches and one synchronisation -- no copy-engine submissions (three pageable
+    // hipMemcpy in and one out were ~40 us of a 69 us call at 32 bodies: 29 us now; N = 4096: 177 us with the per-call allocations
+    // of round 4, 136 without them, 75-80 through the staging buffer -- of which the force kernel is 40)
     const size_t nd = (size_t)n;
     PinnedStage stage(sizeof(double) * 7 * nd);
     if (stage.status()) return stage.status();
+    StreamIdleOnExit idle(s);                         // an error return below leaves only once nothing in flight uses stage / scratch
     double *h = static_cast<double *>(stage.host()), *d = static_cast<double *>(stage.dev());
     std::memcpy(h, mu, sizeof(double) * nd);
     std::memcpy(h + nd, pos, sizeof(double) * 3 * nd);
@@ -625,6 +644,7 @@ int accel_eval_device(int n, const double *pos, const double *mu, double *acc) {
     if ((st = launch_accel(default_pair_variant(), s, n, npad, x->P.p, x->init.p, x->out.p))) return st;
     if ((st = launch_soa_to_aos(s, n, npad, x->out.p, d + 4 * nd))) return st;
     EPH_HIP(hipStreamSynchronize(s));
+    idle.disarm();
     std::memcpy(acc, h + 4 * nd, sizeof(double) * 3 * nd);
     return EPH_OK;
 }

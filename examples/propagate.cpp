@@ -76,6 +76,26 @@ int main() try {
                                                       {ea::Burn{t0 + 7200.0, t0 + 7260.0, {5e-4, 0.0, 0.0}, 1}, ea::Burn{t0 + 2.0 * day, t0 + 2.0 * day + 30.0, {0.0, 1e-4, 0.0}, -1}},
                                                       t0 + 3.0 * day);
     std::printf("flight plan edit restarts at t0 + %.1f s\n", restart - t0);
+
+    // auto-extend (ephemeris_explorer/src/auto_extend.rs:182-202): the bodies' propagator keeps going and every snapshot is merged into
+    // the LIVE table (dynamics/celestial.rs:198-204); a stored ship propagator that ran off the table's end (EvalFailed,
+    // spacecraft.rs:264-281) resumes against the same context once it has grown (prediction.rs:378, flight_plan.rs:363-395)
+    ea::SpacecraftBatch runner(bodies, t0, {craft0}, "DormandPrince54", ea::AdaptiveParams(1e-3), {}, 65536);
+    const double target = t0 + 50.0 * day;
+    runner.step_to(target);
+    std::vector<int32_t> nk0;
+    const int32_t off_the_end = runner.status(&nk0)[0];
+    const bool valid_before = bodies.is_valid_at(target);
+    ea::Solution extension = massive.propagate(t0 + 60.0 * day, &err);
+    bodies.merge(extension);
+    runner.retry_failed();
+    runner.step_to(target);
+    std::vector<int32_t> nk1;
+    const int32_t resumed = runner.status(&nk1)[0];
+    const ea::CubicHermiteSpline path = runner.trajectory(0);
+    std::printf("auto-extend: %s after %d knots (table valid at target: %d -> %d, revision %llu); resumed: %s, knots %d, last knot t = %a r = %a %a %a\n",
+                eph_status_string(off_the_end), (int)nk0[0], (int)valid_before, (int)bodies.is_valid_at(target), (unsigned long long)bodies.revision(),
+                eph_status_string(resumed), (int)nk1[0], path.t.back(), path.position.back()[0], path.position.back()[1], path.position.back()[2]);
     return 0;
 } catch (const ea::Error &e) {
     std::fprintf(stderr, "%s\n", e.what());

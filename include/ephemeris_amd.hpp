@@ -143,6 +143,7 @@ public:
         const int64_t np = len(body);
         coeffs.assign(static_cast<size_t>(np) * 24, 0.0);
         ncoef.assign(static_cast<size_t>(np), 0);
+        if (np == 0) return;                              // (a snapshot taken before the body's first polynomial was complete)
         detail::check(eph_solution_coeffs(h_, body, coeffs.data(), ncoef.data()), "eph_solution_coeffs");
     }
     explicit operator bool() const { return h_ != nullptr; }
@@ -171,6 +172,10 @@ public:
         detail::check(eph_nbody_create(n_, detail::flat(y), detail::flat(dy), gravitational_parameters.data(), time, h, method, &h_), "eph_nbody_create");
     }
     NBodyIntegration(NBodyIntegration &&o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    NBodyIntegration &operator=(NBodyIntegration &&o) noexcept {
+        if (this != &o) { if (h_) eph_nbody_destroy(h_); h_ = std::exchange(o.h_, nullptr); n_ = o.n_; }
+        return *this;
+    }
     NBodyIntegration(const NBodyIntegration &) = delete;
     NBodyIntegration &operator=(const NBodyIntegration &) = delete;
     ~NBodyIntegration() { if (h_) eph_nbody_destroy(h_); }
@@ -211,6 +216,10 @@ public:
                                       static_cast<int32_t>(direction), method, count.data(), degree.data(), &h_), "eph_prop_create");
     }
     NBodyPropagator(NBodyPropagator &&o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    NBodyPropagator &operator=(NBodyPropagator &&o) noexcept {             // `propagator = snapshot` (prediction.rs:378)
+        if (this != &o) { if (h_) eph_prop_destroy(h_); h_ = std::exchange(o.h_, nullptr); n_ = o.n_; }
+        return *this;
+    }
     NBodyPropagator(const NBodyPropagator &) = delete;
     NBodyPropagator &operator=(const NBodyPropagator &) = delete;
     ~NBodyPropagator() { if (h_) eph_prop_destroy(h_); }
@@ -312,18 +321,72 @@ struct Apsides {
 // Timeline::divergence_time_before (spacecraft.rs:179-213): the epoch a flight plan edited from `old_burns` to `new_burns` restarts from
 inline double divergence_time_before(const std::vector<Burn> &old_burns, const std::vector<Burn> &new_burns, double before);
 
-// `Bodies`: the massive bodies' splines resident on the device (dynamics/spacecraft.rs:164-228)
+// `Bodies`: the massive bodies' splines resident on the device (dynamics/spacecraft.rs:164-228). LIVE like the reference's context --
+// GravitationalBody.trajectory is Trajectory(Arc<RwLock<PredictionTrajectory>>) (dynamics/spacecraft.rs:52-74, dynamics/mod.rs:84-85):
+// merged N-body snapshots grow it and every SpacecraftBatch (and clone) bound to it sees the new extent at its next call. The one
+// wrapper that may be shared between threads (it carries the RwLock); hold it in a std::shared_ptr where the app holds the Arc.
 class Ephemeris {
 public:
     Ephemeris(const Solution &splines, const std::vector<double> &gravitational_parameters) {
+        if (gravitational_parameters.size() != static_cast<size_t>(splines.bodies()))
+            throw std::invalid_argument("Ephemeris: one gravitational parameter per body");
         detail::check(eph_ephemeris_create(splines.raw(), gravitational_parameters.data(), &h_), "eph_ephemeris_create");
     }
     Ephemeris(const Ephemeris &) = delete;
     Ephemeris &operator=(const Ephemeris &) = delete;
+    Ephemeris(Ephemeris &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    Ephemeris &operator=(Ephemeris &&o) noexcept {
+        if (this != &o) { if (h_) eph_ephemeris_destroy(h_); h_ = std::exchange(o.h_, nullptr); }
+        return *this;
+    }
     ~Ephemeris() { if (h_) eph_ephemeris_destroy(h_); }
     eph_ephemeris *raw() const { return h_; }
 
+    // UniformSpline::append / prepend for every body (trajectory.rs:515-534); the reference's assert_eq! becomes std::invalid_argument,
+    // the table untouched
+    void append(const Solution &tail, Direction d = Direction::Forward) { grow(eph_ephemeris_append(h_, tail.raw(), static_cast<int32_t>(d)), "eph_ephemeris_append"); }
+    // PredictionTarget::merge for the bodies: clear_after(propagated.start()) + append (dynamics/celestial.rs:198-204), Backward:
+    // clear_before(propagated.end()) + prepend (:220-226) -- what the app calls with every snapshot the N-body task sends
+    void merge(const Solution &propagated, Direction d = Direction::Forward) { grow(eph_ephemeris_merge(h_, propagated.raw(), static_cast<int32_t>(d)), "eph_ephemeris_merge"); }
+    void clear_before(double at, int32_t body = -1) { detail::check(eph_ephemeris_clear(h_, body, at, 0), "eph_ephemeris_clear"); }   // trajectory.rs:536-542
+    void clear_after(double at, int32_t body = -1) { detail::check(eph_ephemeris_clear(h_, body, at, 1), "eph_ephemeris_clear"); }    // :544-549
+    // Bodies::is_valid_at (dynamics/spacecraft.rs:199-201): what flight_plan.rs:363-395 tests before it restarts a ship's prediction
+    bool is_valid_at(double t) const {
+        int32_t f = 0;
+        detail::check(eph_ephemeris_is_valid_at(h_, t, &f), "eph_ephemeris_is_valid_at");
+        return f != 0;
+    }
+    struct Info { double start, interval; int64_t npoly; };           // UniformSpline{start, interval, polynomials.len()} as it is now
+    Info info(int32_t body) const {
+        Info i{};
+        detail::check(eph_ephemeris_info(h_, body, &i.start, &i.interval, &i.npoly, nullptr), "eph_ephemeris_info");
+        return i;
+    }
+    uint64_t revision() const {
+        uint64_t r = 0;
+        detail::check(eph_ephemeris_info(h_, -1, nullptr, nullptr, nullptr, &r), "eph_ephemeris_info");
+        return r;
+    }
+    // one contiguous image of the table (what rank 0 of a multi-GPU sweep broadcasts) and a table built from one
+    std::vector<unsigned char> export_image() const {
+        uint64_t need = 0;
+        (void)eph_ephemeris_export(h_, nullptr, 0, &need);
+        std::vector<unsigned char> buf(static_cast<size_t>(need));
+        detail::check(eph_ephemeris_export(h_, buf.data(), need, &need), "eph_ephemeris_export");
+        return buf;
+    }
+    static Ephemeris from_image(const std::vector<unsigned char> &image) {
+        eph_ephemeris *h = nullptr;
+        detail::check(eph_ephemeris_import(image.data(), image.size(), &h), "eph_ephemeris_import");
+        return Ephemeris(h);
+    }
+
 private:
+    explicit Ephemeris(eph_ephemeris *h) : h_(h) {}
+    static void grow(int32_t st, const char *what) {
+        if (st == EPH_ERR_BAD_ARGUMENT) throw std::invalid_argument(std::string(what) + ": not contiguous (trajectory.rs:517-518,530-531)");
+        detail::check(st, what);
+    }
     eph_ephemeris *h_ = nullptr;
 };
 
@@ -363,6 +426,10 @@ public:
 
     void step_to(double time) { detail::check(eph_craft_batch_propagate(h_, time), "eph_craft_batch_propagate"); }   // every craft: IncrementalPropagator::step_to
     void step(uint32_t n_steps = 1) { detail::check(eph_craft_batch_step_n(h_, n_steps), "eph_craft_batch_step_n"); }
+    // A craft whose last step returned a StepError stays put until the batch is re-armed: the next step_to / step then steps it again,
+    // exactly as the reference's next step() on that propagator would (runge_kutta/mod.rs:414-439) -- how a stored ship propagator
+    // resumes once the bodies' ephemeris has grown (prediction.rs:378)
+    void retry_failed() { detail::check(eph_craft_batch_retry_failed(h_), "eph_craft_batch_retry_failed"); }
     // per craft: Ok / the StepError its propagator returned (EPH_KNOTS_FULL = 6: drain the knots and resume)
     std::vector<int32_t> status(std::vector<int32_t> *nknots = nullptr) const {
         std::vector<int32_t> st(static_cast<size_t>(n_)), nk(static_cast<size_t>(n_));
@@ -379,6 +446,7 @@ public:
         detail::check(eph_craft_batch_knots(h_, craft, t.data(), detail::flat(position), detail::flat(velocity)), "eph_craft_batch_knots");
     }
     CubicHermiteSpline trajectory(int64_t craft) const {
+        if (craft < 0 || craft >= n_) throw std::invalid_argument("SpacecraftBatch::trajectory: craft index");
         std::vector<int32_t> nk;
         (void)status(&nk);
         CubicHermiteSpline sp;
@@ -398,6 +466,7 @@ public:
     }
     // one craft's event lists; returns EPH_OK or EPH_EVENTS_FULL (read, reset_events(), resume)
     int32_t events(int64_t craft, SoiTransitions &transitions, Apsides &apsides) const {
+        if (craft < 0 || craft >= n_) throw std::invalid_argument("SpacecraftBatch::events: craft index");
         const size_t n = static_cast<size_t>(n_), c = static_cast<size_t>(craft);
         std::vector<int32_t> ntr(n), nap(n), st(n);
         detail::check(eph_craft_batch_event_counts(h_, ntr.data(), nap.data(), st.data()), "eph_craft_batch_event_counts");
@@ -421,6 +490,10 @@ public:
         return SpacecraftBatch(c, n_);
     }
     SpacecraftBatch(SpacecraftBatch &&o) noexcept : h_(std::exchange(o.h_, nullptr)), n_(o.n_) {}
+    SpacecraftBatch &operator=(SpacecraftBatch &&o) noexcept {
+        if (this != &o) { if (h_) eph_craft_batch_destroy(h_); h_ = std::exchange(o.h_, nullptr); n_ = o.n_; }
+        return *this;
+    }
     int64_t len() const { return n_; }
 
 private:

@@ -177,6 +177,21 @@ def test_cpp_example_runs_on_the_device(gpu, tmp_path):
     assert int(m.group(1)) == len(trt) and int(m.group(2)) == len(apt) and len(apt) > 0 and float.fromhex(m.group(3)) == apt[0]
     edit = po.timeline_divergence_time_before([burn, (t0 + 2 * 86400.0, t0 + 2 * 86400.0 + 30.0, [0.0, 1e-4, 0.0], -1)], [burn], t0 + 3 * 86400.0)
     assert f"flight plan edit restarts at t0 + {edit - t0:.1f} s" in r.stdout, r.stdout
+    # auto-extend: a ship runs off the table's end, the bodies' next snapshot is merged into the live table, the SAME propagator resumes
+    c = orc.Craft(eph, s.mu, t0, [-27204249.668775786, 132947582.43848978, 57641619.74241204],
+                  [-22.207539106181895, -5.189518219791726, -2.2515617105336263], "DormandPrince54")
+    target = t0 + 50 * 86400.0
+    assert c.step_to(target) == orc.EVAL_FAILED
+    failed_at = len(c.knots()[0])
+    assert o.step_to(t0 + 60 * 86400.0) == 0
+    assert eph.append(o.take_solution())
+    assert c.step_to(target) == 0
+    kt, kp, kv = c.knots()
+    m = re.search(rf"auto-extend: (failed to evaluate ODE) after (\d+) knots \(table valid at target: 0 -> 1, revision 1\); resumed: (\w+), knots (\d+), "
+                  rf"last knot t = {hx} r = {hx} {hx} {hx}", r.stdout)
+    assert m, r.stdout
+    assert int(m.group(2)) == failed_at and int(m.group(4)) == len(kt) > failed_at
+    assert np.array_equal(bits([float.fromhex(x) for x in m.groups()[4:]]), bits(np.concatenate([[kt[-1]], kp[-1]])))
 
 
 def test_c_spacecraft_example_runs_on_the_device(gpu, tmp_path):
