@@ -15,7 +15,8 @@ N_PAIR_VARIANTS = 7      # csrc/pair_term.h: the evaluation orders of the unpinn
 PAIR_SOURCES = ["step_wg.hip", "step_wave.hip", "step_small.hip", "fast.hip", "craft_sweep.hip"]
 # compiled once
 SOURCES = ["solout.hip", "craft.hip", "peer.hip", "dispatch.cpp", "mem.cpp", "coeffs.cpp", "nbody.cpp", "propagator.cpp", "shard.cpp", "api.cpp"]
-HEADERS = ["eph_internal.h", "eph_debug.h", "host.h", "ieee_seq.h", "pair_term.h", "pair_ns.h", "pair_launchers.h", "force_common.h", "craft_device.h",
+EXPORTS = CSRC / "exports.map"      # linker version script: only eph_* is a dynamic symbol
+HEADERS = ["exports.map", "eph_internal.h", "eph_debug.h", "host.h", "ieee_seq.h", "pair_term.h", "pair_ns.h", "pair_launchers.h", "force_common.h", "craft_device.h",
            "coeff_tables.inc", "cr_pow_tables.inc", "craft_attempt.inc", "../../include/ephemeris_amd.h"]
 # -ffp-contract=off is REQUIRED for parity (HIP's default is fast contraction): the reference never fuses a*b+c.
 # -fvisibility=hidden: the library exports the extern "C" boundary of include/ephemeris_amd.h and nothing else
@@ -79,11 +80,12 @@ def build(force=False, verbose=False, lib=LIB, extra_flags=(), obj_dir=None, job
     with ThreadPoolExecutor(jobs or max(2, (os.cpu_count() or 4))) as ex:
         list(ex.map(compile_one, todo))
     hook_objs = [o for o in objs if Path(o).name in {h.rsplit(".", 1)[0] + ".o" for h in HOOKS_SOURCES}]
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}"]
     if hooks is not None:                              # the product: the boundary only; the hooks in a library of their own
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *[o for o in objs if o not in hook_objs]])
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(hooks), *objs])
+        subprocess.check_call([*link, "-o", str(lib), *[o for o in objs if o not in hook_objs]])
+        subprocess.check_call([*link, "-o", str(hooks), *objs])
     else:                                              # a tuning build carries its hooks itself
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *objs])
+        subprocess.check_call([*link, "-o", str(lib), *objs])
     return lib
 
 
