@@ -227,6 +227,46 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     return true;
 }
 
+// ---- stage storage of the thread-per-craft kernels ---------------------------------------------------------------------------------
+// k_s = (dy.position, dy.velocity) of stage s, and dy.position = y.velocity (spacecraft.rs:303-305): the VELOCITY half of every stage
+// derivative is a copy of the stage state's velocity, the ACCELERATION half is the force sum. Round 5 kept both in VGPRs: 13 stages x 6
+// doubles = 156 of a lane's 256 registers at two waves per SIMD, and the allocator spilled 100 VGPRs to scratch (counter traffic 5.9 x
+// algorithmic: 4.63 GB per launch against 0.78 GB). Round 6: the velocity halves live in LDS, one 512-byte row of 64 lanes per
+// (stage, component) -- conflict-free ds_read_b64 / ds_write_b64, no barrier (a lane only ever touches its own column) -- and the
+// acceleration halves in registers. 13 stages x 3 x 512 B = 19 968 B per wave; the CU's 160 KB hold the eight waves of two per SIMD.
+// A 16-stage pair keeps its last three velocity halves in registers (kCraftLdsStages). LDS traffic is ~350 8-byte accesses per lane
+// and attempt against ~31 000 FP64 instructions: nothing. Storage only -- every operand and every operation is the reference's.
+constexpr int kCraftLdsStages = 13;
+template <int S, bool NYS> struct CraftStages {
+    static constexpr int LS = NYS ? 0 : (S < kCraftLdsStages ? S : kCraftLdsStages);      // stages whose velocity half is in LDS
+    static constexpr int RS = NYS ? 0 : S - LS;                                            // ... in registers
+};
+#define EPH_CRAFT_STAGE_STORAGE                                                                            \
+    constexpr int LS = CraftStages<S, NYS>::LS;                                                            \
+    __shared__ double kv_lds[(LS ? LS : 1) * 3 * 64];                                                      \
+    const int lane_ = threadIdx.x;                                                                         \
+    double ka[S][3];                                          /* acceleration halves (ERKNG: dk[s]) */     \
+    double kvr[CraftStages<S, NYS>::RS ? CraftStages<S, NYS>::RS : 1][3];
+#define KV_GET(j, d) ((j) < LS ? kv_lds[((j) * 3 + (d)) * 64 + lane_] : kvr[(j) >= LS ? (j) - LS : 0][d])
+#define KV_PUT(j, d, v)                                                                                    \
+    do {                                                                                                   \
+        if ((j) < LS) kv_lds[((j) * 3 + (d)) * 64 + lane_] = (v);                                          \
+        else kvr[(j) >= LS ? (j) - LS : 0][d] = (v);                                                       \
+    } while (0)
+// the FSAL pairs' k[S-1] / k[0] between calls (a.klast / a.kfirst: [6][n], velocity half first)
+#define EPH_CRAFT_LOAD_FSAL(i_)                                                                            \
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                        \
+        if (!NYS) { KV_PUT(S - 1, d, a.klast[d * n + (i_)]); KV_PUT(0, d, a.kfirst[d * n + (i_)]); }       \
+        ka[S - 1][d] = a.klast[((NYS ? 0 : 3) + d) * n + (i_)];                                            \
+        ka[0][d] = a.kfirst[((NYS ? 0 : 3) + d) * n + (i_)];                                               \
+    }
+#define EPH_CRAFT_STORE_FSAL(i_)                                                                           \
+    _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                        \
+        if (!NYS) { a.klast[d * n + (i_)] = KV_GET(S - 1, d); a.kfirst[d * n + (i_)] = KV_GET(0, d); }     \
+        a.klast[((NYS ? 0 : 3) + d) * n + (i_)] = ka[S - 1][d];                                            \
+        a.kfirst[((NYS ? 0 : 3) + d) * n + (i_)] = ka[0][d];                                               \
+    }
+
 // NYS = false: ERK pair on the 6-vector (explicit.rs).  NYS = true: ERKNG pair on SecondOrderState<[DVec3; 1]>
 // (nystrom/explicit_generalized.rs:97-170, the app's Fine45): k[s][0..2] hold dk[s].
 // Register budget (OCC = waves per SIMD the allocation is held to): the 13- and 16-stage pairs need > 256 registers
@@ -263,11 +303,8 @@ k_craft_propagate(const CraftArgs a) {
     const SegmentDev *segs = a.segs + a.seg_off[i];
     SegmentDev sg = segs[cur];
     double bound = sg.end;
-    double k[S][6];
-    if (FSAL) {
-#pragma unroll
-        for (int d = 0; d < 6; ++d) { k[S - 1][d] = a.klast[d * n + i]; k[0][d] = a.kfirst[d * n + i]; }
-    }
+    EPH_CRAFT_STAGE_STORAGE
+    if (FSAL) { EPH_CRAFT_LOAD_FSAL(i) }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
 
     unsigned taken = 0;
@@ -283,10 +320,12 @@ k_craft_propagate(const CraftArgs a) {
             rk_i = 0;
         }
         // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439
+        // PreviousStep: the state is not copied -- the newest knot of the slab IS the state before this step (knot 0 is the initial
+        // state, and reset_knots keeps the newest), so a rejection reads it back from there
         const double prev_t = time;
-        double prev_y[6], prev_klast[6];
+        double prev_klast[6];
 #pragma unroll
-        for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? k[S - 1][d] : 0.0; }
+        for (int d = 0; d < 3; ++d) { prev_klast[d] = (FSAL && !NYS) ? KV_GET(S - 1, d) : 0.0; prev_klast[3 + d] = FSAL ? ka[S - 1][d] : 0.0; }
         const unsigned prev_i = rk_i;
         bool failed = false;
         for (;;) {
@@ -319,11 +358,11 @@ k_craft_propagate(const CraftArgs a) {
             if (err <= 1.0) break;
             time = prev_t;                            // PreviousStep::restore
 #pragma unroll
-            for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+            for (int d = 0; d < 6; ++d) y[d] = a.knot_y[((long long)(nk - 1) * 6 + d) * n + slot];
             rk_i = prev_i;
             if (FSAL) {
 #pragma unroll
-                for (int d = 0; d < 6; ++d) k[S - 1][d] = prev_klast[d];
+                for (int d = 0; d < 3; ++d) { if (!NYS) KV_PUT(S - 1, d, prev_klast[d]); ka[S - 1][d] = prev_klast[3 + d]; }
             }
         }
         if (failed) break;
@@ -348,10 +387,7 @@ k_craft_propagate(const CraftArgs a) {
     a.nknots[i] = nk;
     a.last_knot_t[i] = last_knot;
     a.status[i] = status;
-    if (FSAL) {
-#pragma unroll
-        for (int d = 0; d < 6; ++d) { a.klast[d * n + i] = k[S - 1][d]; a.kfirst[d * n + i] = k[0][d]; }
-    }
+    if (FSAL) { EPH_CRAFT_STORE_FSAL(i) }
 }
 
 // The sweep, QUEUE form, for batches whose craft need very different numbers of attempts (adaptive step counts differ by
@@ -381,12 +417,12 @@ k_craft_queue(const CraftArgs a) {
     int cur = 0, nk = 0;
     const SegmentDev *segs = a.segs;
     SegmentDev sg{};
-    double k[S][6];
-    double prev_t = 0.0, prev_y[6], prev_klast[6];
+    EPH_CRAFT_STAGE_STORAGE
+    double prev_t = 0.0, prev_klast[6];                 // (PreviousStep's state: the slab's newest knot, as in k_craft_propagate)
     unsigned prev_i = 0;
     bool in_step = false;                               // between a step's prologue and its acceptance
 #pragma unroll
-    for (int d = 0; d < 6; ++d) { prev_y[d] = 0.0; prev_klast[d] = 0.0; }
+    for (int d = 0; d < 6; ++d) prev_klast[d] = 0.0;
 
     auto load = [&]() -> bool {                         // craft i -> registers; false: nothing to do for it
         status = a.status[i];
@@ -402,10 +438,7 @@ k_craft_queue(const CraftArgs a) {
         segs = a.segs + a.seg_off[i];
         sg = segs[cur];
         bound = sg.end;
-        if (FSAL) {
-#pragma unroll
-            for (int d = 0; d < 6; ++d) { k[S - 1][d] = a.klast[d * n + i]; k[0][d] = a.kfirst[d * n + i]; }
-        }
+        if (FSAL) { EPH_CRAFT_LOAD_FSAL(i) }
         taken = 0;
         in_step = false;
         return true;
@@ -422,10 +455,7 @@ k_craft_queue(const CraftArgs a) {
         a.nknots[i] = nk;
         a.last_knot_t[i] = last_knot;
         a.status[i] = status;
-        if (FSAL) {
-#pragma unroll
-            for (int d = 0; d < 6; ++d) { a.klast[d * n + i] = k[S - 1][d]; a.kfirst[d * n + i] = k[0][d]; }
-        }
+        if (FSAL) { EPH_CRAFT_STORE_FSAL(i) }
     };
 
     bool have = first_in_range && load();
@@ -457,7 +487,7 @@ k_craft_queue(const CraftArgs a) {
                 // AdaptiveRungeKuttaIntegrator::advance  mod.rs:414-439: PreviousStep
                 prev_t = time;
 #pragma unroll
-                for (int d = 0; d < 6; ++d) { prev_y[d] = y[d]; prev_klast[d] = FSAL ? k[S - 1][d] : 0.0; }
+                for (int d = 0; d < 3; ++d) { prev_klast[d] = (FSAL && !NYS) ? KV_GET(S - 1, d) : 0.0; prev_klast[3 + d] = FSAL ? ka[S - 1][d] : 0.0; }
                 prev_i = rk_i;
                 in_step = true;
             }
@@ -509,11 +539,11 @@ k_craft_queue(const CraftArgs a) {
             } else {
                 time = prev_t;                            // PreviousStep::restore
 #pragma unroll
-                for (int d = 0; d < 6; ++d) y[d] = prev_y[d];
+                for (int d = 0; d < 6; ++d) y[d] = a.knot_y[((long long)(nk - 1) * 6 + d) * n + col];
                 rk_i = prev_i;
                 if (FSAL) {
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) k[S - 1][d] = prev_klast[d];
+                    for (int d = 0; d < 3; ++d) { if (!NYS) KV_PUT(S - 1, d, prev_klast[d]); ka[S - 1][d] = prev_klast[3 + d]; }
                 }
             }
         }
