@@ -116,6 +116,184 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
+// ---- Bodies::acceleration of the thread-per-craft kernels, PIPELINED over the bodies (round 6) -----------------------------------
+// Round 5's loop evaluated one body_term after the other: per (stage, body) two dependent scalar-memory round trips (the table
+// entry, then the coefficient row whose address needs the segment index), a dozen taken branches between small blocks (every
+// guarded fast path its own block, laid out behind the slow ones) and one dependent chain at a time; inlined thirteen times it was
+// 82 KB of code for the 13-stage pair -- more than the instruction cache. Now, per body b:
+//   P(b)  Horner over the coefficient row that was PREFETCHED into SGPRs while body b-1's term was computed (three independent
+//         chains); lanes inside different polynomials (a long sweep's craft drift apart in time) take the rows one after the other
+//         (waterfall: one pass per distinct row, rows still through the scalar cache);
+//   R(b)  difference and squared distance, the point-mass term of body b -- one dependent chain -- TOGETHER WITH the segment lookup
+//         of body b+1 (a second, independent chain) in ONE basic block; the table entry and the row of body b+1 are requested here
+//         and arrive under the term's arithmetic.
+// The lookup is speculative and branch-free (every guarded choice of spline_locate_fast assumed; one ballot says whether all held);
+// whatever does not fit -- a lane outside its spline (-> EvalFailed), an interval or operand outside the guarded ranges, more than
+// 2^31 polynomials -- goes through ONE out-of-line copy of the plain IEEE path per kernel (body_position_generic / pair_generic),
+// which produces the same bits (ieee_seq.h: the guarded sequences ARE the compiler's expansions without their no-op wrappers).
+// Same operations in the same order per body, terms added in a.bodies order.
+__device__ __forceinline__ BodyEntry entry_uniform(const BodyEntry *table, int b) {
+    // the body's table entry is the same for every lane: scalar loads through the constant address space
+    const int bu = __builtin_amdgcn_readfirstlane(b);
+    const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(table + bu);
+    BodyEntry be;
+    be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
+    be.coeff_off = bc->coeff_off; be.span = bc->span; be.rinv = bc->rinv; be.pad_ = 0.0;
+    return be;
+}
+__device__ __forceinline__ long long uniform64(long long v) {
+    return (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v) | ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32);
+}
+__device__ __forceinline__ long long lane64(long long v, int l) {
+    return (long long)(unsigned)__builtin_amdgcn_readlane((int)v, l) | ((long long)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32);
+}
+struct RowS { double c[kDiv * 3]; };                  // one polynomial's 24 coefficients, wave-uniform: SGPRs
+// EPH_CRAFT_ROW_SPLIT=1 loads it in two parts -- the 16 high coefficients (Horner's first five steps) a body ahead, the 8 low ones at
+// the start of the body's own Horner pass -- so that 32 instead of 48 SGPRs stay occupied across the previous body's term and none of
+// the row is spilled to VGPR lanes. Measured on one box (scripts/ab_craft.sh, 262 144 craft x 0.25 d): 31.1 ms against 29.9-30.0 for
+// the whole row a body ahead (8 v_readlane per term, but no exposed scalar-cache latency in front of Horner): off.
+#ifndef EPH_CRAFT_ROW_SPLIT
+#define EPH_CRAFT_ROW_SPLIT 0
+#endif
+constexpr int kRowLo = EPH_CRAFT_ROW_SPLIT ? 8 : 0;   // coefficients [0, kRowLo) are loaded late
+__device__ __forceinline__ void row_uniform_hi(const double *coeffs, long long row0, RowS &r) {
+    const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(coeffs + row0 * kDiv * 3);
+#pragma unroll
+    for (int k = kRowLo; k < kDiv * 3; ++k) r.c[k] = cs[k];
+}
+__device__ __forceinline__ void row_uniform_lo(const double *coeffs, long long row0, RowS &r) {
+    const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(coeffs + row0 * kDiv * 3);
+#pragma unroll
+    for (int k = 0; k < kRowLo; ++k) r.c[k] = cs[k];
+}
+// eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so the leading steps give
+// 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no ncoef load, no loop
+__device__ __forceinline__ V3 horner_row(const RowS &r, double tau) {
+    V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + r.c[k * 3 + 0];
+        bp.y = bp.y * tau + r.c[k * 3 + 1];
+        bp.z = bp.z * tau + r.c[k * 3 + 2];
+    }
+    return bp;
+}
+// UniformSpline::get_polynomial, speculatively: spline_locate_fast with every guarded choice assumed (shared reciprocal for both
+// quotients, 32-bit segment count). Straight-line; returns whether THIS lane's assumptions hold and it is inside the spline. When
+// they hold for the whole wave (and the entry passes entry_fast), tau and idx are spline_locate_fast's. The tests are folded: both
+// numerators in the guarded range of the shared-reciprocal division (one max over their range keys; a negative, zero or NaN `local`
+// has a key outside it, so the sign test is implied -- t == start exactly, where local = rem = +0 is a legal numerator, takes the
+// out-of-line path), not beyond the span, and the segment inside the table (which also catches a count that was clamped at 2^31:
+// entry_fast requires npoly < 2^31).
+__device__ __forceinline__ unsigned div_key(double x) { return (unsigned)(__double2hiint(x) - 0x33700000); }    // in_range_div: key < 0x19000000
+__device__ __forceinline__ bool locate_spec(const BodyEntry &b, double at, double &tau, unsigned &idx) {
+    const double local = at - b.start;
+    const double c = ceil(div_refined(local, b.interval, b.rinv));
+    const unsigned ci = (unsigned)fmin(fmax(c, 0.0), 2147483648.0);       // c <= 0 (and NaN) -> 0, as `c <= 0.0 ? 0u : (unsigned)c`
+    const unsigned i32 = ci == 0 ? 0u : ci - 1u;
+    const double rem = local - b.interval * (double)i32;
+    tau = div_refined(rem, b.interval, b.rinv);
+    idx = i32;
+    // (bitwise, not &&: a short-circuit chain becomes divergent control flow and cuts the block the lookup shares with the term)
+    return (max(div_key(local), div_key(rem)) < 0x19000000u) & !(local > b.span) & (i32 < (unsigned)b.npoly);
+}
+__device__ __forceinline__ bool entry_fast(const BodyEntry &b) {          // wave-uniform: scalar compares
+    return (__double_as_longlong(b.rinv) != 0) & ((unsigned long long)b.npoly < 0x80000000ull);
+}
+// the out-of-line IEEE path (cold): UniformSpline::get_polynomial + eval with the compiler's divisions, per-lane coefficient loads
+struct BodyPos { double x, y, z; int located; };
+// (reads the table entry itself: the hot loop then keeps nothing of an entry alive for this call's sake)
+__device__ __noinline__ BodyPos body_position_generic(const double *coeffs, const BodyEntry *table, int b, double t) {
+    BodyEntry be = table[b];
+    be.span = be.interval * (double)be.npoly;
+    const long long coeff_off = be.coeff_off;
+    long long idx;
+    double tau;
+    if (!spline_locate(be, t, idx, tau)) return BodyPos{0.0, 0.0, 0.0, 0};
+    const double *co = coeffs + (coeff_off + idx) * kDiv * 3;
+    V3 bp = {0.0, 0.0, 0.0};
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + co[k * 3 + 0];
+        bp.y = bp.y * tau + co[k * 3 + 1];
+        bp.z = bp.z * tau + co[k * 3 + 2];
+    }
+    return BodyPos{bp.x, bp.y, bp.z, 1};
+}
+__device__ __noinline__ V3 pair_generic(double n2, double dx, double dy, double dz, double mu) {
+    V3 term;
+    pair_apply<false>(pair_den<false>(n2), dx, dy, dz, mu, term.x, term.y, term.z);
+    return term;
+}
+__device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t, const V3 &pos, V3 &acc) {
+    const int nb = a.n_bodies;
+    if (nb <= 0) return true;
+    // A lane outside a body's spline (EvalFailed) does NOT leave the loop: it is flagged, kept out of the ballots and carries
+    // harmless numbers to the end. A divergent exit would make every loop-carried value divergent in the compiler's eyes -- table
+    // entries and coefficient rows in VGPRs, per-lane loads -- although they are the same for every lane.
+    bool failed = false;
+    // prologue: body 0's entry, lookup and the high part of its row
+    BodyEntry be = entry_uniform(a.bodies, 0);
+    double tau;
+    unsigned idx;
+    bool good = locate_spec(be, t, tau, idx);
+    bool all_good = entry_fast(be) & (__builtin_amdgcn_ballot_w64(!good) == 0);                         // wave-uniform
+    unsigned i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx) & -(unsigned)all_good;            // (branch-free: row 0 of a body is always a valid address)
+    long long row0 = be.coeff_off + (long long)i0;
+    RowS cs;
+    row_uniform_hi(a.coeffs, row0, cs);
+    for (int b = 0; b < nb; ++b) {
+        // ---- P(b): the body's position at t
+        row_uniform_lo(a.coeffs, row0, cs);
+        const long long off = be.coeff_off;
+        V3 bp;
+        if (__builtin_expect(all_good, 1)) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!failed & (idx != i0)) == 0, 1)) {
+                bp = horner_row(cs, tau);             // every lane inside the SAME polynomial (craft of one sweep started together)
+            } else {
+                bool pending = !failed;               // one pass per distinct polynomial, first the prefetched one
+                bp = V3{0.0, 0.0, 0.0};
+                for (;;) {
+                    if (pending & (idx == i0)) { bp = horner_row(cs, tau); pending = false; }
+                    const unsigned long long left = __builtin_amdgcn_ballot_w64(pending);
+                    if (left == 0) break;
+                    i0 = (unsigned)__builtin_amdgcn_readlane((int)idx, __builtin_ctzll(left));
+                    row_uniform_hi(a.coeffs, off + (long long)i0, cs);
+                    row_uniform_lo(a.coeffs, off + (long long)i0, cs);
+                }
+            }
+        } else {
+            asm volatile("");
+            const BodyPos g = body_position_generic(a.coeffs, a.bodies, b, t);
+            failed = failed | !g.located;
+            bp = V3{g.x, g.y, g.z};
+        }
+        // ---- R(b): the term of body b, with the lookup of body b + 1 beside it and the next row / entry requested
+        const double mu = be.mu;
+        const V3 d = sub(bp, pos);                    // acceleration_at::<false>: dir = body - at
+        const double n2 = dot(d, d);
+        const bool more = b + 1 < nb;
+        be = entry_uniform(a.bodies, more ? b + 1 : 0);      // (one entry in SGPRs at a time: its latency hides under body b's term)
+        good = locate_spec(be, t, tau, idx);
+        // the point-mass term in the build's evaluation order, IEEE sqrt and divide (pair_term.h): the wrapper-free sequences for
+        // every lane; a squared distance outside the guarded range anywhere in the wave sends it through the compiler's expansions
+        const PairDen den = pair_den<true>(n2);
+        all_good = more & entry_fast(be) & (__builtin_amdgcn_ballot_w64(!failed & !good) == 0);
+        i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx) & -(unsigned)all_good;
+        row0 = be.coeff_off + (long long)i0;
+        row_uniform_hi(a.coeffs, row0, cs);
+        V3 term;
+        pair_apply<true>(den, d.x, d.y, d.z, mu, term.x, term.y, term.z);
+        // (the empty asm keeps the straight-line term IN this block, beside the lookup of the next body: two independent chains; without
+        // it the compiler sinks the term behind the range test into a block of its own)
+        asm volatile("" : "+v"(term.x), "+v"(term.y), "+v"(term.z));
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!failed & !in_range(n2)) != 0, 0)) {
+            asm volatile("");
+            term = pair_generic(n2, d.x, d.y, d.z, mu);
+        }
+        acc = add(acc, term);
+    }
+    return !failed;
+}
 constexpr int kRedRow = kTile + 2;                    // LDS row of the wave variant's contribution tile
 
 // FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.
@@ -169,17 +347,7 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             acc.z = lane_bcast(sum, 2);
         }
     } else {
-        for (int b = 0; b < a.n_bodies; ++b) {        // Bodies::acceleration: the order of a.bodies (eph_craft_batch_set_body_order)
-            // the body's table entry is the same for every lane: scalar loads through the constant address space
-            const int bu = __builtin_amdgcn_readfirstlane(b);
-            const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(a.bodies + bu);
-            BodyEntry be;
-            be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
-            be.coeff_off = bc->coeff_off; be.span = bc->span; be.rinv = bc->rinv;
-            V3 term;
-            if (!body_term(a, be, t, pos, term)) return false;
-            acc = add(acc, term);
-        }
+        if (!bodies_acceleration(a, t, pos, acc)) return false;   // Bodies::acceleration: the order of a.bodies (eph_craft_batch_set_body_order)
     }
     V3 man = {0.0, 0.0, 0.0};
     if (sg.is_burn) {

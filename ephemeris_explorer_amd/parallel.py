@@ -114,6 +114,51 @@ def broadcast_unique_id(dist, make_id, device="cpu", group=None):
     return bytes(buf.cpu().tolist())
 
 
+def broadcast_ephemeris(build, dist=None, device="cpu", group=None, from_image=None):
+    """rank 0 builds the massive bodies' table ONCE (build() -> Ephemeris), exports it as one contiguous image
+    (eph_ephemeris_export) and broadcasts it; every other rank imports it (eph_ephemeris_import) instead of integrating the bodies
+    again. `device`: where the broadcast buffers live ("cuda" with the nccl = RCCL backend: over xGMI; "cpu" with gloo).
+    Returns (ephemeris, {"build_s", "export_s", "broadcast_s", "import_s", "bytes"}); the table is bit-identical on every rank
+    (tests/test_gpu_bench.py compares the images). `from_image`: Ephemeris.from_image unless given (the CPU test of this plumbing
+    passes a stand-in)."""
+    import time
+
+    import numpy as np
+    if from_image is None:
+        from . import Ephemeris
+        from_image = Ephemeris.from_image
+    t = {"build_s": 0.0, "export_s": 0.0, "broadcast_s": 0.0, "import_s": 0.0, "bytes": 0}
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size(group)
+    rank = 0 if world == 1 else dist.get_rank(group)
+    eph, image = None, None
+    if rank == 0:
+        t0 = time.perf_counter()
+        eph = build()
+        t["build_s"] = time.perf_counter() - t0
+        if world > 1:
+            t0 = time.perf_counter()
+            image = eph.export_image()
+            t["export_s"] = time.perf_counter() - t0
+            t["bytes"] = int(image.size)
+    if world > 1:
+        import torch
+        t0 = time.perf_counter()
+        size = torch.tensor([image.size if rank == 0 else 0], dtype=torch.int64, device=device)
+        dist.broadcast(size, src=0, group=group)
+        n = int(size.item())
+        buf = torch.from_numpy(image).to(device) if rank == 0 else torch.empty(n, dtype=torch.uint8, device=device)
+        dist.broadcast(buf, src=0, group=group)
+        if device != "cpu":
+            torch.cuda.synchronize()
+        t["broadcast_s"] = time.perf_counter() - t0
+        t["bytes"] = n
+        if rank != 0:
+            t0 = time.perf_counter()
+            eph = from_image(np.ascontiguousarray(buf.cpu().numpy()))
+            t["import_s"] = time.perf_counter() - t0
+    return eph, t
+
+
 def peer_transport(dist, slot_bytes=1 << 22, group=None):
     """A connected PeerTransport over the ranks of the process group: the 64-byte hipIpc handles travel through
     torch.distributed (all_gather_object: any backend), the data never does."""

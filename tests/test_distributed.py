@@ -46,6 +46,22 @@ def _worker(rank, world, port, out):
     all_idx = np.arange(1001, dtype=np.float64)
     assert np.array_equal(table[:, 0], all_idx * 2.0) and np.array_equal(table[:, 2], all_idx + 0.25)
     assert np.array_equal(table[:, 6], -all_idx)
+    # the ephemeris image built once on rank 0 and broadcast (a stand-in table here: the device is not involved)
+    class Table:
+        def __init__(self, image):
+            self.image = image
+
+        def export_image(self):
+            return self.image
+    built = []
+
+    def build():
+        built.append(rank)
+        return Table(np.frombuffer(np.arange(100003, dtype=np.uint32).tobytes(), dtype=np.uint8).copy())
+    tab, parts = parallel.broadcast_ephemeris(build, dist, from_image=Table)
+    assert built == ([0] if rank == 0 else [])                     # only rank 0 integrates the bodies
+    assert parts["bytes"] == 400012 and np.array_equal(np.frombuffer(tab.image.tobytes(), dtype=np.uint32), np.arange(100003, dtype=np.uint32))
+    assert (parts["import_s"] > 0.0) == (rank != 0)
     out[rank] = (total, tmax, lo, hi, float(nb.state()[0].sum()))
     dist.barrier()
     dist.destroy_process_group()

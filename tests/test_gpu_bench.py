@@ -130,6 +130,10 @@ def test_two_ranks_craft_sweep_with_result_gather(population):
     assert d["n_gpus"] == 2 and d["metric"] == "craft-steps/s" and "all-gather" in d["config"]["exchange"]
     assert d["divergence"]["attempts_max_over_mean_per_wave"] >= 1.0
     assert (population == "mixed") == ("population" in d["config"]["workload"])
+    # rank 0 built the table once and broadcast its image; rank 1 imported it; bit-identical to a local rebuild
+    bc = d["ephemeris_broadcast_s"]
+    assert bc["identical_to_the_local_rebuild"] is True and bc["rank0_parts"]["bytes"] > 100000
+    assert bc["max_over_ranks"] > 0.0 and d["ephemeris_rebuild_s"]["max_over_ranks"] > 0.0
 
 
 @pytest.mark.parametrize("transport", ["host", "peer"])
