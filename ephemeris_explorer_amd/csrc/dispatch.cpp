@@ -124,6 +124,9 @@ int fast_slices(int npad, bool approx) {
     S = std::max(8, std::min(64, S));            // (8 rather than 4 slices at 65 536 bodies, eight waves per SIMD: 1.17 -> 1.13 ms on the f32 path)
     return (S + 3) / 4 * 4;
 }
+// the fast paths' scratch: [S][3][npad] partial sums (the larger of the two slice counts) + one arrival ticket per block of 64 targets
+size_t fast_partial_doubles(int npad) { return (size_t)fast_slices(npad, true) * 3 * npad + (size_t)(npad / 64 + 2) / 2 + 1; }
+size_t fast_ticket_offset_doubles(int npad) { return (size_t)fast_slices(npad, true) * 3 * npad; }
 int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf, int f32_stage, int conv_lo,
                         int conv_cnt) {
     const PairKernels *t = table(pv);
@@ -134,7 +137,16 @@ int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial,
     if (conv_cnt < 0) { conv_lo = 0; conv_cnt = a.npad; }
     if (f32_stage != 1 && a.hi <= a.lo) return EPH_OK;                  // a rank whose slice is all padding
     static const int unroll = env_int("EPH_FAST_UNROLL", 4) == 8 ? 8 : 4;
-    return t->lm_step_fast(s, a, partial, fast_slices(a.npad, approx), unroll, approx, posf, f32_stage, conv_lo, conv_cnt);
+    // One launch per step (k_fast_step: the last workgroup of a block finishes it) for the IEEE and the binary32 forms, two launches
+    // for the rsq form; EPH_FAST_FUSED=0|1 forces one or the other. Measured on one box, us per step, one launch / two launches
+    // (scripts/time_fast.py, profiles/r06_fast_fused.md): fast 31.4 / 32.8, f32 pairs 14.3 / 15.1 at N = 4096 and 1114 / 1125 at
+    // 65 536, fast-rsq 22.1 / 20.1-21.6 -- the finish is latency-bound either way (64 dependent loads-then-adds per body), fusing
+    // removes a launch gap and pays a barrier, a ticket and the epilogue's registers. The arrival tickets live behind the partial
+    // sums (fast_partial_doubles).
+    static const int forced = env_int("EPH_FAST_FUSED", -1);
+    const bool fused = forced >= 0 ? forced != 0 : !approx;
+    unsigned *tickets = fused ? reinterpret_cast<unsigned *>(partial + fast_ticket_offset_doubles(a.npad)) : nullptr;
+    return t->lm_step_fast(s, a, partial, fast_slices(a.npad, approx), unroll, approx, posf, f32_stage, conv_lo, conv_cnt, tickets);
 }
 int launch_craft(int pv, hipStream_t s, const CraftArgs &a, const CraftLaunch &how) {
     const PairKernels *t = table(pv);

@@ -109,6 +109,8 @@ int launch_lm_small_many(int pv, hipStream_t s, const LmArgs *argv_dev, int coun
 int fast_slices(int npad, bool approx = false);                     // S (the rsq form takes twice the waves)
 // posf: EPH_PATH_F32_PAIRS scratch, 4 floats per padded body. f32_stage 0: the whole step; 1: only the binary32 copy of rows
 // [conv_lo, conv_lo + conv_cnt) (conv_cnt < 0: all); 2: the step on a copy that is complete already (a sharded handle gathers between)
+size_t fast_partial_doubles(int npad);           // scratch of the fast paths incl. the arrival tickets behind the partial sums
+size_t fast_ticket_offset_doubles(int npad);
 int launch_lm_step_fast(int pv, hipStream_t s, const LmArgs &a, double *partial, bool approx, float *posf = nullptr, int f32_stage = 0,
                         int conv_lo = 0, int conv_cnt = -1);
 // the massless sweep (craft_sweep.hip); CraftArgs: craft_device.h
@@ -128,7 +130,7 @@ struct PairKernels {                        // one evaluation order's launchers 
     int (*lm_persistent)(hipStream_t, const LmArgs &, int64_t);
     int (*lm_small)(hipStream_t, const LmArgs &, int64_t);
     int (*lm_small_many)(hipStream_t, const LmArgs *, int, int, int64_t);
-    int (*lm_step_fast)(hipStream_t, const LmArgs &, double *, int, int, bool, float *, int, int, int);
+    int (*lm_step_fast)(hipStream_t, const LmArgs &, double *, int, int, bool, float *, int, int, int, unsigned *);
     int (*craft_launch)(hipStream_t, const CraftArgs &, const CraftLaunch &);
     int (*debug_inv_r3)(hipStream_t, int64_t, const double *, double *, double *);
     int (*debug_inv_r3_sweep)(hipStream_t, uint64_t, int64_t, unsigned long long *);

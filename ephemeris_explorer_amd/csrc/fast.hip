@@ -135,10 +135,8 @@ __device__ __forceinline__ void fast_slice_rsq(const __attribute__((address_spac
     }
 }
 
-// partial: [S][3][npad] scratch. Two launches per step: the kernel boundary is the release/acquire between the
-// slice sums and their combination. (First version: one launch with a per-block arrival ticket, the last workgroup
-// of a block combining -- measured 66 / 96 / 166 us per step at 16 / 32 / 64 slices, N = 4096: the agent-scope
-// fence each workgroup needs before its ticket costs ~0.13 us and they serialise; gpurun_out r02a.)
+// partial: [S][3][npad] scratch. The TWO-launch form (EPH_FAST_FUSED=0): the kernel boundary is the release/acquire between the
+// slice sums and their combination (k_fast_finish). The one-launch form is k_fast_step below.
 template <int UNROLL, bool APPROX>
 __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial(int n, int npad, const Body4 *__restrict__ pos,
                                                                   int S, int slice_len, double *__restrict__ partial) {
@@ -258,34 +256,38 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_fast_partial_f32(int n, int
     pp[(size_t)2 * npad] = az;
 }
 
-// thread per (component, body): partial sums combined in slice order, then the rest of the fused step
-template <int L>
-__global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, const double *__restrict__ partial) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int span = a.hi - a.lo;                               // the launch's bodies [lo, hi): all of them unless the handle is sharded
-    if (t >= 3 * span) return;
-    const int cc = t / span, my_i = a.lo + t % span;            // consecutive threads = consecutive bodies: coalesced
+// one (component, body): partial sums combined in slice order, then the rest of the fused step. COHERENT: the partial sums were
+// written by OTHER workgroups of this launch (agent-scope write-through stores): read them with agent-scope loads
+template <int L, bool COHERENT>
+__device__ __forceinline__ void fast_finish_one(const LmArgs &a, int S, const double *__restrict__ partial, int cc, int my_i) {
     const size_t lvl = (size_t)3 * a.npad;
     const size_t off = (size_t)cc * a.npad + my_i;
+    // EVERY slice's load in flight before the first ordered add (S <= kFastMaxSlices; groups of 16 behind one another paid the
+    // memory latency S / 16 times: 7.3 us for this kernel at S = 64, round 5). In the one-launch form (COHERENT) the registers of
+    // this epilogue set the occupancy of the whole kernel -- the rsq form's slice loop wants four waves per SIMD -- so the sums are
+    // taken in groups of 32 (two latencies at 64 slices) and the history is loaded only afterwards: ~80 instead of 186 VGPRs.
+    constexpr int G = COHERENT ? 32 : kFastMaxSlices;
+    double anew = 0.0;
+#pragma unroll
+    for (int g0 = 0; g0 < kFastMaxSlices; g0 += G) {
+        if (g0 >= S) break;
+        double pv[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if constexpr (COHERENT) pv[u] = g0 + u < S ? __hip_atomic_load(partial + (size_t)(g0 + u) * lvl + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            else pv[u] = g0 + u < S ? partial[(size_t)(g0 + u) * lvl + off] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (g0 + u < S) anew = anew + pv[u];
+    }
+    if constexpr (COHERENT) asm volatile("" : "+v"(anew) :: "memory");      // (the history loads below stay below)
     double yv[L], av[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const int slot = (a.cur + j) % L;
         yv[j] = a.Y[slot * lvl + off];
         av[j] = j > 0 ? a.A[slot * lvl + off] : 0.0;
-    }
-    // all loads of a group of 16 slices in flight before the ordered adds (one load per add would pay the memory
-    // latency S times: measured 11 us for this kernel at S = 32)
-    // EVERY slice's load in flight before the first ordered add (S <= kFastMaxSlices; groups of 16 behind one another paid the
-    // memory latency S / 16 times: 7.3 us for this kernel at S = 64, round 5)
-    double anew = 0.0;
-    {
-        double pv[kFastMaxSlices];
-#pragma unroll
-        for (int u = 0; u < kFastMaxSlices; ++u) pv[u] = u < S ? partial[(size_t)u * lvl + off] : 0.0;
-#pragma unroll
-        for (int u = 0; u < kFastMaxSlices; ++u)
-            if (u < S) anew = anew + pv[u];
     }
     a.A[(size_t)a.cur * lvl + off] = anew;
     {
@@ -304,23 +306,130 @@ __global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, cons
         reinterpret_cast<double *>(a.pos_next + my_i)[cc] = ynext;
     }
 }
+// thread per (component, body): the second launch of the two-launch form
+template <int L>
+__global__ void __launch_bounds__(256) k_fast_finish(const LmArgs a, int S, const double *__restrict__ partial) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int span = a.hi - a.lo;                               // the launch's bodies [lo, hi): all of them unless the handle is sharded
+    if (t >= 3 * span) return;
+    fast_finish_one<L, false>(a, S, partial, t / span, a.lo + t % span);     // consecutive threads = consecutive bodies: coalesced
+}
 
+// ONE launch per step (round 6): the workgroup that arrives LAST at a block of 64 targets combines the block's S slice sums, in
+// slice order, and does Cowell / sample / predictor for those bodies -- the same arithmetic in the same order as k_fast_finish, so
+// the result does not depend on which workgroup that is (tests/test_gpu_fast.py: bit-identical to the two-launch form and from run
+// to run). Inter-workgroup hand-off by the write-through recipe of MI355X_MICROARCH.md (splitk-seam / publish-large): the slice
+// sums leave as agent-scope (sc1) stores, every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE relaxed
+// agent-scope ticket per workgroup; the last arriver reads the sums with agent-scope (sc1) loads and puts the ticket back to 0 for
+// the next step. No agent-scope fence anywhere: round 2's single-launch form had one release fence (buffer_wbl2) per workgroup in
+// front of its ticket and they serialised (66 / 96 / 166 us per step at 16 / 32 / 64 slices).
+__device__ __forceinline__ void publish_slice(double *pp, size_t npad, double ax, double ay, double az) {
+    __hip_atomic_store(pp, ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pp + npad, ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pp + 2 * npad, az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores have left before the barrier
+}
+template <int L>
+__device__ __forceinline__ void arrive_and_finish(const LmArgs &a, int S, const double *partial, unsigned *tickets, int block,
+                                                  int wgs_per_block) {
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)(wgs_per_block - 1);
+        if (last) __hip_atomic_store(tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // every other arrival is in
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int t = threadIdx.x;                                  // 192 of the 256 threads: (component, body of the block)
+    const int my_i = block * 64 + (t & 63);
+    if (t < 192 && my_i >= a.lo && my_i < a.hi) fast_finish_one<L, true>(a, S, partial, t >> 6, my_i);
+}
+template <int UNROLL, bool APPROX, int L>
+__global__ void __launch_bounds__(64 * kFastWaves) k_fast_step(const LmArgs a, int S, int slice_len, double *__restrict__ partial,
+                                                               unsigned *__restrict__ tickets) {
+    const int n = a.n, npad = a.npad;
+    const Body4 *__restrict__ pos = a.pos_cur;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgs_per_block = S / kFastWaves;
+    const int block = blockIdx.x / wgs_per_block;
+    const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
+    const int i = block * 64 + lane;
+    const int ic = min(i, n - 1);
+    const auto *src = (const __attribute__((address_space(4))) Body4 *)(unsigned long long)pos;
+    const double xi = pos[ic].x, yi = pos[ic].y, zi = pos[ic].z;
+    const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (j0 < j1) {
+        const bool diag = j0 < block * 64 + 64 && j1 > block * 64;
+        if constexpr (APPROX) {
+            const bool pad = j1 > n;                    // wave-uniform
+            if (diag && pad) fast_slice_rsq<true, true, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else if (diag) fast_slice_rsq<true, false, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else if (pad) fast_slice_rsq<false, true, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else fast_slice_rsq<false, false, UNROLL>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        } else {
+            if (diag) fast_slice<true, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+            else fast_slice<false, UNROLL, APPROX>(src, j0, j1, n, i, xi, yi, zi, ax, ay, az);
+        }
+    }
+    publish_slice(partial + (size_t)slice * 3 * npad + i, (size_t)npad, ax, ay, az);
+    arrive_and_finish<L>(a, S, partial, tickets, block, wgs_per_block);
+}
+template <int L>
+__global__ void __launch_bounds__(64 * kFastWaves) k_fast_step_f32(const LmArgs a, const float *__restrict__ posf, int S, int slice_len,
+                                                                   double *__restrict__ partial, unsigned *__restrict__ tickets, int block0) {
+    const int n = a.n, npad = a.npad;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgs_per_block = S / kFastWaves;
+    const int block = block0 + blockIdx.x / wgs_per_block;
+    const int slice = (blockIdx.x % wgs_per_block) * kFastWaves + wave;
+    const int i = block * 64 + lane;
+    const int ic = min(i, n - 1);
+    const auto *src = (const __attribute__((address_space(4))) float *)(unsigned long long)posf;
+    const float *own = posf + (size_t)(ic >> 1) * 8 + (ic & 1);
+    const float xi = own[0], yi = own[2], zi = own[4];
+    const int j0 = slice * slice_len, j1 = min(j0 + slice_len, npad);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (j0 < j1) f32_slice(src, j0, j1, xi, yi, zi, ax, ay, az);
+    publish_slice(partial + (size_t)slice * 3 * npad + i, (size_t)npad, ax, ay, az);
+    arrive_and_finish<L>(a, S, partial, tickets, block, wgs_per_block);
+}
 
 // f32_stage (EPH_PATH_F32_PAIRS only): 0 = the whole step; 1 = only the binary32 copy of rows [conv_lo, conv_lo + conv_cnt) (a sharded
 // handle: its own rows, which it then all-gathers); 2 = the step on a copy that is already complete
 int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unroll, bool approx, float *posf, int f32_stage,
-                 int conv_lo, int conv_cnt) {
+                 int conv_lo, int conv_cnt, unsigned *tickets) {
     int slice_len = (a.npad + S - 1) / S;
     const int un = posf ? kF32Group : approx ? 4 : unroll;   // (8 sources per trip spill 149 SGPRs: the prefetched group is 64 of the 102)
     slice_len = (slice_len + un - 1) / un * un;
     const int block0 = a.lo / 64, nblocks = (a.hi - a.lo + 63) / 64;    // (a.lo is a multiple of 64 on a sharded handle, else 0)
     if (!posf && (a.lo != 0 || a.hi != a.n)) return EPH_ERR_UNSUPPORTED;
+    if (a.L != 12 && a.L != 13) return EPH_ERR_UNSUPPORTED;
     const dim3 pgrid((unsigned)(nblocks * (S / kFastWaves))), pblock(64 * kFastWaves);
+    const bool fused = tickets != nullptr;                              // one launch per step: the last workgroup of a block finishes it
     if (posf) {                                                         // EPH_PATH_F32_PAIRS
         if (f32_stage != 2 && conv_cnt > 0)
             hipLaunchKernelGGL(k_pos_to_f32, dim3((unsigned)((conv_cnt + 255) / 256)), dim3(256), 0, s, a.n, conv_lo, conv_cnt, a.pos_cur, posf);
         if (f32_stage == 1) return launched("k_pos_to_f32");
+        if (fused) {
+            if (a.L == 12) hipLaunchKernelGGL(k_fast_step_f32<12>, pgrid, pblock, 0, s, a, (const float *)posf, S, slice_len, partial, tickets, block0);
+            else hipLaunchKernelGGL(k_fast_step_f32<13>, pgrid, pblock, 0, s, a, (const float *)posf, S, slice_len, partial, tickets, block0);
+            return launched("k_fast_step_f32");
+        }
         hipLaunchKernelGGL(k_fast_partial_f32, pgrid, pblock, 0, s, a.n, a.npad, (const float *)posf, S, slice_len, partial, block0);
+    } else if (fused) {
+#define EPH_FAST_STEP(U, AP) \
+        do { if (a.L == 12) hipLaunchKernelGGL((k_fast_step<U, AP, 12>), pgrid, pblock, 0, s, a, S, slice_len, partial, tickets); \
+             else hipLaunchKernelGGL((k_fast_step<U, AP, 13>), pgrid, pblock, 0, s, a, S, slice_len, partial, tickets); } while (0)
+        if (approx) EPH_FAST_STEP(4, true);
+        else if (unroll == 8 && a.npad % 8 == 0) EPH_FAST_STEP(8, false);
+        else EPH_FAST_STEP(4, false);
+#undef EPH_FAST_STEP
+        return launched("k_fast_step");
     } else if (approx)
         hipLaunchKernelGGL((k_fast_partial<4, true>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     else if (unroll == 8 && a.npad % 8 == 0)
@@ -329,8 +438,7 @@ int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unr
         hipLaunchKernelGGL((k_fast_partial<4, false>), pgrid, pblock, 0, s, a.n, a.npad, a.pos_cur, S, slice_len, partial);
     const dim3 grid((3 * (a.hi - a.lo) + 255) / 256), block(256);
     if (a.L == 12) hipLaunchKernelGGL(k_fast_finish<12>, grid, block, 0, s, a, S, partial);
-    else if (a.L == 13) hipLaunchKernelGGL(k_fast_finish<13>, grid, block, 0, s, a, S, partial);
-    else return EPH_ERR_UNSUPPORTED;
+    else hipLaunchKernelGGL(k_fast_finish<13>, grid, block, 0, s, a, S, partial);
     return launched("k_fast_partial / k_fast_finish");
 }
 

@@ -273,7 +273,10 @@ int NBodyIntegration::lm_batch(int64_t k) {
     if (fast && (n_ <= kSmallN || (sharded() && path_ != EPH_PATH_F32_PAIRS))) return EPH_ERR_UNSUPPORTED;
     const bool f32_sharded = sharded() && path_ == EPH_PATH_F32_PAIRS;
     if (fast && !fast_partial_.p) {
-        if ((st = fast_partial_.alloc((size_t)fast_slices(npad_, true) * 3 * npad_))) return st;      // (the larger of the two slice counts)
+        if ((st = fast_partial_.alloc(fast_partial_doubles(npad_)))) return st;
+        // the arrival tickets of the one-launch step start at 0 (the last arriver of every block puts its ticket back)
+        const size_t toff = fast_ticket_offset_doubles(npad_);
+        EPH_HIP(hipMemsetAsync(fast_partial_.p + toff, 0, sizeof(double) * (fast_partial_doubles(npad_) - toff), stream_));
     }
     if (path_ == EPH_PATH_F32_PAIRS && !posf_.p) {
         if ((st = posf_.alloc((size_t)4 * npad_))) return st;

@@ -10,7 +10,7 @@ int lm_persistent(hipStream_t s, const LmArgs &a, int64_t nsteps);              
 int lm_small(hipStream_t s, const LmArgs &a, int64_t nsteps);                                              // step_small.hip
 int lm_small_many(hipStream_t s, const LmArgs *argv_dev, int count, int L, int64_t nsteps);                // step_small.hip
 int lm_step_fast(hipStream_t s, const LmArgs &a, double *partial, int S, int unroll, bool approx, float *posf, int f32_stage,
-                 int conv_lo, int conv_cnt);                                                                // fast.hip
+                 int conv_lo, int conv_cnt, unsigned *tickets);                                             // fast.hip
 int craft_launch(hipStream_t s, const CraftArgs &a, const CraftLaunch &how);                               // craft_sweep.hip
 int debug_inv_r3(hipStream_t s, int64_t n, const double *n2, double *fast, double *ieee);                  // step_wave.hip
 int debug_inv_r3_sweep(hipStream_t s, uint64_t seed, int64_t n, unsigned long long *out2);

@@ -179,3 +179,39 @@ def test_f32_pairs_bodies_coinciding_in_binary32(gpu):
     assert sum(together) >= 3, together               # (a pair can straddle a rounding boundary: 1e-9 against an ulp of 6e-8)
     assert np.isfinite(am).all() and np.isfinite(pm).all()
     assert np.abs(am - ae).max() / np.abs(ae).max() < 2e-5
+
+
+_FUSED_CHILD = """
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import ephemeris_explorer_amd as ea
+from ephemeris_explorer_amd.workloads import plummer
+out = []
+for n, path in ((4096, 4), (4096, 5), (5000, 4), (8192, 6), (1000, 5)):
+    pos, vel, mu = plummer(n)
+    g = ea.NBodyIntegration(pos, vel, mu, 0.0, 1.0 / 1024.0)
+    g.set_path(path)
+    g.advance(12 + 25)
+    p, v, t, c = g.state()
+    out.append(hashlib.sha256(p.tobytes() + v.tobytes() + g.acc().tobytes()).hexdigest())
+print(" ".join(out))
+"""
+
+
+def test_one_launch_step_equals_the_two_launch_form(gpu):
+    """Round 6: the fast paths' step is ONE launch -- the workgroup that arrives last at a block of 64 targets combines the block's
+    slice sums in slice order and does Cowell / predictor (k_fast_step; sc1 write-through stores, one relaxed agent-scope ticket per
+    workgroup, no fence). Same arithmetic in the same order as the two-launch form (k_fast_partial + k_fast_finish,
+    EPH_FAST_FUSED=0): bit-identical state after 25 steady steps for every fast path, twice (whichever workgroup arrives last)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    runs = {}
+    for fused in ("1", "0", "1"):
+        env = dict(os.environ, EPH_FAST_FUSED=fused)
+        r = subprocess.run([sys.executable, "-c", _FUSED_CHILD, str(ROOT)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.setdefault(fused, []).append(r.stdout.strip().split())
+    assert len(runs["1"][0]) == 5 and runs["1"][0] == runs["1"][1] == runs["0"][0]

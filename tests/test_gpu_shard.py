@@ -451,6 +451,26 @@ def test_f32_pairs_on_a_target_partition(gpu, n, world, transport, monkeypatch):
         assert gathers == 1 + (steps_f32 - 1)        # the batch's first prediction in f64 + the binary32 rows once per step
 
 
+def test_configs4_at_full_width_on_a_partition(gpu, monkeypatch):
+    """BASELINE configs[4] as stated, at its stated size: 65 536 bodies, binary32 pair arithmetic (EPH_PATH_F32_PAIRS) on a target
+    partition, two ranks (sharing this box's one GPU), direct peer writes into hipIpc-mapped mailboxes; the sharded start-up (302
+    exact force evaluations), 4 binary32 steps and one exact step afterwards, bit-identical to the single-device run of the same."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("EPH_PEER_TIMEOUT_MS", "20000")
+    n, world, steps_f32, steps_exact = 65536, 2, 4, 1
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_f32_worker, args=(world, _free_port(), n, steps_f32, steps_exact, out, "peer"), nprocs=world, join=True)
+    mid0, end0 = _single_f32(n, steps_f32, steps_exact)
+    assert set(out.keys()) == set(range(world))
+    for r in range(world):
+        mid, end, gathers, twin_ok = out[r]
+        for (st, a), (st0, a0), what in ((mid, mid0, "f32 leg"), (end, end0, "exact leg after it")):
+            assert st[2:] == st0[2:], what
+            assert np.array_equal(st[0], st0[0]) and np.array_equal(st[1], st0[1]) and np.array_equal(a, a0), (r, what)
+        assert twin_ok and gathers == 1 + (steps_f32 - 1)
+
+
 def test_f32_pairs_sharded_through_rccl(gpu):
     """the same through ncclAllGather (a one-rank communicator: the collective still runs on the 16-byte rows)"""
     import ephemeris_explorer_amd as ea

@@ -13,7 +13,15 @@ Answers, in this order:
   3. otherwise the closest trees, with how many of the printed values they reproduce and the largest distance in ulp.
 Separately: whether `acceleration_at::<false>` follows the same order as `acceleration_paired`, and how the platform's powf
 relates to the correctly rounded value the library's step-size controller uses (integration/src/runge_kutta/mod.rs:238-239).
-Pure Python; reads tests/golden/pair_probe.json."""
+Pure Python; reads tests/golden/pair_probe.json.
+
+The walk-through (on a machine that builds the reference; the choice moves positions by 1.2-2.4e-8 AU over 1e5 steps):
+  a. tools/pair_probe.py wrote tests/golden/pair_probe.json (64 operand pairs on which the seven orders give pairwise different
+     bits + 8 edge operands, with the expected bits per k; 256 operands of the controller's powf) and tools/particular_probe.rs, a
+     Rust test with the operands baked in that prints `pair i <6 words>` (acceleration_paired, nbody.rs:29), `at i <3 words>`
+     (acceleration_at::<false>, dynamics/spacecraft.rs:73) and `pow k i <word>` (err.powf(-1/k), runge_kutta/mod.rs:238-239);
+  b. cp tools/particular_probe.rs <reference>/ephemeris/tests/ ; cargo test -p ephemeris --test particular_probe -- --nocapture > printout.txt
+  c. python tools/identify_pair_variant.py printout.txt"""
 import json
 import sys
 from pathlib import Path
@@ -79,7 +87,7 @@ def main(argv):
     doc, ops = load_probe()
     if len(argv) == 3 and argv[1] == "--emulate":
         text = emulate(doc, int(argv[2]))
-    elif len(argv) == 2:
+    elif len(argv) == 2 and argv[1] not in ("-h", "--help"):
         text = Path(argv[1]).read_text()
     else:
         print(__doc__)
