@@ -266,7 +266,8 @@ def craft_main(args):
                 att_launch = attempts_local / nsweeps
                 out["roofline"]["traffic"] = tinfo["traffic_bytes_per_attempt"] * att_launch
                 out["roofline"]["traffic_source"] = (tinfo.get("source", "") + ": raw FETCH_SIZE + WRITE_SIZE per attempt x this launch's attempts "
-                                                     "(5-6 x the 56 B per accepted step: mostly the scratch stores of the 100 spilled VGPRs)")
+                                                     "(1.5 x the 56 B per accepted step since round 6 -- the stage derivatives' velocity halves live in LDS; round 5: "
+                                                     "5.9 x, the scratch stores of 100 spilled VGPRs)")
                 lane_ops = tinfo["valu_wave_insts_per_attempt"] * att_launch * 64.0 / launch_s
                 out["roofline"]["fp64"]["valu_issue"] = {
                     "achieved": lane_ops / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS / 2.0, "unit": "T lane-ops/s",
@@ -275,7 +276,8 @@ def craft_main(args):
                     "f64_wave_insts_per_attempt": tinfo.get("f64_wave_insts_per_attempt"),
                     "active_inst_valu_over_wave_cycles": tinfo.get("active_inst_valu_over_wave_cycles"),
                     "waves_per_simd": tinfo.get("waves_per_simd"), "vgpr_count": tinfo.get("vgpr_count"),
-                    "vgpr_spill_count": tinfo.get("vgpr_spill_count")}
+                    "vgpr_spill_count": tinfo.get("vgpr_spill_count"), "scratch_bytes_per_lane": tinfo.get("scratch_bytes_per_lane"),
+                    "lds_bytes_per_workgroup": tinfo.get("lds_bytes_per_workgroup")}
                 out["fp64"]["valu_issue"] = out["roofline"]["fp64"]["valu_issue"]
             elif not current:
                 out["roofline"]["traffic_stale"] = f"{tj.name} not used: {why}"

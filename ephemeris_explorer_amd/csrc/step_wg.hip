@@ -433,6 +433,9 @@ __global__ void __launch_bounds__(kWgThreads) k_accel_wg(int n, int npad, const 
 // this launch evaluates its acceleration (reference-order all-pairs sum), recovers its velocity (Cowell), stores the solout sample
 // if one is due, predicts the positions of the NEXT level and publishes them (ring + packed ping-pong buffer) -- the kernel
 // boundary is the only grid-wide synchronisation a step needs.
+// (amdgpu_waves_per_eu(3, 3): for the twelve-wave forms it restates what __launch_bounds__(768) already implies -- three waves per
+// SIMD, 168 VGPRs -- and changes nothing in their code; for the six-wave DUO form it is a choice (its 1.5 waves per SIMD would
+// allow 256 VGPRs): that form was measured WITH it (17.7 against 18.6 us at 2048 bodies, round 5) and ships as measured.)
 template <int L, int WB = kWgBodies, bool DUO = false>
 __global__ void __launch_bounds__(DUO ? kDuoThreads : kWgThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_lm_step_wg(const LmArgs a) {

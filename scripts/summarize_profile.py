@@ -28,6 +28,38 @@ def keep_measurement_commit(path, new):
     return new
 
 from ephemeris_explorer_amd.workloads import profile_stamp      # sha256 of the kernel sources a counter file was taken with
+
+
+def craft_code_object():
+    """registers / spills / scratch / LDS / occupancy of the 13-stage sweep kernels as THIS tree compiles them (order 0):
+    hipcc -Rpass-analysis=kernel-resource-usage on csrc/craft_sweep.hip"""
+    import re
+    import subprocess
+    from ephemeris_explorer_amd import build as b
+    cmd = [b.hipcc(), *b.FLAGS, "-DEPH_PAIR_VARIANT=0", "-x", "hip", "--offload-device-only", "-c", str(b.CSRC / "craft_sweep.hip"),
+           "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    text = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    out = {"source": "hipcc -Rpass-analysis=kernel-resource-usage of csrc/craft_sweep.hip (order 0) at summarize time"}
+    want = {"17k_craft_propagateILi13ELb0ELb0ELi2EE": "k_craft_propagate<13,false,false,2>",
+            "17k_craft_propagateILi13ELb0ELb0ELi1EE": "k_craft_propagate<13,false,false,1>",
+            "13k_craft_queueILi13ELb0ELb0EE": "k_craft_queue<13,false,false>"}
+    cur = None
+    for ln in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            cur = next((v for k, v in want.items() if k in m.group(1)), None)
+            if cur:
+                out[cur] = {}
+            continue
+        if cur:
+            for key, name in (("VGPRs:", "vgpr_count"), ("VGPRs Spill:", "vgpr_spill_count"), ("TotalSGPRs:", "sgpr_count"),
+                              ("SGPRs Spill:", "sgpr_spill_count"), ("ScratchSize [bytes/lane]:", "scratch_bytes_per_lane"),
+                              ("Occupancy [waves/SIMD]:", "waves_per_simd"), ("LDS Size [bytes/block]:", "lds_bytes_per_workgroup")):
+                m = re.search(re.escape(key) + r"\s+(\d+)", ln)
+                if m and " " + key in " " + ln.split("remark:")[-1].strip()[: len(key) + 1]:
+                    out[cur][name] = int(m.group(1))
+    return out
+
 tag = sys.argv[1]
 src = ROOT / "gpurun_out" / tag
 dst = ROOT / "profiles"
@@ -62,10 +94,8 @@ if craft.exists():
         derived.update({"attempts": att, "valu_wave_insts_per_body_term": c["SQ_INSTS_VALU"] / terms,
                         "f64_wave_insts_per_body_term": f64 / terms,
                         "write_bytes_per_accepted_step": derived["write_bytes_raw"] / float(b.get("accepted_steps", att))})
-    code_object = {"k_craft_propagate<13,false,false,2>": {"vgpr_count": 256, "vgpr_spill_count": 100, "sgpr_count": 106,
-                                                           "scratch_bytes_per_lane": 384, "waves_per_simd": 2},
-                   "k_craft_propagate<13,false,false,1>": {"vgpr_count": 340, "vgpr_spill_count": 0, "waves_per_simd": 1},
-                   "source": "hipcc -S --cuda-device-only of csrc/craft_sweep.hip (order 0), .amdgpu_metadata"}
+    code_object = craft_code_object()
+    co2 = code_object.get("k_craft_propagate<13,false,false,2>", {})
     (dst / f"{tag}_craft_pmc.json").write_text(json.dumps({
         "command": f"scripts/prof_craft.sh {tag}: scripts/bench_craft.py {b.get('n_craft')} {b.get('days')} under rocprofv3 --kernel-include-regex k_craft, "
                    "one --pmc pass per line of the script (FETCH_SIZE and WRITE_SIZE in passes of their own)",
@@ -78,7 +108,8 @@ if craft.exists():
         "valu_wave_insts_per_attempt": c["SQ_INSTS_VALU"] / att if att else None,
         "f64_wave_insts_per_attempt": f64 / att if att else None,
         "active_inst_valu_over_wave_cycles": derived["active_inst_valu_over_wave_cycles"],
-        "waves_per_simd": 2, "vgpr_count": 256, "vgpr_spill_count": 100,
+        "waves_per_simd": co2.get("waves_per_simd", 2), "vgpr_count": co2.get("vgpr_count"), "vgpr_spill_count": co2.get("vgpr_spill_count"),
+        "scratch_bytes_per_lane": co2.get("scratch_bytes_per_lane"), "lds_bytes_per_workgroup": co2.get("lds_bytes_per_workgroup"),
         "avg_ns_kernel_trace": ns, **profile_stamp("craft")}), indent=1) + "\n")
     print(json.dumps(derived, indent=1))
 
