@@ -40,7 +40,9 @@ __global__ void k_body_reciprocals(int n, BodyEntry *bodies) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
     const double iv = bodies[b].interval;
-    bodies[b].rinv = in_range_div(iv) ? rcp_refined(iv) : 0.0;
+    // +0.0 = "take the plain IEEE lookup": the interval outside the guarded range of the shared-reciprocal division, or more than
+    // 2^31 - 1 segments (the sweep's speculative lookup converts the segment count in 32 bits)
+    bodies[b].rinv = in_range_div(iv) && (unsigned long long)bodies[b].npoly < 0x80000000ull ? rcp_refined(iv) : 0.0;
 }
 
 __global__ void k_debug_div(long long n, const double *__restrict__ a, const double *__restrict__ b,
@@ -986,7 +988,7 @@ static int eph_upload_bodies(eph_ephemeris *e) {
         be.start = u.start; be.interval = u.interval; be.mu = e->gm[(size_t)b];
         be.npoly = (long long)u.polynomials.size();
         be.span = u.interval * (double)u.polynomials.size();     // interval.scaled(len): the product UniformSpline::span() forms
-        be.rinv = 0.0; be.pad_ = 0.0;
+        be.rinv = 0.0; be.rows = e->coeffs.p + (size_t)be.coeff_off * kDiv * 3;
     }
     if (!nb) return EPH_OK;
     EPH_HIP(hipMemcpy(e->bodies.p, e->host_bodies.data(), sizeof(BodyEntry) * (size_t)nb, hipMemcpyHostToDevice));

@@ -18,7 +18,9 @@ struct BodyEntry {            // one massive body's UniformSpline on the device
     long long coeff_off;      // index of polynomial 0 in the coefficient / ncoef arrays
     double span;              // interval * (double)npoly, the product UniformSpline::span() forms on every lookup
     double rinv;              // rcp_refined(interval), filled on the device (k_body_reciprocals); +0.0 = the interval is out of
-    double pad_;              //   range for the wrapper-free division (pair_term.h in_range_div): use the compiler's
+                              //   range for the wrapper-free division (pair_term.h in_range_div): use the compiler's
+    const double *rows;       // device address of polynomial 0's coefficient row (= coeffs + coeff_off * 24): the sweep's body loop forms a
+                              //   row address from the entry alone (no table base to keep in SGPRs, half the scalar address arithmetic)
 };
 struct SegmentDev {           // Segment<DVec3, ReferenceFrame>
     double start, end;

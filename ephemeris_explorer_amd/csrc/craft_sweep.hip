@@ -138,7 +138,7 @@ __device__ __forceinline__ BodyEntry entry_uniform(const BodyEntry *table, int b
     const auto *bc = (const __attribute__((address_space(4))) BodyEntry *)(unsigned long long)(table + bu);
     BodyEntry be;
     be.start = bc->start; be.interval = bc->interval; be.mu = bc->mu; be.npoly = bc->npoly;
-    be.coeff_off = bc->coeff_off; be.span = bc->span; be.rinv = bc->rinv; be.pad_ = 0.0;
+    be.coeff_off = bc->coeff_off; be.span = bc->span; be.rinv = bc->rinv; be.rows = bc->rows;
     return be;
 }
 __device__ __forceinline__ long long uniform64(long long v) {
@@ -156,13 +156,13 @@ struct RowS { double c[kDiv * 3]; };                  // one polynomial's 24 coe
 #define EPH_CRAFT_ROW_SPLIT 0
 #endif
 constexpr int kRowLo = EPH_CRAFT_ROW_SPLIT ? 8 : 0;   // coefficients [0, kRowLo) are loaded late
-__device__ __forceinline__ void row_uniform_hi(const double *coeffs, long long row0, RowS &r) {
-    const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(coeffs + row0 * kDiv * 3);
+__device__ __forceinline__ void row_uniform_hi(const double *rows, unsigned i0, RowS &r) {
+    const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(rows + (size_t)i0 * (kDiv * 3));
 #pragma unroll
     for (int k = kRowLo; k < kDiv * 3; ++k) r.c[k] = cs[k];
 }
-__device__ __forceinline__ void row_uniform_lo(const double *coeffs, long long row0, RowS &r) {
-    const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(coeffs + row0 * kDiv * 3);
+__device__ __forceinline__ void row_uniform_lo(const double *rows, unsigned i0, RowS &r) {
+    const auto *cs = (const __attribute__((address_space(4))) double *)(unsigned long long)(rows + (size_t)i0 * (kDiv * 3));
 #pragma unroll
     for (int k = 0; k < kRowLo; ++k) r.c[k] = cs[k];
 }
@@ -197,9 +197,9 @@ __device__ __forceinline__ bool locate_spec(const BodyEntry &b, double at, doubl
     // (bitwise, not &&: a short-circuit chain becomes divergent control flow and cuts the block the lookup shares with the term)
     return (max(div_key(local), div_key(rem)) < 0x19000000u) & !(local > b.span) & (i32 < (unsigned)b.npoly);
 }
-__device__ __forceinline__ bool entry_fast(const BodyEntry &b) {          // wave-uniform: scalar compares
-    return (__double_as_longlong(b.rinv) != 0) & ((unsigned long long)b.npoly < 0x80000000ull);
-}
+// wave-uniform, one scalar compare: the entry's refined reciprocal is +0.0 unless the interval is in the guarded range of the
+// shared-reciprocal division AND the segment count fits 31 bits (k_body_reciprocals); a nonzero one is a normal number
+__device__ __forceinline__ bool entry_fast(const BodyEntry &b) { return __double2hiint(b.rinv) != 0; }
 // the out-of-line IEEE path (cold): UniformSpline::get_polynomial + eval with the compiler's divisions, per-lane coefficient loads
 struct BodyPos { double x, y, z; int located; };
 // (reads the table entry itself: the hot loop then keeps nothing of an entry alive for this call's sake)
@@ -227,9 +227,11 @@ __device__ __noinline__ V3 pair_generic(double n2, double dx, double dy, double 
 __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t, const V3 &pos, V3 &acc) {
     const int nb = a.n_bodies;
     if (nb <= 0) return true;
-    // A lane outside a body's spline (EvalFailed) does NOT leave the loop: it is flagged, kept out of the ballots and carries
-    // harmless numbers to the end. A divergent exit would make every loop-carried value divergent in the compiler's eyes -- table
-    // entries and coefficient rows in VGPRs, per-lane loads -- although they are the same for every lane.
+    // A lane outside a body's spline (EvalFailed) does NOT leave the loop: it is flagged and carries harmless numbers to the end (a
+    // divergent exit would make every loop-carried value divergent in the compiler's eyes -- table entries and coefficient rows in
+    // VGPRs, per-lane loads -- although they are the same for every lane). It stays IN the ballots: where its numbers fail a test the
+    // wave takes the out-of-line IEEE path for that body, which gives the other lanes the same bits -- a slow last evaluation for a
+    // wave that holds a failing craft, three scalar operations less per term for everybody else.
     bool failed = false;
     // prologue: body 0's entry, lookup and the high part of its row
     BodyEntry be = entry_uniform(a.bodies, 0);
@@ -238,27 +240,26 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
     bool good = locate_spec(be, t, tau, idx);
     bool all_good = entry_fast(be) & (__builtin_amdgcn_ballot_w64(!good) == 0);                         // wave-uniform
     unsigned i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx) & -(unsigned)all_good;            // (branch-free: row 0 of a body is always a valid address)
-    long long row0 = be.coeff_off + (long long)i0;
+    const double *rows = be.rows;                     // (a row address from the entry alone: no table base in the loop)
     RowS cs;
-    row_uniform_hi(a.coeffs, row0, cs);
+    row_uniform_hi(rows, i0, cs);
     for (int b = 0; b < nb; ++b) {
         // ---- P(b): the body's position at t
-        row_uniform_lo(a.coeffs, row0, cs);
-        const long long off = be.coeff_off;
+        row_uniform_lo(rows, i0, cs);
         V3 bp;
         if (__builtin_expect(all_good, 1)) {
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!failed & (idx != i0)) == 0, 1)) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(idx != i0) == 0, 1)) {
                 bp = horner_row(cs, tau);             // every lane inside the SAME polynomial (craft of one sweep started together)
             } else {
-                bool pending = !failed;               // one pass per distinct polynomial, first the prefetched one
+                bool pending = true;                  // one pass per distinct polynomial, first the prefetched one
                 bp = V3{0.0, 0.0, 0.0};
                 for (;;) {
                     if (pending & (idx == i0)) { bp = horner_row(cs, tau); pending = false; }
                     const unsigned long long left = __builtin_amdgcn_ballot_w64(pending);
                     if (left == 0) break;
                     i0 = (unsigned)__builtin_amdgcn_readlane((int)idx, __builtin_ctzll(left));
-                    row_uniform_hi(a.coeffs, off + (long long)i0, cs);
-                    row_uniform_lo(a.coeffs, off + (long long)i0, cs);
+                    row_uniform_hi(rows, i0, cs);
+                    row_uniform_lo(rows, i0, cs);
                 }
             }
         } else {
@@ -272,21 +273,23 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
         const V3 d = sub(bp, pos);                    // acceleration_at::<false>: dir = body - at
         const double n2 = dot(d, d);
         const bool more = b + 1 < nb;
+        // (the last body's block looks up entry 0 once more and discards it: a lookup behind `if (more)` was measured -- the branch
+        // cuts the block in three, the lookup no longer overlaps the term and the allocation changes: 40.5 against 29.2 ms)
         be = entry_uniform(a.bodies, more ? b + 1 : 0);      // (one entry in SGPRs at a time: its latency hides under body b's term)
         good = locate_spec(be, t, tau, idx);
         // the point-mass term in the build's evaluation order, IEEE sqrt and divide (pair_term.h): the wrapper-free sequences for
         // every lane; a squared distance outside the guarded range anywhere in the wave sends it through the compiler's expansions
         const PairDen den = pair_den<true>(n2);
-        all_good = more & entry_fast(be) & (__builtin_amdgcn_ballot_w64(!failed & !good) == 0);
+        all_good = more & entry_fast(be) & (__builtin_amdgcn_ballot_w64(!good) == 0);
         i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx) & -(unsigned)all_good;
-        row0 = be.coeff_off + (long long)i0;
-        row_uniform_hi(a.coeffs, row0, cs);
+        rows = be.rows;
+        row_uniform_hi(rows, i0, cs);
         V3 term;
         pair_apply<true>(den, d.x, d.y, d.z, mu, term.x, term.y, term.z);
         // (the empty asm keeps the straight-line term IN this block, beside the lookup of the next body: two independent chains; without
         // it the compiler sinks the term behind the range test into a block of its own)
         asm volatile("" : "+v"(term.x), "+v"(term.y), "+v"(term.z));
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!failed & !in_range(n2)) != 0, 0)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!in_range(n2)) != 0, 0)) {
             asm volatile("");
             term = pair_generic(n2, d.x, d.y, d.z, mu);
         }
