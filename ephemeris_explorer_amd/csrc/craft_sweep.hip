@@ -179,14 +179,16 @@ __device__ __forceinline__ V3 horner_row(const RowS &r, double tau) {
     return bp;
 }
 // UniformSpline::get_polynomial, speculatively: spline_locate_fast with every guarded choice assumed (shared reciprocal for both
-// quotients, 32-bit segment count). Straight-line; returns whether THIS lane's assumptions hold and it is inside the spline. When
-// they hold for the whole wave (and the entry passes entry_fast), tau and idx are spline_locate_fast's. The tests are folded: both
+// quotients, 32-bit segment count). Straight-line. When every lane's assumptions hold and it is inside the spline (and the entry
+// passes entry_fast), tau and idx are spline_locate_fast's. The tests are folded: both
 // numerators in the guarded range of the shared-reciprocal division (one max over their range keys; a negative, zero or NaN `local`
 // has a key outside it, so the sign test is implied -- t == start exactly, where local = rem = +0 is a legal numerator, takes the
 // out-of-line path), not beyond the span, and the segment inside the table (which also catches a count that was clamped at 2^31:
 // entry_fast requires npoly < 2^31).
 __device__ __forceinline__ unsigned div_key(double x) { return (unsigned)(__double2hiint(x) - 0x33700000); }    // in_range_div: key < 0x19000000
-__device__ __forceinline__ bool locate_spec(const BodyEntry &b, double at, double &tau, unsigned &idx) {
+// Returns the wave's ballot of lanes for which an assumption does NOT hold (0 = every lane fine), as the OR of one ballot per test: a
+// ballot of a single compare is the compare's own result mask, a ballot of a combined per-lane flag costs a select and a second compare.
+__device__ __forceinline__ unsigned long long locate_spec(const BodyEntry &b, double at, double &tau, unsigned &idx) {
     const double local = at - b.start;
     const double c = ceil(div_refined(local, b.interval, b.rinv));
     const unsigned ci = (unsigned)fmin(fmax(c, 0.0), 2147483648.0);       // c <= 0 (and NaN) -> 0, as `c <= 0.0 ? 0u : (unsigned)c`
@@ -194,8 +196,8 @@ __device__ __forceinline__ bool locate_spec(const BodyEntry &b, double at, doubl
     const double rem = local - b.interval * (double)i32;
     tau = div_refined(rem, b.interval, b.rinv);
     idx = i32;
-    // (bitwise, not &&: a short-circuit chain becomes divergent control flow and cuts the block the lookup shares with the term)
-    return (max(div_key(local), div_key(rem)) < 0x19000000u) & !(local > b.span) & (i32 < (unsigned)b.npoly);
+    return __builtin_amdgcn_ballot_w64(max(div_key(local), div_key(rem)) >= 0x19000000u) | __builtin_amdgcn_ballot_w64(local > b.span) |
+           __builtin_amdgcn_ballot_w64(i32 >= (unsigned)b.npoly);
 }
 // wave-uniform, one scalar compare: the entry's refined reciprocal is +0.0 unless the interval is in the guarded range of the
 // shared-reciprocal division AND the segment count fits 31 bits (k_body_reciprocals); a nonzero one is a normal number
@@ -237,8 +239,8 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
     BodyEntry be = entry_uniform(a.bodies, 0);
     double tau;
     unsigned idx;
-    bool good = locate_spec(be, t, tau, idx);
-    bool all_good = entry_fast(be) & (__builtin_amdgcn_ballot_w64(!good) == 0);                         // wave-uniform
+    unsigned long long bad = locate_spec(be, t, tau, idx);
+    bool all_good = entry_fast(be) & (bad == 0);                                                        // wave-uniform
     unsigned i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx) & -(unsigned)all_good;            // (branch-free: row 0 of a body is always a valid address)
     const double *rows = be.rows;                     // (a row address from the entry alone: no table base in the loop)
     RowS cs;
@@ -276,11 +278,11 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
         // (the last body's block looks up entry 0 once more and discards it: a lookup behind `if (more)` was measured -- the branch
         // cuts the block in three, the lookup no longer overlaps the term and the allocation changes: 40.5 against 29.2 ms)
         be = entry_uniform(a.bodies, more ? b + 1 : 0);      // (one entry in SGPRs at a time: its latency hides under body b's term)
-        good = locate_spec(be, t, tau, idx);
+        bad = locate_spec(be, t, tau, idx);
         // the point-mass term in the build's evaluation order, IEEE sqrt and divide (pair_term.h): the wrapper-free sequences for
         // every lane; a squared distance outside the guarded range anywhere in the wave sends it through the compiler's expansions
         const PairDen den = pair_den<true>(n2);
-        all_good = more & entry_fast(be) & (__builtin_amdgcn_ballot_w64(!good) == 0);
+        all_good = more & entry_fast(be) & (bad == 0);
         i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx) & -(unsigned)all_good;
         rows = be.rows;
         row_uniform_hi(rows, i0, cs);
