@@ -221,6 +221,22 @@ __device__ __noinline__ BodyPos body_position_generic(const double *coeffs, cons
     }
     return BodyPos{bp.x, bp.y, bp.z, 1};
 }
+// Horner with PER-LANE coefficient loads (cold): the lanes of a wave that are inside many different polynomials of one body -- craft
+// whose epochs have drifted far apart (an undealt heterogeneous batch in the work-queue kernel: lanes pick up new craft at any time)
+__device__ __noinline__ V3 horner_lane_rows(const double *rows, unsigned idx, double tau) {
+    const double2 *co = reinterpret_cast<const double2 *>(rows + (size_t)idx * (kDiv * 3));
+    double c[kDiv * 3];
+#pragma unroll
+    for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
+    V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + c[k * 3 + 0];
+        bp.y = bp.y * tau + c[k * 3 + 1];
+        bp.z = bp.z * tau + c[k * 3 + 2];
+    }
+    return bp;
+}
 __device__ __noinline__ V3 pair_generic(double n2, double dx, double dy, double dz, double mu) {
     V3 term;
     pair_apply<false>(pair_den<false>(n2), dx, dy, dz, mu, term.x, term.y, term.z);
@@ -253,12 +269,20 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(idx != i0) == 0, 1)) {
                 bp = horner_row(cs, tau);             // every lane inside the SAME polynomial (craft of one sweep started together)
             } else {
-                bool pending = true;                  // one pass per distinct polynomial, first the prefetched one
+                // one pass per distinct polynomial, first the prefetched one (rows still through the scalar cache); lanes that are
+                // left after kWaterfallPasses take per-lane loads, out of line -- a wave of the work-queue kernel can hold 64 craft
+                // at 64 epochs (measured on the undealt mixed population: 1010 ms per sweep with an unbounded waterfall, 350 before)
+                constexpr int kWaterfallPasses = 2;
+                bool pending = true;
                 bp = V3{0.0, 0.0, 0.0};
-                for (;;) {
+                for (int pass = 0;; ++pass) {
                     if (pending & (idx == i0)) { bp = horner_row(cs, tau); pending = false; }
                     const unsigned long long left = __builtin_amdgcn_ballot_w64(pending);
                     if (left == 0) break;
+                    if (pass + 1 == kWaterfallPasses) {
+                        if (pending) bp = horner_lane_rows(rows, idx, tau);
+                        break;
+                    }
                     i0 = (unsigned)__builtin_amdgcn_readlane((int)idx, __builtin_ctzll(left));
                     row_uniform_hi(rows, i0, cs);
                     row_uniform_lo(rows, i0, cs);
@@ -277,7 +301,9 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
         const bool more = b + 1 < nb;
         // (the last body's block looks up entry 0 once more and discards it: a lookup behind `if (more)` was measured -- the branch
         // cuts the block in three, the lookup no longer overlaps the term and the allocation changes: 40.5 against 29.2 ms)
-        be = entry_uniform(a.bodies, more ? b + 1 : 0);      // (one entry in SGPRs at a time: its latency hides under body b's term)
+        // (ONE entry in SGPRs at a time, its latency under body b's term; requested a body earlier -- before Horner -- the second entry
+        // costs the row its registers: 32.4 against 27.5 ms)
+        be = entry_uniform(a.bodies, more ? b + 1 : 0);
         bad = locate_spec(be, t, tau, idx);
         // the point-mass term in the build's evaluation order, IEEE sqrt and divide (pair_term.h): the wrapper-free sequences for
         // every lane; a squared distance outside the guarded range anywhere in the wave sends it through the compiler's expansions
