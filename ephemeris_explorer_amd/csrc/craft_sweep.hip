@@ -122,8 +122,8 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {
 // guarded fast path its own block, laid out behind the slow ones) and one dependent chain at a time; inlined thirteen times it was
 // 82 KB of code for the 13-stage pair -- more than the instruction cache. Now, per body b:
 //   P(b)  Horner over the coefficient row that was PREFETCHED into SGPRs while body b-1's term was computed (three independent
-//         chains); lanes inside different polynomials (a long sweep's craft drift apart in time) take the rows one after the other
-//         (waterfall: one pass per distinct row, rows still through the scalar cache);
+//         chains); lanes inside OTHER polynomials than the first lane's (a long sweep's craft drift apart in time) load their own rows,
+//         out of line;
 //   R(b)  difference and squared distance, the point-mass term of body b -- one dependent chain -- TOGETHER WITH the segment lookup
 //         of body b+1 (a second, independent chain) in ONE basic block; the table entry and the row of body b+1 are requested here
 //         and arrive under the term's arithmetic.
@@ -269,24 +269,12 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(idx != i0) == 0, 1)) {
                 bp = horner_row(cs, tau);             // every lane inside the SAME polynomial (craft of one sweep started together)
             } else {
-                // one pass per distinct polynomial, first the prefetched one (rows still through the scalar cache); lanes that are
-                // left after kWaterfallPasses take per-lane loads, out of line -- a wave of the work-queue kernel can hold 64 craft
-                // at 64 epochs (measured on the undealt mixed population: 1010 ms per sweep with an unbounded waterfall, 350 before)
-                constexpr int kWaterfallPasses = 2;
-                bool pending = true;
-                bp = V3{0.0, 0.0, 0.0};
-                for (int pass = 0;; ++pass) {
-                    if (pending & (idx == i0)) { bp = horner_row(cs, tau); pending = false; }
-                    const unsigned long long left = __builtin_amdgcn_ballot_w64(pending);
-                    if (left == 0) break;
-                    if (pass + 1 == kWaterfallPasses) {
-                        if (pending) bp = horner_lane_rows(rows, idx, tau);
-                        break;
-                    }
-                    i0 = (unsigned)__builtin_amdgcn_readlane((int)idx, __builtin_ctzll(left));
-                    row_uniform_hi(rows, i0, cs);
-                    row_uniform_lo(rows, i0, cs);
-                }
+                // the lanes inside the prefetched polynomial take it from the SGPRs; the others load their own rows, out of line.
+                // (A waterfall -- one scalar-cache pass per distinct polynomial -- was measured: unbounded it costs the work-queue
+                // kernel, whose waves can hold 64 craft at 64 epochs, a factor of three on the undealt mixed population (1010 ms per
+                // sweep; round 4: 350); bounded to 3 / 2 / 1 passes 413 / 370 / 329 ms, the dealt sweeps unchanged by the bound.)
+                bp = horner_row(cs, tau);
+                if (idx != i0) bp = horner_lane_rows(rows, idx, tau);
             }
         } else {
             asm volatile("");
