@@ -315,6 +315,58 @@ __device__ __forceinline__ bool bodies_acceleration(const CraftArgs &a, double t
 }
 constexpr int kRedRow = kTile + 2;                    // LDS row of the wave variant's contribution tile
 
+// The manoeuvre's acceleration in its frame (ConstantThrust in ReferenceFrame::Relative(body) -> TNB of (craft - body), or inertial):
+// ephemeris/src/propagators/spacecraft.rs:319-331, ephemeris_explorer/src/dynamics/spacecraft.rs:240-293. false = EvalFailed.
+__device__ __forceinline__ bool burn_acceleration(const BodyEntry *bodies_by_index, const double *coeffs, const int *ncoef, int ref, double ax,
+                                                  double ay, double az, double t, const V3 &pos, const V3 &vel, V3 &man) {
+    const V3 thrust = {ax, ay, az};
+    if (ref >= 0) {                                   // ReferenceFrame::Relative -> TNB::try_new(sv - ref.state_vector(t))
+        const BodyEntry be = bodies_by_index[ref];
+        long long idx;
+        double tau;
+        if (!spline_locate(be, t, idx, tau)) return false;
+        const double *co = coeffs + (be.coeff_off + idx) * kDiv * 3;
+        const int nc = ncoef[be.coeff_off + idx];
+        double rp[3], rv[3];
+        for (int c = 0; c < 3; ++c) {                 // Polynomial::eval_and_deriv
+            const double first = nc ? co[c] : 0.0;
+            const double last = nc ? co[(nc - 1) * 3 + c] : 0.0;
+            double e = last, d = last;
+            for (int k = nc - 2; k >= 1; --k) {
+                e = e * tau + co[k * 3 + c];
+                d = d * tau + e;
+            }
+            e = e * tau + first;
+            rp[c] = e;
+            rv[c] = d / be.interval;
+        }
+        const V3 rel_p = sub(pos, V3{rp[0], rp[1], rp[2]}), rel_v = sub(vel, V3{rv[0], rv[1], rv[2]});
+        V3 x, yv;
+        if (!try_normalize(rel_v, x)) return false;
+        if (!try_normalize(cross(rel_p, rel_v), yv)) return false;
+        const V3 xy = cross(x, yv);
+        const V3 z = scale(xy, length_recip(xy));
+        V3 r = scale(x, thrust.x);                    // DMat3::from_cols(x, z, y).mul_vec3(thrust)
+        r = add(r, scale(z, thrust.y));
+        r = add(r, scale(yv, thrust.z));
+        man = r;
+    } else {                                          // TNB::IDENTITY.mul_vec3(thrust)
+        V3 r = scale(V3{1.0, 0.0, 0.0}, thrust.x);
+        r = add(r, scale(V3{0.0, 1.0, 0.0}, thrust.y));
+        r = add(r, scale(V3{0.0, 0.0, 1.0}, thrust.z));
+        man = r;
+    }
+    return true;
+}
+struct BurnAcc { double x, y, z; int ok; };
+__device__ __noinline__ BurnAcc burn_acceleration_cold(const BodyEntry *bodies_by_index, const double *coeffs, const int *ncoef, int ref,
+                                                       double ax, double ay, double az, double t, double px, double py, double pz, double vx,
+                                                       double vy, double vz) {
+    V3 man = {0.0, 0.0, 0.0};
+    const bool ok = burn_acceleration(bodies_by_index, coeffs, ncoef, ref, ax, ay, az, t, V3{px, py, pz}, V3{vx, vy, vz}, man);
+    return BurnAcc{man.x, man.y, man.z, ok ? 1 : 0};
+}
+
 // FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.
 // WAVE = false: one thread per spacecraft, the bodies in a loop. WAVE = true: one WAVE per spacecraft (every lane
 // carries the same craft state): lane b evaluates body b, the terms go through LDS and lanes 0..2 add them in body
@@ -370,42 +422,16 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
     }
     V3 man = {0.0, 0.0, 0.0};
     if (sg.is_burn) {
-        const V3 thrust = {sg.ax, sg.ay, sg.az};
-        if (sg.ref >= 0) {                            // ReferenceFrame::Relative -> TNB::try_new(sv - ref.state_vector(t))
-            const BodyEntry be = a.bodies_by_index[sg.ref];
-            long long idx;
-            double tau;
-            if (!spline_locate(be, t, idx, tau)) return false;
-            const double *co = a.coeffs + (be.coeff_off + idx) * kDiv * 3;
-            const int nc = a.ncoef[be.coeff_off + idx];
-            double rp[3], rv[3];
-            for (int c = 0; c < 3; ++c) {             // Polynomial::eval_and_deriv
-                const double first = nc ? co[c] : 0.0;
-                const double last = nc ? co[(nc - 1) * 3 + c] : 0.0;
-                double e = last, d = last;
-                for (int k = nc - 2; k >= 1; --k) {
-                    e = e * tau + co[k * 3 + c];
-                    d = d * tau + e;
-                }
-                e = e * tau + first;
-                rp[c] = e;
-                rv[c] = d / be.interval;
-            }
-            const V3 rel_p = sub(pos, V3{rp[0], rp[1], rp[2]}), rel_v = sub(vel, V3{rv[0], rv[1], rv[2]});
-            V3 x, yv;
-            if (!try_normalize(rel_v, x)) return false;
-            if (!try_normalize(cross(rel_p, rel_v), yv)) return false;
-            const V3 xy = cross(x, yv);
-            const V3 z = scale(xy, length_recip(xy));
-            V3 r = scale(x, thrust.x);                // DMat3::from_cols(x, z, y).mul_vec3(thrust)
-            r = add(r, scale(z, thrust.y));
-            r = add(r, scale(yv, thrust.z));
-            man = r;
-        } else {                                      // TNB::IDENTITY.mul_vec3(thrust)
-            V3 r = scale(V3{1.0, 0.0, 0.0}, thrust.x);
-            r = add(r, scale(V3{0.0, 1.0, 0.0}, thrust.y));
-            r = add(r, scale(V3{0.0, 0.0, 1.0}, thrust.z));
-            man = r;
+        // (thread-per-craft kernels: out of line -- the frame arithmetic with its three IEEE reciprocal square roots, inlined once per
+        // stage, was 33 of the 13-stage kernel's 81 KB of code, and burns are minutes of a sweep's days. No measurable difference on
+        // a sweep without burns: 25.5-25.6 against 25.6-25.7 ms -- the instruction cache was not the limit.)
+        if (WAVE) {
+            if (!burn_acceleration(a.bodies_by_index, a.coeffs, a.ncoef, sg.ref, sg.ax, sg.ay, sg.az, t, pos, vel, man)) return false;
+        } else {
+            const BurnAcc r = burn_acceleration_cold(a.bodies_by_index, a.coeffs, a.ncoef, sg.ref, sg.ax, sg.ay, sg.az, t, pos.x, pos.y, pos.z,
+                                                     vel.x, vel.y, vel.z);
+            if (!r.ok) return false;
+            man = V3{r.x, r.y, r.z};
         }
     }
     const V3 tot = add(acc, man);
