@@ -168,10 +168,13 @@ __device__ __forceinline__ void row_uniform_lo(const double *rows, unsigned i0, 
 }
 // eval_slice_horner over all kDiv rows: rows >= ncoef are +0.0 in the device table (eph_ephemeris_create), so the leading steps give
 // 0*tau + 0 = +0, the state the reference's Horner starts from -- same bits, no ncoef load, no loop
+// ... and the first step without its product: the reference starts from T::default() = +0 (trajectory.rs:404-407), and (+0) * tau is +0
+// for every tau the speculative lookup lets through (tau > 0: the remainder of a positive `local`), so step one is (+0) + c -- kept as
+// an addition, because (+0) + (-0) is +0, not -0. Three multiplications less per term; same bits.
 __device__ __forceinline__ V3 horner_row(const RowS &r, double tau) {
-    V3 bp = {0.0, 0.0, 0.0};
+    V3 bp = {0.0 + r.c[(kDiv - 1) * 3 + 0], 0.0 + r.c[(kDiv - 1) * 3 + 1], 0.0 + r.c[(kDiv - 1) * 3 + 2]};
 #pragma unroll
-    for (int k = kDiv - 1; k >= 0; --k) {
+    for (int k = kDiv - 2; k >= 0; --k) {
         bp.x = bp.x * tau + r.c[k * 3 + 0];
         bp.y = bp.y * tau + r.c[k * 3 + 1];
         bp.z = bp.z * tau + r.c[k * 3 + 2];
