@@ -779,8 +779,23 @@ template <bool NYS>
 __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
     __shared__ __attribute__((aligned(16))) double K[16 * 6];          // k[s][d] (ERK) / dk[s][0..2] (ERKNG)
     __shared__ __attribute__((aligned(16))) double red[3 * kRedRow];
+    // ERK pairs (round 6): the stage combinations are LANE-parallel. y_i = y + sum_j k_j (h A_ij) is a chain of additions in j
+    // order per component -- the reference's order -- but the products are independent: lane j forms k_j[d] * (h A_sj) for the six
+    // components, lanes 0..5 each add one component's products in j order, and the six sums are broadcast. The run-time loop it
+    // replaces paid a scalar load of A[s][j] and six LDS reads per (s, j), one after the other, on the single wave this kernel is:
+    // a third of a step. The method's tables sit in LDS (Al, Bl, Cl, El), loaded once per launch.
+    __shared__ __attribute__((aligned(16))) double Pl[16 * 6], Pe[16 * 6];
+    __shared__ __attribute__((aligned(16))) double Al[16 * 16], Bl[16], Cl[16], El[16];
     const long long i = blockIdx.x, n = a.n_craft;
     const int lane = threadIdx.x;
+    if (!NYS) {
+        const double *ga = &a.rkd->A[0][0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Al[lane * 4 + q] = ga[lane * 4 + q];
+        if (lane < 16) { Bl[lane] = a.rkd->B[lane]; Cl[lane] = a.rkd->C[lane]; El[lane] = a.rkd->E[lane]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     int status = a.status[i];
     if (status != EPH_OK && status != EPH_KNOTS_FULL && !a.retry) return;    // a failed craft stays failed until the batch is re-armed
     status = EPH_OK;
@@ -862,7 +877,7 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
                     continue;
                 }
                 if (!ok) continue;
-                const double ti = time + h * rc->C[s];
+                const double ti = time + h * (NYS ? rc->C[s] : Cl[s]);
                 double yi[6], out[6];
                 if (NYS) {
                     const double hc = h * rc->C[s];
@@ -884,13 +899,23 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
                     put_k(s, dk);
                     continue;
                 }
+                {
+                    if (lane < s) {                   // lane j: the products k_j[d] * (h A_sj)
+                        const double ha = h * Al[s * 16 + lane];
 #pragma unroll
-                for (int d = 0; d < 6; ++d) yi[d] = y[d];
-                for (int jv = 0; jv < s; ++jv) {
-                    const int j = __builtin_amdgcn_readfirstlane(jv);
-                    const double ha = h * rc->A[s][j];
+                        for (int d = 0; d < 6; ++d) Pl[lane * 6 + d] = K[lane * 6 + d] * ha;
+                    }
+                    wave_sync();
+                    // lane d < 6: y_i[d] = (..((y[d] + p_0[d]) + p_1[d]) + ..) in j order
+                    double sum = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : lane == 3 ? y[3] : lane == 4 ? y[4] : y[5];
+                    if (lane < 6) {
+                        const double *col = Pl + lane;
+#pragma unroll 4
+                        for (int j = 0; j < s; ++j) sum = sum + col[j * 6];
+                    }
+                    wave_sync();
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) yi[d] = yi[d] + K[j * 6 + d] * ha;
+                    for (int d = 0; d < 6; ++d) yi[d] = lane_bcast(sum, d);
                 }
                 ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
                 if (!ok) {                            // an Err leaves k[s] as `self.k[s].zero()` made it  explicit.rs:92
@@ -925,17 +950,29 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
                     }
                 }
             } else {
-                for (int sv = 0; sv < S; ++sv) {
-                    const int s = __builtin_amdgcn_readfirstlane(sv);
-                    const double hb = h * rc->B[s];
+                // the solution update y += sum_s k_s (h B_s) and RKEmbedded::error e = sum_s k_s (h E_s), lane-parallel like the stage
+                // combinations: lane s forms both products, lanes 0..5 add y's components, lanes 8..13 the error's, in s order
+                if (lane < S) {
+                    const double hb = h * Bl[lane], he = h * El[lane];
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) y[d] = y[d] + K[s * 6 + d] * hb;
+                    for (int d = 0; d < 6; ++d) {
+                        const double ks = K[lane * 6 + d];
+                        Pl[lane * 6 + d] = ks * hb;
+                        Pe[lane * 6 + d] = ks * he;
+                    }
                 }
-                for (int sv = 0; sv < S; ++sv) {      // RKEmbedded::error
-                    const int s = __builtin_amdgcn_readfirstlane(sv);
-                    const double he = h * rc->E[s];
+                wave_sync();
+                {
+                    const int dsel = lane & 7;
+                    double sum = lane >= 8 ? 0.0 : dsel == 0 ? y[0] : dsel == 1 ? y[1] : dsel == 2 ? y[2] : dsel == 3 ? y[3] : dsel == 4 ? y[4] : y[5];
+                    if (lane < 14 && dsel < 6) {
+                        const double *col = (lane >= 8 ? Pe : Pl) + dsel;
+#pragma unroll 4
+                        for (int sv = 0; sv < S; ++sv) sum = sum + col[sv * 6];
+                    }
+                    wave_sync();
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) e[d] = e[d] + K[s * 6 + d] * he;
+                    for (int d = 0; d < 6; ++d) { y[d] = lane_bcast(sum, d); e[d] = lane_bcast(sum, 8 + d); }
                 }
             }
             time = time + h;
