@@ -917,6 +917,9 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
 #pragma unroll
                     for (int d = 0; d < 6; ++d) yi[d] = lane_bcast(sum, d);
                 }
+#if defined(EPH_EXPERIMENTS) && defined(EPH_WAVE_RHS2)
+                { double o2[6]; (void)craft_rhs<true>(a, sg, ti + 1e-3, yi, o2, red, &lb); asm volatile("" ::"v"(o2[3]), "v"(o2[4]), "v"(o2[5])); }   // TIMING: one evaluation more per stage
+#endif
                 ok = craft_rhs<true>(a, sg, ti, yi, out, red, &lb);
                 if (!ok) {                            // an Err leaves k[s] as `self.k[s].zero()` made it  explicit.rs:92
 #pragma unroll
@@ -983,6 +986,9 @@ __global__ void __launch_bounds__(64) k_craft_wave(const CraftArgs a) {
             const double vm = fmax(fabs(e[3] / a.tol_vel), fmax(fabs(e[4] / a.tol_vel), fabs(e[5] / a.tol_vel)));
             const double err = fmax(pm, vm);
             // IController::step  mod.rs:225-243
+#if defined(EPH_EXPERIMENTS) && defined(EPH_WAVE_POW2)
+            { const double m2 = cr_pow(err * 1.0000001, -(1.0 / (double)lower)); asm volatile("" ::"v"(m2)); }   // TIMING: one pow more per attempt
+#endif
             const double m = a.fac * cr_pow(err, -(1.0 / (double)lower));
             const double c = m < a.fac_min ? a.fac_min : (m > a.fac_max ? a.fac_max : m);
             const double nh = next_h * c;
