@@ -112,6 +112,45 @@ __device__ __forceinline__ bool body_term_cached(const CraftArgs &a, LaneBody &l
     else pair_apply<false>(pair_den<false>(n2), d.x, d.y, d.z, b.mu, term.x, term.y, term.z);
     return true;
 }
+__device__ __forceinline__ unsigned div_key(double x) { return (unsigned)(__double2hiint(x) - 0x33700000); }    // in_range_div: key < 0x19000000
+// The same term with the lookup SPECULATIVE and branch-free, like the thread-per-craft kernels' locate_spec (every guarded choice of
+// body_term_cached assumed -- the lane's own reciprocal for both quotients, 32-bit segment count, in-range squared distance -- and ONE
+// ballot at the end; whatever does not hold sends the wave through body_term_cached itself, which gives the same bits). On the single
+// wave this kernel is, every branch of the guarded form is a bubble: a ship's step 32.0-32.7 -> 30.7-31.1 us (64 craft: 27.5 -> 26.1).
+__device__ __forceinline__ bool body_term_wave(const CraftArgs &a, LaneBody &lb, double t, const V3 &pos, V3 &term) {
+    const BodyEntry &b = lb.be;
+    const double local = t - b.start;
+    const double cq = ceil(div_refined(local, b.interval, lb.r));
+    const unsigned ci = (unsigned)fmin(fmax(cq, 0.0), 2147483648.0);
+    const unsigned i32 = ci == 0 ? 0u : ci - 1u;
+    const double rem = local - b.interval * (double)i32;
+    const double tau = div_refined(rem, b.interval, lb.r);
+    bool bad = !lb.b_ok | (max(div_key(local), div_key(rem)) >= 0x19000000u) | (local > b.span) |
+               ((unsigned long long)i32 >= (unsigned long long)b.npoly);
+    const long long idx = (long long)i32;
+    if (!bad && idx != lb.idx) {                      // (the lane's polynomial changed: every few hundred steps)
+        const double2 *co = reinterpret_cast<const double2 *>(a.coeffs + (b.coeff_off + idx) * kDiv * 3);
+#pragma unroll
+        for (int q = 0; q < kDiv * 3 / 2; ++q) { const double2 v = co[q]; lb.c[2 * q] = v.x; lb.c[2 * q + 1] = v.y; }
+        lb.idx = idx;
+    }
+    V3 bp = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = kDiv - 1; k >= 0; --k) {
+        bp.x = bp.x * tau + lb.c[k * 3 + 0];
+        bp.y = bp.y * tau + lb.c[k * 3 + 1];
+        bp.z = bp.z * tau + lb.c[k * 3 + 2];
+    }
+    const V3 d = sub(bp, pos);
+    const double n2 = dot(d, d);
+    pair_apply<true>(pair_den<true>(n2), d.x, d.y, d.z, b.mu, term.x, term.y, term.z);
+    bad = bad | !in_range(n2);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+        asm volatile("");
+        return body_term_cached(a, lb, t, pos, term);
+    }
+    return true;
+}
 __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
@@ -188,7 +227,6 @@ __device__ __forceinline__ V3 horner_row(const RowS &r, double tau) {
 // has a key outside it, so the sign test is implied -- t == start exactly, where local = rem = +0 is a legal numerator, takes the
 // out-of-line path), not beyond the span, and the segment inside the table (which also catches a count that was clamped at 2^31:
 // entry_fast requires npoly < 2^31).
-__device__ __forceinline__ unsigned div_key(double x) { return (unsigned)(__double2hiint(x) - 0x33700000); }    // in_range_div: key < 0x19000000
 // Returns the wave's ballot of lanes for which an assumption does NOT hold (0 = every lane fine), as the OR of one ballot per test: a
 // ballot of a single compare is the compare's own result mask, a ballot of a combined per-lane flag costs a select and a second compare.
 __device__ __forceinline__ unsigned long long locate_spec(const BodyEntry &b, double at, double &tau, unsigned &idx) {
@@ -386,7 +424,7 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
             V3 term = {0.0, 0.0, 0.0};
             bool located = true;
             if (b < a.n_bodies) {
-                if (a.n_bodies <= kTile) located = body_term_cached(a, *lb, t, pos, term);
+                if (a.n_bodies <= kTile) located = body_term_wave(a, *lb, t, pos, term);
                 else {
                     const BodyEntry be = a.bodies[b];
                     located = body_term(a, be, t, pos, term);
