@@ -128,7 +128,10 @@ __device__ __noinline__ double cr_pow(double x, double y) {
     const DD s = dd_div(DD{m - 1.0, 0.0}, dd_two_sum(m, 1.0));
     const DD s2 = dd_mul(s, s);
     // atanh(s)/s = sum_k s2^k / (2k+1), Horner over the double-double table (remainder < 2^-120)
+    // (both series fully unrolled: the table entries become literals. As run-time loops they paid a scalar-cache round trip per
+    // three terms, waited for on the spot -- half of the function's time on the single wave k_craft_wave is)
     DD sum = {eph_pow_atanh[EPH_POW_TERMS - 1].hi, eph_pow_atanh[EPH_POW_TERMS - 1].lo};
+#pragma unroll
     for (int k = EPH_POW_TERMS - 2; k >= 0; --k) sum = dd_add(dd_mul(sum, s2), DD{eph_pow_atanh[k].hi, eph_pow_atanh[k].lo});
     DD lg = dd_mul(dd_mul_d(s, 2.0), sum);
     lg = dd_add(dd_mul_d(ln2, (double)e), lg);
@@ -139,6 +142,7 @@ __device__ __noinline__ double cr_pow(double x, double y) {
     const DD r = dd_add(z, dd_neg(dd_mul_d(ln2, kf)));
     // exp(r) = sum_n r^n / n!, Horner over the double-double table, |r| <= ln2/2
     DD ex = {eph_pow_invfact[EPH_POW_TERMS - 1].hi, eph_pow_invfact[EPH_POW_TERMS - 1].lo};
+#pragma unroll
     for (int n = EPH_POW_TERMS - 2; n >= 0; --n) ex = dd_add(dd_mul(ex, r), DD{eph_pow_invfact[n].hi, eph_pow_invfact[n].lo});
     return ldexp(ex.hi + ex.lo, (int)kf);
 }
