@@ -1049,6 +1049,16 @@ static int eph_follow(eph_ephemeris *e, const std::vector<long long> &front, con
     return eph_upload_bodies(e);
 }
 
+// The host splines have changed already when the device table follows them: if the incremental update fails half way (a copy, an
+// allocation), the table is laid out afresh from the host copy once before the error is reported, so that the two do not stay apart.
+static int eph_follow_or_rebuild(eph_ephemeris *e, const std::vector<long long> &front, const std::vector<long long> &back,
+                                 const std::vector<long long> &dropped_front) {
+    const int st = eph_follow(e, front, back, dropped_front);
+    if (st == EPH_OK) return st;
+    (void)hipGetLastError();
+    return eph_rebuild(e) == EPH_OK ? EPH_OK : st;
+}
+
 // Timeline::new  ephemeris/src/propagators/spacecraft.rs:129-152: stable sort by start, coast segments in the gaps,
 // from Epoch::MIN to Epoch::MAX; appended to `segs`
 static void timeline_new(long long nburns, const double *burn_start, const double *burn_end, const double *burn_acc,
@@ -1129,7 +1139,7 @@ int32_t eph_ephemeris_append(eph_ephemeris *e, const eph_solution *tail, int32_t
             }
         }
         e->revision += 1;
-        return eph_follow(e, front, back, none);
+        return eph_follow_or_rebuild(e, front, back, none);
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 // UniformSpline::clear_before (after = 0, trajectory.rs:536-542) / clear_after (after != 0, :544-549) on body's spline or on all (body < 0)
@@ -1148,7 +1158,7 @@ int32_t eph_ephemeris_clear(eph_ephemeris *e, int32_t body, double at, int32_t a
             else { u.clear_before(at); dropped[b] = (long long)(before - u.polynomials.size()); }
         }
         e->revision += 1;
-        return eph_follow(e, none, none, dropped);
+        return eph_follow_or_rebuild(e, none, none, dropped);
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 // CelestialTrajectory::merge  ephemeris_explorer/src/dynamics/celestial.rs:198-204 (Forward: clear_after(propagated.start()) then
@@ -1198,7 +1208,7 @@ int32_t eph_ephemeris_merge(eph_ephemeris *e, const eph_solution *propagated, in
             }
         }
         e->revision += 1;
-        return eph_follow(e, front, back, dropped);
+        return eph_follow_or_rebuild(e, front, back, dropped);
     } catch (const std::bad_alloc &) { return EPH_ERR_OUT_OF_MEMORY; } catch (...) { return EPH_ERR_HIP; }
 }
 int32_t eph_ephemeris_info(const eph_ephemeris *e, int32_t body, double *start, double *interval, int64_t *npoly, uint64_t *revision) {

@@ -168,3 +168,22 @@ def test_integration_shims_use_only_declared_names():
     called = {n for n in used if n in fns}
     assert len(called) >= 50                         # the shims bind most of the boundary (94 - 7 hooks = 87 functions)
     assert "never been compiled" in text or "never met" in text     # section 0 says so in one line
+
+
+def test_live_ephemeris_entry_points_refuse_null_handles(product_lib):
+    """ABI 3's new entry points return EPH_ERR_BAD_ARGUMENT for missing handles before they touch a device (no compute without a GPU)."""
+    import ctypes as C
+    L = product_lib._lib()
+    bad = product_lib.ERR_BAD_ARGUMENT
+    f = C.c_int32(7)
+    n = C.c_uint64(0)
+    h = C.c_void_p()
+    assert L.eph_ephemeris_append(None, None, 1) == bad
+    assert L.eph_ephemeris_merge(None, None, 1) == bad
+    assert L.eph_ephemeris_clear(None, -1, 0.0, 0) == bad
+    assert L.eph_ephemeris_info(None, -1, None, None, None, None) == bad
+    assert L.eph_ephemeris_is_valid_at(None, 0.0, C.byref(f)) == bad and f.value == 7
+    assert L.eph_ephemeris_export(None, None, 0, C.byref(n)) == bad
+    assert L.eph_ephemeris_import(None, 0, C.byref(h)) == bad and not h.value
+    assert L.eph_ephemeris_import((C.c_char * 8)(), 8, C.byref(h)) == bad and not h.value      # shorter than an image header
+    assert L.eph_craft_batch_retry_failed(None) == bad
