@@ -15,7 +15,10 @@
  *  - a handle is not thread-safe; distinct handles may be used from distinct threads (the reference runs its forward and
  *    backward propagators and one task per ship concurrently, ephemeris_explorer/src/prediction.rs:385-391). Each handle
  *    owns one HIP stream on the device that was current when it was created. The one handle meant to be SHARED between
- *    threads is eph_ephemeris: it carries the reference's RwLock (see there).
+ *    threads is eph_ephemeris: it carries the reference's RwLock (see there). A handle passed as `const` is only read: an
+ *    eph_solution that no thread modifies may be read by several at once (Rust's &T of a Sync type). Handles may be created on
+ *    one thread, used on another and destroyed on a third (the reference's propagators are Send: the task pool moves them). The
+ *    library holds no process-wide lock across a device synchronisation (examples/threads.cpp, tests/test_gpu_threads.py).
  *  - results are bit-identical to the reference algorithm's f64 arithmetic (same operation order, no FMA
  *    contraction); see DESIGN.md for the one unpinned formula (the `particular` pair interaction).
  */
