@@ -6,6 +6,8 @@ from a fixed seed (the failures, if any, are reproducible by their seed), every 
   * spacecraft: random embedded pair, tolerances over twelve decades (unequal for position and velocity), h_init, h_max, controller
     factors, n_max small enough to trip now and then, up to four burns in inertial and body-relative TNB frames, propagation in
     random legs -- status, attempt counter, next_h, state and every knot (runge_kutta/mod.rs:225-243,414-439; spacecraft.rs:598-615)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,7 +149,12 @@ def simple_system(gpu):
 PAIRS = ["CashKarp45", "DormandPrince54", "DormandPrince87", "Fehlberg45", "Tsitouras75", "Verner87", "Verner98", "Fine45"]
 
 
-@pytest.mark.parametrize("seed", range(64))
+# EPH_FUZZ_CRAFT_SEEDS="first:count" widens the draw for soak runs (default 0:64); EPH_CRAFT_FORM / EPH_CRAFT_QUEUE / EPH_CRAFT_SORT pick the
+# sweep kernel as everywhere (the default for these one-to-five-craft batches is the wave-per-craft kernel)
+_FIRST, _COUNT = (int(x) for x in os.environ.get("EPH_FUZZ_CRAFT_SEEDS", "0:64").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
 def test_craft_random_scenarios(gpu, simple_system, seed):
     s, eph, osol = simple_system
     ship = load_ship(SYSTEMS / "full_solar_system_2433282.5" / "ships" / "Mars Transfer Ship.json")
@@ -189,6 +196,11 @@ def test_craft_random_scenarios(gpu, simple_system, seed):
     for i, c in enumerate(crafts):
         cs = c.state()
         what = f"seed {seed} craft {i} ({method}, tol {p.tol_position:.1e}/{p.tol_velocity:.1e}, n_max {p.n_max}, {len(blist[i])} burns)"
+        if st["status"][i] == gpu.KNOTS_FULL:          # (a soak seed whose craft takes > 30 000 steps, e.g. 4617: the slab's knots are the
+            kt, kp, kv = batch.knots(i)                #  oracle's first 30 000 -- the test does not drain slabs)
+            ot, op, ov = c.knots()
+            assert len(kt) == 30000 < len(ot) and same(kt, ot[:30000]) and same(kp, op[:30000]) and same(kv, ov[:30000]), what
+            continue
         assert st["status"][i] == ost[i], f"{what}: status {st['status'][i]} vs {ost[i]}"
         assert st["attempts"][i] == cs["attempts"] and st["steps"][i] == cs["steps"], what
         assert bits(gs["t"][i]) == bits(cs["t"]) and bits(gs["next_h"][i]) == bits(cs["next_h"]), what
