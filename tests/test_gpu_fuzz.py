@@ -30,7 +30,12 @@ FIXED_METHODS = ["QuinlanTremaine12", "Stormer13", "BlanesMoan6B", "BlanesMoan11
                  "McLachlanSS17", "Pefrl", "Ruth"]
 
 
-@pytest.mark.parametrize("seed", range(40))
+def _seeds(var, default):
+    first, count = (int(x) for x in os.environ.get(var, default).split(":"))
+    return range(first, first + count)
+
+
+@pytest.mark.parametrize("seed", _seeds("EPH_FUZZ_NBODY_SEEDS", "0:40"))      # ("first:count": wider draws for soak runs)
 def test_nbody_random_scenarios(gpu, seed):
     rng = np.random.default_rng(7000 + seed)
     n = int(rng.choice([2, 3, 5, 17, 32, 33, 47, 64, 65, 130, 300, 513, 700, 1100, 2050]))
@@ -81,7 +86,7 @@ def test_nbody_random_scenarios(gpu, seed):
         assert same(tg_.state()[0], to_.state()[0]) and same(tg_.state()[1], to_.state()[1])
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", _seeds("EPH_FUZZ_PROP_SEEDS", "0:20"))
 def test_propagator_random_scenarios(gpu, seed):
     """NBodyPropagator with the SplineInterpolators solout (nbody.rs:65-235,371-400; celestial.rs:19-135): random systems, sample
     counts and polynomial degrees per body, both directions, the two multistep methods, step / step_n / step_to / take_solution in
