@@ -65,6 +65,31 @@ def test_cli_run_matches_the_restatement(gpu):
     assert seen == {"Mars Transfer Ship": 0, "Moon Transfer Ship": 0, "Voyager Style Ship": orc.EVAL_FAILED}
 
 
+def test_cli_live_flow_equals_the_static_one(gpu):
+    """`--live`: the app's own flow -- the bodies' task sends a snapshot every 30 days, each is merged into the LIVE device table,
+    one task per ship chases it (three ship threads + the N-body thread, one shared eph_ephemeris): knots, events and statuses equal
+    the static run's (ships against the finished table), which test_cli_run_matches_the_restatement pins to the oracle."""
+    from ephemeris_explorer_amd import cli
+    sysdir = SYSTEMS / "full_solar_system_2433282.5"
+    static = cli.run(sysdir, 2.0, backward=False)
+    for rep in range(2):
+        live = cli.run_live(sysdir, 2.0, chunk_days=30.0)
+        assert live.live_revision >= 23                                  # two years in 30-day snapshots, the first seeds the table
+        for b in range(static.system.n):
+            assert live.forward.info(b) == static.forward.info(b)
+            assert np.array_equal(bits(live.forward.coeffs(b)[0]), bits(static.forward.coeffs(b)[0]))
+        assert [s[0].name for s in live.ships] == [s[0].name for s in static.ships]
+        for (ship, _, bl, skip_l), (_, _, bs, skip_s) in zip(live.ships, static.ships):
+            assert skip_l is None and skip_s is None
+            assert bl.status()["status"][0] == bs.status()["status"][0], ship.name
+            for x, y in zip(bl.knots(0), bs.knots(0)):
+                assert np.array_equal(bits(x), bits(y)), (rep, ship.name)
+            (tl, bl_), (al, dl, abl, akl) = bl.events(0)
+            (ts, bs_), (as_, ds, abs_, aks) = bs.events(0)
+            assert np.array_equal(bits(tl), bits(ts)) and np.array_equal(bl_, bs_) and np.array_equal(bits(al), bits(as_))
+            assert np.array_equal(bits(dl), bits(ds)) and np.array_equal(abl, abs_) and np.array_equal(akl, aks)
+
+
 def test_cli_fine45_ship(gpu, tmp_path):
     """A ships/*.json selecting the app's ERKNG integrator (Fine45, dynamics/spacecraft.rs:797) goes through the headless
     flow like any other (it used to be skipped)."""
