@@ -408,12 +408,19 @@ __device__ __noinline__ BurnAcc burn_acceleration_cold(const BodyEntry *bodies_b
     return BurnAcc{man.x, man.y, man.z, ok ? 1 : 0};
 }
 
+// What the thread-per-craft kernels keep of the current timeline segment in registers: whether it is a burn, and where the rest is
+// (the thrust, its frame and the bounds are read back in the burn branch only: ten registers less across every body loop; the
+// segment's end is the kernels' `bound`)
+struct SegLight { int is_burn; const SegmentDev *full; };
+__device__ __forceinline__ const SegmentDev &seg_full(const SegmentDev &sg) { return sg; }
+__device__ __forceinline__ SegmentDev seg_full(const SegLight &sg) { return *sg.full; }
+
 // FirstOrderODE::eval for SpacecraftModel (spacecraft.rs:297-308). Returns false for EvalFailed.
 // WAVE = false: one thread per spacecraft, the bodies in a loop. WAVE = true: one WAVE per spacecraft (every lane
 // carries the same craft state): lane b evaluates body b, the terms go through LDS and lanes 0..2 add them in body
 // order -- the same chain of f64 additions -- then the sum is broadcast. `red` = 3 x kRedRow doubles of LDS.
-template <bool WAVE>
-__device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &sg, double t, const double (&y)[6],
+template <bool WAVE, typename Seg>
+__device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const Seg &sg, double t, const double (&y)[6],
                                           double (&dy)[6], double *red, LaneBody *lb = nullptr) {
     const V3 pos = {y[0], y[1], y[2]}, vel = {y[3], y[4], y[5]};
     V3 acc = {0.0, 0.0, 0.0};
@@ -466,10 +473,11 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
         // (thread-per-craft kernels: out of line -- the frame arithmetic with its three IEEE reciprocal square roots, inlined once per
         // stage, was 33 of the 13-stage kernel's 81 KB of code, and burns are minutes of a sweep's days. No measurable difference on
         // a sweep without burns: 25.5-25.6 against 25.6-25.7 ms -- the instruction cache was not the limit.)
+        const SegmentDev f = seg_full(sg);
         if (WAVE) {
-            if (!burn_acceleration(a.bodies_by_index, a.coeffs, a.ncoef, sg.ref, sg.ax, sg.ay, sg.az, t, pos, vel, man)) return false;
+            if (!burn_acceleration(a.bodies_by_index, a.coeffs, a.ncoef, f.ref, f.ax, f.ay, f.az, t, pos, vel, man)) return false;
         } else {
-            const BurnAcc r = burn_acceleration_cold(a.bodies_by_index, a.coeffs, a.ncoef, sg.ref, sg.ax, sg.ay, sg.az, t, pos.x, pos.y, pos.z,
+            const BurnAcc r = burn_acceleration_cold(a.bodies_by_index, a.coeffs, a.ncoef, f.ref, f.ax, f.ay, f.az, t, pos.x, pos.y, pos.z,
                                                      vel.x, vel.y, vel.z);
             if (!r.ok) return false;
             man = V3{r.x, r.y, r.z};
@@ -490,7 +498,13 @@ __device__ __forceinline__ bool craft_rhs(const CraftArgs &a, const SegmentDev &
 // acceleration halves in registers. 13 stages x 3 x 512 B = 19 968 B per wave; the CU's 160 KB hold the eight waves of two per SIMD.
 // A 16-stage pair keeps its last three velocity halves in registers (kCraftLdsStages). LDS traffic is ~350 8-byte accesses per lane
 // and attempt against ~31 000 FP64 instructions: nothing. Storage only -- every operand and every operation is the reference's.
-constexpr int kCraftLdsStages = 13;
+// (tuning: -DEPH_CRAFT_LDS_STAGES=8 -DEPH_CRAFT_OCC2_WAVES=3 holds the big-batch kernel to THREE waves per SIMD -- 168 VGPRs, 12 KB of
+// LDS per wave, the compiler spilling the rest: 144 spilled VGPRs, 25.6-25.8 against 24.9-25.0 ms, 3 % slower; round 5's same
+// experiment on the old structure: 16 % slower)
+#ifndef EPH_CRAFT_LDS_STAGES
+#define EPH_CRAFT_LDS_STAGES 13
+#endif
+constexpr int kCraftLdsStages = EPH_CRAFT_LDS_STAGES;
 template <int S, bool NYS> struct CraftStages {
     static constexpr int LS = NYS ? 0 : (S < kCraftLdsStages ? S : kCraftLdsStages);      // stages whose velocity half is in LDS
     static constexpr int RS = NYS ? 0 : S - LS;                                            // ... in registers
@@ -537,7 +551,10 @@ template <int S, bool NYS> struct CraftStages {
 // time scale of their orbits (craft_sort: a.perm; the knot slabs keep lane columns). k_craft_queue below is the form for
 // heterogeneous batches that were not dealt (craft_launch chooses).
 template <int S, bool FSAL, bool NYS = false, int OCC = 1>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+#ifndef EPH_CRAFT_OCC2_WAVES
+#define EPH_CRAFT_OCC2_WAVES 2
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC == 2 ? EPH_CRAFT_OCC2_WAVES : OCC, OCC == 2 ? EPH_CRAFT_OCC2_WAVES : OCC)))
 k_craft_propagate(const CraftArgs a) {
     const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= a.n_craft) return;
@@ -555,8 +572,8 @@ k_craft_propagate(const CraftArgs a) {
     int cur = a.cur_seg[i], nk = a.nknots[i];
     double last_knot = a.last_knot_t[i];
     const SegmentDev *segs = a.segs + a.seg_off[i];
-    SegmentDev sg = segs[cur];
-    double bound = sg.end;
+    SegLight sg{segs[cur].is_burn, segs + cur};
+    double bound = segs[cur].end;
     EPH_CRAFT_STAGE_STORAGE
     if (FSAL) { EPH_CRAFT_LOAD_FSAL(i) }
     const int lower = a.rk.order < a.rk.order_embedded ? a.rk.order : a.rk.order_embedded;
@@ -565,10 +582,10 @@ k_craft_propagate(const CraftArgs a) {
     while (!(last_knot >= a.t_end) && !(a.step_limit && taken >= a.step_limit)) {   // has_reached: solution.end() >= time
         if (nk >= a.max_knots) { status = EPH_KNOTS_FULL; break; }
         // SpacecraftPropagator::step: advance_timeline + reset_integrator  spacecraft.rs:606-609
-        if (time >= sg.end) {
+        if (time >= bound) {                          // (bound = the segment's end)
             cur += 1;
-            sg = segs[cur];
-            bound = sg.end;
+            sg = SegLight{segs[cur].is_burn, segs + cur};
+            bound = segs[cur].end;
             next_h = a.h_init;
             n_att = 0;
             rk_i = 0;
